@@ -1,0 +1,254 @@
+"""CPU oracle for the Variational-FM ELBO step.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; the product package `vae_amd` never does (its ops fail
+loudly when the HIP library is missing).
+
+Two restatements of the per-batch hot path of the reference
+(`/root/reference/vfm-torch.py`, class `CF` + loss line):
+
+* `reference_shaped_*` -- torch-CPU, the SAME op graph as the reference:
+  `torch.unique` (:190-192) -> embedding lookups of the unique rows (:207-208)
+  -> `Normal(loc, |scale|)` samplers (:200-203,212-215,223-226) -> `rsample`
+  (:238-241) -> expand to rows with the inverse index, sum / prod over the two
+  fields (:244-245) -> likelihood (:264-270) -> `kl_divergence` to N(0,1)
+  (:290,295,322) -> occurrence re-weighting with the `<= N` test (:298-317)
+  -> loss `-log_prob(y).mean()*nb_train + kl` (:359) -> autograd backward
+  (:368-369) -> dense Adam (:339,370).  This is the function `bench.py` times
+  on the host cores as `cpu_baseline` (kind "port").
+
+* `rowwise_elbo` -- numpy float64, the row-wise identity the HIP kernels
+  implement: every term is a sum over batch rows,
+  general number of fields F, general id groups, analytic gradients.
+
+Parity pin: both are checked in `tests/test_oracle.py` against the golden
+vectors in `tests/golden/*.npz`, which were produced by running the
+reference's own `CF` class (lifted with `ast` by `tools/make_golden.py`) in the
+build container.  The reference repo itself has no tests / known answers for
+this path, so those vectors are the pin.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch import distributions
+
+LOG_SQRT_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+# --------------------------------------------------------------------------
+# (a) reference-shaped torch-CPU restatement
+# --------------------------------------------------------------------------
+def make_params(T, d, dtype=torch.float32, seed=42, alpha=None):
+    """Parameters of `CF.__init__` (vfm-torch.py:133-153): alpha~U(0,1), global
+    bias N(0, 1) posterior init (mean 0, scale 1), Embedding tables ~N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    P = {
+        "alpha": torch.rand(1, generator=g) if alpha is None else torch.tensor([float(alpha)]),
+        "global_bias_mean": torch.zeros(1),
+        "global_bias_scale": torch.ones(1),
+        "bias_params": torch.randn(T, 2, generator=g),
+        "entity_params": torch.randn(T, 2 * d, generator=g),
+    }
+    return {k: v.to(dtype).requires_grad_(True) for k, v in P.items()}
+
+
+def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None):
+    """One `CF.forward` (vfm-torch.py:189-324), S = 1 variational sample.
+
+    eps: None -> draw with rsample exactly like the reference (RNG order eps0,
+    eps_w[U], eps_v[U,d] over the SORTED unique ids); or a tuple
+    (eps0[1], eps_w[U], eps_v[U,d]) to replay recorded draws.
+    Returns (likelihood distribution with batch shape [1,B], kl_term[1])."""
+    uniq, pos, cnt = torch.unique(x, return_inverse=True, return_counts=True)
+    users, cnt_u = torch.unique(x[:, 0], return_counts=True)
+    items, cnt_i = torch.unique(x[:, 1], return_counts=True)
+    prior = distributions.Normal(0, 1)
+
+    theta = torch.nn.functional.embedding(uniq, P["bias_params"])
+    phi = torch.nn.functional.embedding(uniq, P["entity_params"])
+    d = phi.shape[1] // 2
+    q0 = distributions.Normal(P["global_bias_mean"], torch.abs(P["global_bias_scale"]))
+    qw = distributions.Normal(theta[:, 0], torch.abs(theta[:, 1]))
+    qv = distributions.Normal(loc=phi[:, :d], scale=torch.abs(phi[:, d:]))
+
+    if eps is None:
+        w0, w, z = q0.rsample((1,)), qw.rsample((1,)), qv.rsample((1,))
+    else:
+        e0, ew, ev = (torch.as_tensor(e, dtype=phi.dtype) for e in eps)
+        w0 = (q0.loc + e0.reshape(1, 1) * q0.scale)
+        w = (qw.loc + ew.reshape(1, -1) * qw.scale)
+        z = (qv.loc + ev.reshape(1, -1, d) * qv.scale)
+
+    first = w[:, pos].sum(axis=2).mean(axis=0).squeeze()
+    second = z[:, pos].prod(axis=2).sum(axis=2).mean(axis=0)
+    logits = w0 + first + second
+    if output == "reg":
+        lik = distributions.Normal(logits, torch.sqrt(1 / torch.abs(P["alpha"])))
+    else:
+        lik = distributions.Bernoulli(logits=logits)
+
+    kl_e = distributions.kl_divergence(qw, prior) + distributions.kl_divergence(qv, prior).sum(axis=1)
+    occ = nb_occ[uniq]
+    w_user = (cnt_u / nb_occ[users]).sum(axis=0)
+    w_item = (cnt_i / nb_occ[items]).sum(axis=0)
+    kl = (kl_e * (cnt / occ) * ((uniq <= N) * N / w_user + (uniq > N) * M / w_item)).sum(axis=0)
+    return lik, distributions.kl_divergence(q0, prior) + kl
+
+
+def reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output="reg", eps=None):
+    lik, kl = reference_shaped_forward(P, x, nb_occ, N, M, output, eps)
+    loss = -lik.log_prob(y.to(kl.dtype)).mean() * nb_train + kl          # vfm-torch.py:359
+    return loss, lik, kl
+
+
+def reference_shaped_step(P, opt, x, y, nb_occ, N, M, nb_train, output="reg", eps=None):
+    """forward + loss + backward + optimiser step (vfm-torch.py:353-370)."""
+    loss, lik, _ = reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output, eps)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss.detach(), lik.mean.detach()
+
+
+# --------------------------------------------------------------------------
+# (b) row-wise float64 restatement (what the HIP kernels compute)
+# --------------------------------------------------------------------------
+def group_of(ids, group_hi):
+    """Group of an entity id: first g with id < group_hi[g].  The reference's two
+    groups are `id <= N` and `id > N` (vfm-torch.py:316) -> group_hi = [N+1, T]."""
+    return np.searchsorted(np.asarray(group_hi), ids, side="right")
+
+
+def batch_norms(x, nb_occ):
+    """W_f = sum_r 1/occ(x[r,f]) per COLUMN f (vfm-torch.py:305-306: the
+    normalisers are built from the unique values of each column)."""
+    return (1.0 / nb_occ[x].astype(np.float64)).sum(axis=0)
+
+
+def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_v,
+                 output="reg", W=None, B_global=None, want_grads=True):
+    """Row-wise ELBO + analytic gradients, float64.
+
+    P: dict of numpy arrays (alpha[1], global_bias_mean[1], global_bias_scale[1],
+       bias_params[T,2], entity_params[T,2d]).
+    x [B,F] int, y [B], nb_occ [T] int; eps_w [T], eps_v [T,d] are indexed BY ENTITY ID
+    (one draw per entity per batch, shared by all rows that contain it).
+    group_hi [G] exclusive id upper bounds, group_n [G] the n_g multipliers (N, M);
+    column f's normaliser W_f divides group f's KL sum (G == F).
+    W / B_global: batch-global normalisers / row count when `x` is only a shard."""
+    f8 = np.float64
+    x = np.asarray(x)
+    B, F = x.shape
+    Bg = B if B_global is None else B_global
+    ent = np.asarray(P["entity_params"])
+    bia = np.asarray(P["bias_params"])
+    d = ent.shape[1] // 2
+    alpha, m0, s0 = (float(np.asarray(P[k]).reshape(-1)[0])
+                     for k in ("alpha", "global_bias_mean", "global_bias_scale"))
+    eps0 = float(np.asarray(eps0).reshape(-1)[0])
+    eps_w = np.asarray(eps_w, f8)
+    eps_v = np.asarray(eps_v, f8)
+    group_n = np.asarray(group_n, f8)
+    inv_occ = 1.0 / nb_occ.astype(f8)
+    if W is None:
+        W = batch_norms(x, nb_occ)
+    W = np.asarray(W, f8)
+    G = len(group_n)
+    assert G == F == len(W)
+
+    bx, ex = bia[x].astype(f8), ent[x].astype(f8)       # gather first, then widen
+    mu_w, s_w = bx[..., 0], bx[..., 1]                  # [B,F]
+    mu_v, s_v = ex[..., :d], ex[..., d:]                # [B,F,d]
+    sg_w, sg_v = np.abs(s_w), np.abs(s_v)
+    ew, ev = eps_w[x], eps_v[x]
+    w = mu_w + sg_w * ew
+    z = mu_v + sg_v * ev
+    w0 = m0 + abs(s0) * eps0
+    sz = z.sum(axis=1)                                   # [B,d]
+    q = 0.5 * ((sz * sz).sum(axis=1) - (z * z).sum(axis=(1, 2)))
+    pred = w0 + w.sum(axis=1) + q
+
+    a = abs(alpha)
+    if output == "reg":
+        ll = -0.5 * a * (y - pred) ** 2 + 0.5 * math.log(a) - LOG_SQRT_2PI
+        dll = a * (y - pred)
+        mean = pred
+    else:
+        ll = y * pred - np.logaddexp(0.0, pred)
+        mean = 1.0 / (1.0 + np.exp(-pred))
+        dll = y - mean
+
+    kl_w = 0.5 * (sg_w ** 2 + mu_w ** 2 - 1.0) - np.log(sg_w)
+    kl_v = (0.5 * (sg_v ** 2 + mu_v ** 2 - 1.0) - np.log(sg_v)).sum(axis=2)
+    kl_e = kl_w + kl_v                                   # [B,F] per occurrence
+    grp = group_of(x, group_hi)                          # [B,F]
+    io = inv_occ[x]
+    S = np.zeros(G, f8)
+    np.add.at(S, grp.reshape(-1), (kl_e * io).reshape(-1))
+    kl0 = 0.5 * (s0 * s0 + m0 * m0 - 1.0) - math.log(abs(s0))
+    cscale = group_n / W                                 # n_g / W_g
+    kl = kl0 + (cscale * S).sum()
+    ll_sum = ll.sum()
+    loss = -(nb_train / Bg) * ll_sum + kl
+    out = {"pred": pred, "mean": mean, "ll_sum": ll_sum, "S": S, "W": W, "kl0": kl0,
+           "kl": kl, "loss": loss}
+    if not want_grads:
+        return out
+
+    g = -(nb_train / Bg) * dll                           # dloss/dpred  [B]
+    c = cscale[grp] * io                                 # [B,F]
+    g_bias = np.zeros(bia.shape, f8)
+    g_ent = np.zeros(ent.shape, f8)
+    np.add.at(g_bias[:, 0], x, g[:, None] + c * mu_w)
+    np.add.at(g_bias[:, 1], x, np.sign(s_w) * (g[:, None] * ew + c * (sg_w - 1.0 / sg_w)))
+    other = sz[:, None, :] - z                           # sum over the other fields
+    gz = g[:, None, None] * other
+    gm = gz + c[:, :, None] * mu_v
+    gs = np.sign(s_v) * (gz * ev + c[:, :, None] * (sg_v - 1.0 / sg_v))
+    np.add.at(g_ent, x.reshape(-1), np.concatenate([gm, gs], axis=2).reshape(B * F, 2 * d))
+    gsum = g.sum()
+    out["g_global_bias_mean"] = np.array([gsum + m0])
+    out["g_global_bias_scale"] = np.array([np.sign(s0) * (eps0 * gsum + abs(s0) - 1.0 / abs(s0))])
+    if output == "reg":
+        out["g_alpha"] = np.array([np.sign(alpha) * (nb_train / Bg) *
+                                   (0.5 * (y - pred) ** 2 - 0.5 / a).sum()])
+    else:
+        out["g_alpha"] = np.zeros(1)
+    out["g_bias_params"] = g_bias
+    out["g_entity_params"] = g_ent
+    out["g_row"] = g
+    return out
+
+
+def pairwise_second_order(z):
+    """Explicit sum_{f<g} <z_f, z_g> for z [B,F,d] -- the identity the FM trick
+    1/2((sum z)^2 - sum z^2) must satisfy (vfm.py:491-493, vfm-tomasrch.py:379-393)."""
+    B, F, d = z.shape
+    acc = np.zeros(B)
+    for f in range(F):
+        for g in range(f + 1, F):
+            acc += (z[:, f] * z[:, g]).sum(axis=1)
+    return acc
+
+
+def adam_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update (defaults of vfm-torch.py:339), numpy.
+    t is the 1-based step count."""
+    m[:] = b1 * m + (1 - b1) * g
+    v[:] = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    p[:] = p - (lr / bc1) * m / (np.sqrt(v) / math.sqrt(bc2) + eps)
+
+
+def scatter_eps(T, d, uniq, eps_w_u, eps_v_u, dtype=np.float32):
+    """Golden fixtures store eps over the sorted unique ids of the batch; the
+    kernels (and `rowwise_elbo`) index eps by entity id."""
+    ew = np.zeros(T, dtype)
+    ev = np.zeros((T, d), dtype)
+    ew[uniq] = eps_w_u
+    ev[uniq] = eps_v_u
+    return ew, ev

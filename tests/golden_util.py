@@ -1,0 +1,71 @@
+"""Helpers to read the golden fixtures written by tools/make_golden.py."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+SINGLE_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20", "ml100k_class_d20",
+                "ml20m_reg_d128"]
+F64_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20"]
+
+PARAM_KEYS = ("alpha", "global_bias_mean", "global_bias_scale", "bias_params", "entity_params")
+
+
+class Case:
+    """One single-step fixture with dense tables rebuilt (fixtures of big tables
+    only store the rows the batch touches)."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        self.name = name
+        self.N, self.M, self.d = int(z["N"]), int(z["M"]), int(z["d"])
+        self.T = self.N + self.M
+        self.nb_train = int(z["nb_train"])
+        self.output = str(z["output"])
+        self.x, self.y, self.nb_occ = z["x"], z["y"], z["nb_occ"]
+        self.uniq = z["uniq"]
+        self.sparse = "sparse_rows" in z.files
+        self.group_hi = np.array([self.N + 1, self.T], dtype=np.int64)   # `<= N` quirk
+        self.group_n = np.array([self.N, self.M], dtype=np.float64)
+
+    def params(self, dtype=np.float32):
+        P = {k: self.z["p_" + k].astype(dtype) for k in PARAM_KEYS}
+        if self.sparse:
+            rng = np.random.default_rng(123)
+            for k, w in (("bias_params", 2), ("entity_params", 2 * self.d)):
+                full = rng.standard_normal((self.T, w)).astype(dtype)
+                full[self.uniq] = P[k]
+                P[k] = full
+        return P
+
+    def eps(self, tag="f32", dtype=None):
+        """eps0[1], eps_w[T], eps_v[T,d] scattered to entity-id order."""
+        z = self.z
+        dt = dtype or z[f"{tag}_eps_v"].dtype
+        ew = np.zeros(self.T, dt)
+        ev = np.zeros((self.T, self.d), dt)
+        ew[self.uniq] = z[f"{tag}_eps_w"]
+        ev[self.uniq] = z[f"{tag}_eps_v"]
+        return z[f"{tag}_eps0"].astype(dt), ew, ev
+
+    def eps_uniq(self, tag="f32"):
+        z = self.z
+        return z[f"{tag}_eps0"], z[f"{tag}_eps_w"], z[f"{tag}_eps_v"]
+
+    def expected(self, key, tag="f32"):
+        v = self.z[f"{tag}_{key}"]
+        if self.sparse and key in ("g_bias_params", "g_entity_params"):
+            full = np.zeros((self.T, v.shape[1]), v.dtype)
+            full[self.uniq] = v
+            return full
+        return v
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    den = max(np.abs(b).max(), 1e-30)
+    return np.abs(a - b).max() / den

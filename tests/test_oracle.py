@@ -1,0 +1,192 @@
+"""CPU: the oracle (oracle/vfm_oracle.py) against the golden vectors produced by the
+reference's own CF class (tools/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Case, SINGLE_CASES, F64_CASES, PARAM_KEYS, rel_err
+from oracle import vfm_oracle as O
+
+GRADS = ("g_alpha", "g_global_bias_mean", "g_global_bias_scale", "g_bias_params",
+         "g_entity_params")
+
+
+def _torch_params(P, dtype):
+    return {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in P.items()}
+
+
+@pytest.mark.parametrize("name", SINGLE_CASES)
+def test_reference_shaped_f32(name):
+    c = Case(name)
+    P = _torch_params(c.params(), torch.float32)
+    loss, lik, kl = O.reference_shaped_loss(
+        P, torch.tensor(c.x), torch.tensor(c.y), torch.tensor(c.nb_occ), c.N, c.M,
+        c.nb_train, c.output, eps=c.eps_uniq("f32"))
+    loss.backward()
+    assert rel_err(loss.detach().numpy(), c.expected("loss")) < 1e-6
+    assert rel_err(kl.detach().numpy(), c.expected("kl")) < 1e-6
+    assert rel_err(lik.mean.detach().numpy().reshape(-1), c.expected("pred")) < 1e-6
+    for g in GRADS:
+        got = P[g[2:]].grad
+        got = np.zeros(1, np.float32) if got is None else got.numpy()
+        assert rel_err(got, c.expected(g)) < 1e-5, g
+
+
+@pytest.mark.parametrize("name", F64_CASES)
+def test_reference_shaped_f64(name):
+    c = Case(name)
+    P = _torch_params(c.params(np.float64), torch.float64)
+    loss, lik, kl = O.reference_shaped_loss(
+        P, torch.tensor(c.x), torch.tensor(c.y), torch.tensor(c.nb_occ), c.N, c.M,
+        c.nb_train, c.output, eps=c.eps_uniq("f64"))
+    loss.backward()
+    assert rel_err(loss.detach().numpy(), c.expected("loss", "f64")) < 1e-12
+    for g in GRADS:
+        got = P[g[2:]].grad
+        got = np.zeros(1) if got is None else got.numpy()
+        assert rel_err(got, c.expected(g, "f64")) < 1e-11, g
+
+
+@pytest.mark.parametrize("name", F64_CASES)
+def test_rowwise_f64(name):
+    """Row-wise identity == the reference's unique-based form.  Residual: the
+    reference forms cnt/occ in fp32 even for a double model (int64/int64 -> fp32)."""
+    c = Case(name)
+    e0, ew, ev = c.eps("f64")
+    r = O.rowwise_elbo(c.params(np.float64), c.x, c.y.astype(np.float64), c.nb_occ,
+                       c.group_hi, c.group_n, c.nb_train, e0, ew, ev, c.output)
+    assert rel_err(r["loss"], c.expected("loss", "f64")) < 1e-7
+    assert rel_err(r["kl"], c.expected("kl", "f64")) < 1e-6
+    pred = r["pred"] if c.output == "reg" else r["mean"]
+    assert rel_err(pred, c.expected("pred", "f64")) < 1e-12
+    for g in GRADS:
+        assert rel_err(r[g], c.expected(g, "f64")) < 1e-6, g
+
+
+@pytest.mark.parametrize("name", SINGLE_CASES)
+def test_rowwise_vs_f32_golden(name):
+    """fp64 row-wise restatement on the fp32 inputs vs the reference's fp32 outputs:
+    bounds the fp32 rounding of the reference itself (tolerance budget for the kernels)."""
+    c = Case(name)
+    e0, ew, ev = c.eps("f32")
+    r = O.rowwise_elbo(c.params(), c.x, c.y.astype(np.float64), c.nb_occ,
+                       c.group_hi, c.group_n, c.nb_train, e0, ew, ev, c.output)
+    assert rel_err(r["loss"], c.expected("loss")) < 2e-6
+    pred = r["pred"] if c.output == "reg" else r["mean"]
+    assert rel_err(pred, c.expected("pred")) < 1e-5
+    for g in GRADS:
+        assert rel_err(r[g], c.expected(g)) < 2e-5, g
+
+
+def test_quirk_case_contains_boundary_id():
+    c = Case("quirk_reg_d8")
+    assert (c.x[:, 1] == c.N).any()
+    # with the "clean" grouping (id < N) the loss must differ -> the quirk is exercised
+    e0, ew, ev = c.eps("f64")
+    P = c.params(np.float64)
+    a = O.rowwise_elbo(P, c.x, c.y, c.nb_occ, c.group_hi, c.group_n, c.nb_train, e0, ew, ev,
+                       want_grads=False)["loss"]
+    b = O.rowwise_elbo(P, c.x, c.y, c.nb_occ, np.array([c.N, c.T]), c.group_n, c.nb_train,
+                       e0, ew, ev, want_grads=False)["loss"]
+    assert abs(a - b) / abs(a) > 1e-9
+
+
+def test_fm_identity_general_F():
+    """1/2((sum_f z)^2 - sum_f z^2) == sum_{f<g} <z_f,z_g>; at F=2 == prod().sum()
+    (vfm-torch.py:245)."""
+    g = np.random.default_rng(0)
+    for F in (2, 3, 5, 32):
+        z = g.standard_normal((17, F, 12))
+        sz = z.sum(1)
+        trick = 0.5 * ((sz * sz).sum(1) - (z * z).sum((1, 2)))
+        np.testing.assert_allclose(trick, O.pairwise_second_order(z), rtol=1e-10, atol=1e-10)
+    z = g.standard_normal((9, 2, 7))
+    np.testing.assert_allclose(O.pairwise_second_order(z), z.prod(1).sum(1), rtol=1e-12)
+
+
+def test_rowwise_grads_match_autograd_general_F():
+    """F=4 fields (no reference oracle for F>2): analytic grads vs torch autograd of the
+    same row-wise loss in float64."""
+    g = np.random.default_rng(5)
+    F, d, B = 4, 6, 64
+    sizes = [7, 5, 9, 4]
+    hi = np.cumsum(sizes)
+    T = int(hi[-1])
+    lo = hi - sizes
+    x = np.stack([g.integers(lo[f], hi[f], B) for f in range(F)], 1)
+    nb_occ = g.integers(1, 50, T)
+    y = g.standard_normal(B)
+    P = {"alpha": np.array([0.7]), "global_bias_mean": np.array([0.1]),
+         "global_bias_scale": np.array([-0.8]),
+         "bias_params": g.standard_normal((T, 2)), "entity_params": g.standard_normal((T, 2 * d))}
+    e0, ew, ev = g.standard_normal(1), g.standard_normal(T), g.standard_normal((T, d))
+    nb_train = 1000
+    for output in ("reg", "class"):
+        yy = y if output == "reg" else (y > 0).astype(np.float64)
+        r = O.rowwise_elbo(P, x, yy, nb_occ, hi, np.array(sizes, float), nb_train, e0, ew, ev, output)
+        # autograd restatement
+        tp = {k: torch.tensor(v, requires_grad=True) for k, v in P.items()}
+        xt = torch.tensor(x)
+        mu_w, s_w = tp["bias_params"][xt][..., 0], tp["bias_params"][xt][..., 1]
+        E = tp["entity_params"][xt]
+        mu_v, s_v = E[..., :d], E[..., d:]
+        w = mu_w + s_w.abs() * torch.tensor(ew)[xt]
+        z = mu_v + s_v.abs() * torch.tensor(ev)[xt]
+        w0 = tp["global_bias_mean"] + tp["global_bias_scale"].abs() * torch.tensor(e0)
+        pred = w0 + w.sum(1) + 0.5 * ((z.sum(1) ** 2).sum(1) - (z ** 2).sum((1, 2)))
+        yt = torch.tensor(yy)
+        if output == "reg":
+            ll = torch.distributions.Normal(pred, torch.sqrt(1 / tp["alpha"].abs())).log_prob(yt)
+        else:
+            ll = torch.distributions.Bernoulli(logits=pred).log_prob(yt)
+        kl_e = (0.5 * (s_w ** 2 + mu_w ** 2 - 1) - s_w.abs().log()
+                + (0.5 * (s_v ** 2 + mu_v ** 2 - 1) - s_v.abs().log()).sum(2))
+        io = 1.0 / torch.tensor(nb_occ, dtype=torch.float64)[xt]
+        Wt = io.sum(0)
+        kl = (kl_e * io * (torch.tensor(sizes, dtype=torch.float64) / Wt)).sum()
+        s0 = tp["global_bias_scale"]
+        kl0 = 0.5 * (s0 ** 2 + tp["global_bias_mean"] ** 2 - 1) - s0.abs().log()
+        loss = -(nb_train / B) * ll.sum() + kl0 + kl
+        loss.backward()
+        assert rel_err(r["loss"], loss.item()) < 1e-12
+        for k in PARAM_KEYS:
+            got = tp[k].grad
+            got = np.zeros(1) if got is None else got.numpy()
+            assert rel_err(r["g_" + k], got) < 1e-10, (output, k)
+
+
+def test_adam_step_matches_torch():
+    g = np.random.default_rng(1)
+    p = g.standard_normal((5, 3))
+    pt = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=0.25)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for t in range(1, 5):
+        grad = g.standard_normal((5, 3))
+        pt.grad = torch.tensor(grad)
+        opt.step()
+        O.adam_step(p, grad, m, v, t, 0.25)
+        np.testing.assert_allclose(p, pt.detach().numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_trajectory_fixture_reference_shaped():
+    """The 6-step Adam trajectory (incl. a short last batch) replayed with the
+    reference-shaped restatement reproduces the reference's losses and final weights."""
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "traj_reg_d16.npz"))
+    N, M = int(z["N"]), int(z["M"])
+    P = {k: torch.tensor(z["p0_" + k], requires_grad=True) for k in PARAM_KEYS}
+    opt = torch.optim.Adam(list(P.values()), lr=float(z["lr"]))
+    X, Y, occ = torch.tensor(z["x"]), torch.tensor(z["y"]), torch.tensor(z["nb_occ"])
+    nb, B = int(z["nb_train"]), int(z["batch"])
+    step = 0
+    for _ in range(int(z["n_epochs"])):
+        for lo in range(0, nb, B):
+            eps = (z[f"s{step}_eps0"], z[f"s{step}_eps_w"], z[f"s{step}_eps_v"])
+            loss, mean = O.reference_shaped_step(P, opt, X[lo:lo + B], Y[lo:lo + B], occ, N, M,
+                                                 nb, "reg", eps)
+            assert abs(loss.item() - z["losses"][step]) / abs(z["losses"][step]) < 1e-5
+            step += 1
+    for k in PARAM_KEYS:
+        assert rel_err(P[k].detach().numpy(), z["pT_" + k]) < 1e-4, k

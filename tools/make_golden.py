@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the reference's own `CF` class.
+
+Runs ONLY in the build container (needs /root/reference).  Nothing from the
+reference is copied into the repo: the class `CF` is located in
+`/root/reference/vfm-torch.py` with `ast`, compiled in memory, executed in a
+namespace that provides the module globals it reads (vfm-torch.py:18-19,
+87-89,125-126), and the *data* it produces (inputs, the epsilon draws, outputs,
+gradients, a short Adam trajectory) is written to `tests/golden/*.npz`.
+
+The loss line is vfm-torch.py:359, the optimiser vfm-torch.py:339, the
+learning-rate rule vfm-torch.py:92.
+
+Usage:  python tools/make_golden.py            (writes tests/golden/)
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+from torch import nn, distributions
+
+REF = os.environ.get("VFM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                   "tests", "golden")
+
+
+def lift_cf(namespace):
+    """Compile the reference's `class CF` in `namespace` (no file is imported)."""
+    path = os.path.join(REF, "vfm-torch.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    node = next(n for n in tree.body
+                if isinstance(n, ast.ClassDef) and n.name == "CF")
+    mod = ast.Module(body=[node], type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace["CF"], (node.lineno, node.end_lineno)
+
+
+class EpsRecorder:
+    """Record every standard-normal draw made by torch.distributions.Normal.rsample
+    (torch/distributions/normal.py:83-86 calls `_standard_normal`)."""
+
+    def __init__(self):
+        import torch.distributions.normal as tn
+        self.tn = tn
+        self.orig = tn._standard_normal
+        self.draws = []
+
+    def __enter__(self):
+        def rec(shape, dtype, device):
+            e = self.orig(shape, dtype, device)
+            self.draws.append(e.detach().clone())
+            return e
+        self.tn._standard_normal = rec
+        return self
+
+    def __exit__(self, *a):
+        self.tn._standard_normal = self.orig
+
+
+def make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed):
+    ns.update(N=N, M=M, nb_occ=nb_occ, EMBEDDING_SIZE=d,
+              N_VARIATIONAL_SAMPLES=1, LINK=torch.abs)
+    torch.manual_seed(seed)
+    model = CF(d, output=output)
+    if dtype == torch.float64:
+        model = model.double()
+    return model
+
+
+def param_dict(model):
+    return {
+        "alpha": model.alpha.detach().numpy().copy(),
+        "global_bias_mean": model.global_bias_mean.detach().numpy().copy(),
+        "global_bias_scale": model.global_bias_scale.detach().numpy().copy(),
+        "bias_params": model.bias_params.weight.detach().numpy().copy(),
+        "entity_params": model.entity_params.weight.detach().numpy().copy(),
+    }
+
+
+def out_dtype(model):
+    return model.alpha.detach().numpy().dtype
+
+
+def one_step(model, x, y, nb_train):
+    """forward + loss (vfm-torch.py:353,359) + backward (:368-369)."""
+    with EpsRecorder() as rec:
+        lik, _, _, kl = model(x)
+    eps0, eps_w, eps_v = rec.draws  # order of vfm-torch.py:238-241
+    loss = -lik.log_prob(y.to(kl.dtype)).mean() * nb_train + kl
+    model.zero_grad()
+    loss.backward()
+    uniq = torch.unique(x)
+    out = {
+        "uniq": uniq.numpy(),
+        "eps0": eps0.numpy().reshape(-1),
+        "eps_w": eps_w.numpy().reshape(-1),                 # [U] over sorted uniq
+        "eps_v": eps_v.numpy().reshape(len(uniq), -1),      # [U, d]
+        "pred": lik.mean.detach().numpy().reshape(-1),      # sigmoid(logit) for 'class'
+        "kl": kl.detach().numpy().reshape(-1),
+        "loss": loss.detach().numpy().reshape(-1),
+        # alpha takes no part in the Bernoulli likelihood (vfm-torch.py:270): grad None
+        "g_alpha": (model.alpha.grad.numpy().copy() if model.alpha.grad is not None
+                    else np.zeros(1, dtype=out_dtype(model))),
+        "g_global_bias_mean": model.global_bias_mean.grad.numpy().copy(),
+        "g_global_bias_scale": model.global_bias_scale.grad.numpy().copy(),
+        "g_bias_params": model.bias_params.weight.grad.numpy().copy(),
+        "g_entity_params": model.entity_params.weight.grad.numpy().copy(),
+    }
+    if model.output != "reg":
+        out["logits"] = lik.logits.detach().numpy().reshape(-1)
+    return out
+
+
+def single_case(ns, CF, name, N, M, d, x, y, nb_train, nb_occ, output,
+                seed=42, eps_seed=7, also_f64=True, sparse_rows=False):
+    x = torch.as_tensor(x, dtype=torch.int64)
+    y = torch.as_tensor(y, dtype=torch.float32)
+    nb_occ = torch.as_tensor(nb_occ, dtype=torch.int64)
+    rec = {"N": N, "M": M, "d": d, "nb_train": nb_train,
+           "output": np.array(output), "x": x.numpy(), "y": y.numpy(),
+           "nb_occ": nb_occ.numpy()}
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        if dtype == torch.float64 and not also_f64:
+            continue
+        model = make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed)
+        if dtype == torch.float32:
+            p = param_dict(model)
+        torch.manual_seed(eps_seed)
+        out = one_step(model, x, y, nb_train)
+        if dtype == torch.float32:
+            for k in ("uniq",):
+                rec[k] = out[k]
+        for k, v in out.items():
+            if k == "uniq":
+                continue
+            rec[f"{tag}_{k}"] = v
+    if sparse_rows:
+        # big tables: keep only the rows the batch touches (everything else has
+        # zero gradient, asserted here, and does not influence any output)
+        u = rec["uniq"]
+        for tag in ("f32", "f64"):
+            for k in ("g_bias_params", "g_entity_params"):
+                key = f"{tag}_{k}"
+                if key in rec:
+                    full = rec[key]
+                    mask = np.ones(len(full), bool)
+                    mask[u] = False
+                    assert not full[mask].any()
+                    rec[key] = full[u]
+        p["bias_params"] = p["bias_params"][u]
+        p["entity_params"] = p["entity_params"][u]
+        rec["sparse_rows"] = np.array(1)
+    for k, v in p.items():
+        rec[f"p_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: B={len(y)} U={len(rec['uniq'])} loss_f32={rec['f32_loss']}",
+          f"loss_f64={rec.get('f64_loss')}")
+
+
+def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
+                    seed=42, eps_seed=11):
+    """The loop of vfm-torch.py:347-370 for a few steps (incl. a short last batch)."""
+    X = torch.as_tensor(X, dtype=torch.int64)
+    Y = torch.as_tensor(Y, dtype=torch.float32)
+    nb_train = len(Y)
+    nb_occ = torch.bincount(X.flatten(), minlength=N + M)   # vfm-torch.py:89
+    lr = 1 / (1 + nb_train // batch)                        # vfm-torch.py:92
+    model = make_model(ns, CF, N, M, d, nb_occ, output, torch.float32, seed)
+    rec = {"N": N, "M": M, "d": d, "nb_train": nb_train, "batch": batch,
+           "lr": lr, "n_epochs": n_epochs, "output": np.array(output),
+           "x": X.numpy(), "y": Y.numpy(), "nb_occ": nb_occ.numpy()}
+    for k, v in param_dict(model).items():
+        rec[f"p0_{k}"] = v
+    opt = torch.optim.Adam(model.parameters(), lr=lr)       # vfm-torch.py:339
+    torch.manual_seed(eps_seed)
+    step = 0
+    losses = []
+    for epoch in range(n_epochs):
+        for lo in range(0, nb_train, batch):                # DataLoader, no shuffle (:121-122)
+            x, y = X[lo:lo + batch], Y[lo:lo + batch]
+            with EpsRecorder() as r:
+                lik, _, _, kl = model(x)
+            loss = -lik.log_prob(y).mean() * nb_train + kl
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            e0, ew, ev = r.draws
+            uniq = torch.unique(x)
+            rec[f"s{step}_uniq"] = uniq.numpy()
+            rec[f"s{step}_eps0"] = e0.numpy().reshape(-1)
+            rec[f"s{step}_eps_w"] = ew.numpy().reshape(-1)
+            rec[f"s{step}_eps_v"] = ev.numpy().reshape(len(uniq), -1)
+            rec[f"s{step}_pred"] = lik.mean.detach().numpy().reshape(-1)
+            losses.append(float(loss))
+            step += 1
+    rec["n_steps"] = step
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in param_dict(model).items():
+        rec[f"pT_{k}"] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: steps={step} lr={lr:.4f} losses={losses}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = {"torch": torch, "nn": nn, "distributions": distributions, "np": np}
+    CF, span = lift_cf(ns)
+    print("lifted CF from vfm-torch.py lines", span)
+
+    # (1) tiny quirk case: N=50, M=30, d=8, B=512; contains item id == N (vfm-torch.py:316)
+    g = np.random.default_rng(0)
+    N, M, d, B, nb_train = 50, 30, 8, 512, 4000
+    Xall = np.stack([g.integers(0, N, nb_train), N + g.integers(0, M, nb_train)], 1)
+    Xall[:40, 1] = N                                   # make sure id == N is present
+    nb_occ = np.bincount(Xall.reshape(-1), minlength=N + M)
+    x = Xall[:B]
+    assert (x[:, 1] == N).any() and nb_occ.min() > 0
+    y = g.integers(1, 6, B).astype(np.float32)
+    single_case(ns, CF, "quirk_reg_d8", N, M, d, x, y, nb_train, nb_occ, "reg")
+
+    # (2) fraction data set (reference data/fraction/data.csv: user,item,outcome), d=5, Bernoulli
+    import pandas as pd
+    df = pd.read_csv(os.path.join(REF, "data", "fraction", "data.csv"))
+    N, M, d = int(df.user.nunique()), int(df.item.nunique()), 5
+    Xall = np.stack([df.user.to_numpy(), df.item.to_numpy() + N], 1)
+    Yall = df.outcome.to_numpy().astype(np.float32)
+    perm = np.random.default_rng(0).permutation(len(Yall))
+    tr = perm[: int(0.8 * len(Yall))]
+    nb_occ = np.bincount(Xall[tr].reshape(-1), minlength=N + M)
+    keep = tr[(nb_occ[Xall[tr]] > 0).all(1)]
+    single_case(ns, CF, "fraction_class_d5", N, M, d, Xall[keep], Yall[keep],
+                len(keep), nb_occ, "class")
+
+    # (3) ML-100K-shape, d=20, B=1000 of nb_train=80000
+    g = np.random.default_rng(1)
+    N, M, d, B, nb_train = 943, 1682, 20, 1000, 80000
+    Xall = np.stack([g.integers(0, N, nb_train), N + g.integers(0, M, nb_train)], 1)
+    nb_occ = np.bincount(Xall.reshape(-1), minlength=N + M)
+    x = Xall[:B]
+    y = g.integers(1, 6, B).astype(np.float32)
+    single_case(ns, CF, "ml100k_reg_d20", N, M, d, x, y, nb_train, nb_occ, "reg")
+
+    # (3b) same shape, Bernoulli likelihood
+    yb = (y >= 4).astype(np.float32)
+    single_case(ns, CF, "ml100k_class_d20", N, M, d, x, yb, nb_train, nb_occ, "class",
+                also_f64=False)
+
+    # (4) d=128 slice with ML-20M-shape ids, B=256 (only touched rows are stored)
+    g = np.random.default_rng(2)
+    N, M, d, B, nb_train = 138493, 26744, 128, 256, 16_000_000
+    x = np.stack([g.integers(0, N, B), N + g.integers(0, M, B)], 1)
+    x[:8, 0] = x[0, 0]                                  # repeated user
+    x[8:24, 1] = x[8, 1]                                # repeated item
+    nb_occ = g.integers(1, 400, N + M)
+    y = (g.integers(1, 11, B) / 2).astype(np.float32)
+    single_case(ns, CF, "ml20m_reg_d128", N, M, d, x, y, nb_train, nb_occ, "reg",
+                also_f64=False, sparse_rows=True)
+
+    # (5) 3 batches/epoch (1000,1000,500) x 2 epochs Adam trajectory, short last batch
+    g = np.random.default_rng(3)
+    N, M, d = 120, 200, 16
+    nb = 2500
+    X = np.stack([g.integers(0, N, nb), N + g.integers(0, M, nb)], 1)
+    Y = g.integers(1, 6, nb).astype(np.float32)
+    trajectory_case(ns, CF, "traj_reg_d16", N, M, d, X, Y, 1000, "reg")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
