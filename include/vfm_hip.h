@@ -1,0 +1,153 @@
+/*
+ * vfm_hip.h -- C ABI of libvfm_hip.so: the MI355X (gfx950) Variational-FM ELBO step.
+ *
+ * Drop-in boundary.  The reference (jilljenn/vae) has no FFI / operator API; the one
+ * boundary of its hot path is the Python call `CF.forward(x)` (vfm-torch.py:189) whose
+ * results are combined into the loss at vfm-torch.py:359 and differentiated at :368-369.
+ * Every entry point below replaces a slice of that call; the slice is cited per function.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer except `vfm_problem_t*` is DEVICE memory
+ *    owned by the caller; the library never allocates, frees or keeps a pointer past return.
+ *  - launch-only: no host synchronisation inside, safe under hipGraph capture, re-entrant
+ *    (the only state is a thread-local error string).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - return 0 on success, otherwise a negative VFM_E_* code or a positive hipError_t;
+ *    `vfm_last_error()` describes the last failure on the calling thread.
+ *  - all floating point is fp32 (as the reference), reductions accumulate in fp64.
+ *
+ * Data layout in HBM (identical to the reference's nn.Embedding tables, so state_dicts
+ * line up, vfm-torch.py:152-153):
+ *    entity_params [T, 2d] row-major: row e = [ mu_v(0..d-1) | s_v(0..d-1) ]  (8d bytes)
+ *    bias_params   [T, 2]           : row e = [ mu_w, s_w ]
+ *    scalars       [3]              : alpha, global_bias_mean, global_bias_scale
+ *    x             [B, F] row-major entity ids, int64 (reference: torch.LongTensor) or int32
+ *    link function is |.| (vfm-torch.py:126): sigma = |s|.
+ */
+#ifndef VFM_HIP_H
+#define VFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFM_ABI_VERSION 1
+#define VFM_MAX_FIELDS 64
+
+#define VFM_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported size)   */
+#define VFM_E_UNSUPPORTED (-2)
+
+#define VFM_LIK_NORMAL 0     /* 'reg'  : Normal(pred, 1/sqrt|alpha|)  vfm-torch.py:268  */
+#define VFM_LIK_BERNOULLI 1  /* 'class': Bernoulli(logits=pred)       vfm-torch.py:270  */
+
+/* vfm_problem_t.flags */
+#define VFM_FLAG_NO_PRIOR_TERMS 1 /* this rank leaves out the terms that do not depend on batch
+                                     rows -- KL(q(w0)||N(0,1)) in the loss and its gradient wrt
+                                     global_bias_mean/scale -- so that SUMMING loss and scalar
+                                     gradients over ranks counts them exactly once                */
+#define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
+                                     posterior means (vfm-torch.py:248-259)                       */
+
+/* indices into the fp64 `partials` vector written by vfm_elbo_fwd_f32 */
+#define VFM_P_LL 0      /* sum_r log p(y_r | pred_r)                                    */
+#define VFM_P_KL 1      /* sum over occurrences of KL_e/occ(e) * n_g/W_g (kl_rescaled)  */
+#define VFM_P_G 2       /* sum_r dloss/dpred_r                                          */
+#define VFM_P_ALPHA 3   /* sum_r [(y-pred)^2/2 - 1/(2|alpha|)]                          */
+#define VFM_P_BADID 4   /* number of ids outside [0,T) met (they are clamped to 0)      */
+#define VFM_N_PARTIALS 8
+
+/* Problem description shared by all kernels of one step (host memory). */
+typedef struct vfm_problem {
+  int64_t B;          /* rows handled by THIS call (this rank's shard of the batch)       */
+  int64_t B_global;   /* rows of the whole batch over all ranks (loss uses nb_train/B_global) */
+  int64_t T;          /* rows of the two tables (N + M in the reference)                 */
+  int64_t nb_train;   /* vfm-torch.py:91                                                 */
+  int32_t F;          /* fields per row (2 in the reference: user, item)                 */
+  int32_t d;          /* embedding size                                                  */
+  int32_t likelihood; /* VFM_LIK_*                                                       */
+  int32_t id_bits;    /* 64 or 32: element type of x                                     */
+  int32_t n_samples;  /* variational samples S; only 1 is supported (vfm-torch.py:19)    */
+  int32_t flags;      /* VFM_FLAG_*                                                      */
+  /* id groups for the KL re-weighting (vfm-torch.py:314-317): entity e belongs to the first
+   * g with e < group_hi[g]; its KL is scaled by group_n[g] / W[g].  There are F groups and
+   * W[f] is the normaliser of column f.  Reference: group_hi = {N+1, N+M} (the `<= N` test
+   * of :316 puts item id N into the user group), group_n = {N, M}.                      */
+  int64_t group_hi[VFM_MAX_FIELDS];
+  double group_n[VFM_MAX_FIELDS];
+  /* counter-based RNG key, used when the eps tables are NULL: eps(e,k) =
+   * BoxMuller(Philox4x32-10(key = seed, ctr = (k/4, e, step, tag))).  One draw per ENTITY per
+   * step, shared by every row that contains it (vfm-torch.py:207-208,238-245).          */
+  uint64_t seed;
+  uint64_t step;
+} vfm_problem_t;
+
+int vfm_abi_version(void);
+const char* vfm_last_error(void);
+
+/* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
+ * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */
+int vfm_inv_occ_f32(const int64_t* nb_occ, float* inv_occ, int64_t T, void* stream);
+
+/* W[f] = sum_r inv_occ[x[r,f]] -- the user/item normalisers of vfm-torch.py:305-306 in
+ * row-wise form.  `W` (fp64 [F]) is zeroed by the call.  Parameter-free: depends on the
+ * batch only, so it can be computed once per batch and cached over epochs.  With several
+ * ranks the caller sums W over ranks before the forward call. */
+int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ, double* W,
+                    void* stream);
+
+/* Forward of the fused hot path (vfm-torch.py:189-324 without torch.unique, plus the
+ * per-row terms of the loss :359): gathers, reparameterised sample z = mu + |s| * eps,
+ * FM prediction  pred_r = w0 + sum_f w_f + 1/2 sum_k[(sum_f z_fk)^2 - sum_f z_fk^2],
+ * log-likelihood, KL-to-prior with occurrence re-weighting.
+ *  in : x [B,F], y [B] (may be NULL => prediction only: no likelihood / KL / training state)
+ *       W [F] batch-global normalisers, eps_* tables indexed BY ENTITY ID
+ *       (eps_entity [T,d], eps_bias [T], eps_global [1]) or all three NULL => Philox.
+ *  out: pred [B]      unscaled prediction (logit for Bernoulli)
+ *       partials [VFM_N_PARTIALS] fp64, zeroed by the call (see VFM_P_*)
+ *       sumz [B,d] and grow [B] (both may be NULL together): training state for the
+ *       backward call: sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.        */
+int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
+                     const float* entity_params, const float* bias_params,
+                     const float* inv_occ, const float* scalars, const double* W,
+                     const float* eps_entity, const float* eps_bias, const float* eps_global,
+                     float* pred, double* partials, float* sumz, float* grow, void* stream);
+
+/* loss[0] = -(nb_train/B_global) * partials[LL] + KL(q(w0)||N(0,1)) + partials[KL]
+ * (vfm-torch.py:322,359), loss[1] = the likelihood term, loss[2] = the KL term.  NaN when
+ * partials[BADID] != 0.  With several ranks, sum `partials` over ranks first. */
+int vfm_elbo_finalize_f32(const vfm_problem_t* p, const double* partials, const float* scalars,
+                          float* loss, void* stream);
+
+/* Backward (replaces autograd through vfm-torch.py:189-324,359; :368-369).  Entity-centric:
+ * one lane group per table row e sums grow[r] * sumz[r,:] over the rows that contain e
+ * (inverted index: occ_ptr [T+1] int32 offsets into occ_rows [B*F] int32 row numbers, sorted
+ * by entity id), then writes the DENSE gradient row (zeros for rows not in the batch, like
+ * the reference's dense nn.Embedding gradients).  No atomics; bitwise reproducible for a
+ * fixed index.  grad_out [1] = dL/dloss (device).  g_scalars [3] = grads of alpha,
+ * global_bias_mean, global_bias_scale from the (rank-summed) partials. */
+int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+                     const float* entity_params, const float* bias_params,
+                     const float* inv_occ, const float* scalars, const double* W,
+                     const float* eps_entity, const float* eps_bias, const float* eps_global,
+                     const float* sumz, const float* grow, const double* partials,
+                     const float* grad_out, float* g_entity, float* g_bias, float* g_scalars,
+                     void* stream);
+
+/* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
+ * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of
+ * this update (bias corrections are formed on the host in fp64).  In place on p, m, v; all four
+ * pointers 16-byte aligned. */
+int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int64_t step, void* stream);
+
+/* Debug / test helper: write the eps the kernels would generate from (seed, step) into
+ * tables (eps_entity [T,d], eps_bias [T], eps_global [1]). */
+int vfm_philox_eps_f32(const vfm_problem_t* p, float* eps_entity, float* eps_bias,
+                       float* eps_global, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFM_HIP_H */

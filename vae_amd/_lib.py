@@ -1,0 +1,96 @@
+"""Loader for the C-ABI library `libvfm_hip.so` (include/vfm_hip.h).
+
+The library is built in-tree by `vae_amd.build.build_all()` (hipcc, gfx950).  There is NO
+fallback: if it is missing or does not load, every op of this package raises.
+`import torch` must happen before the library is opened so that both resolve the same
+HIP runtime (`libamdhip64.so.7`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
+OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
+
+ABI_VERSION = 1
+MAX_FIELDS = 64
+N_PARTIALS = 8
+P_LL, P_KL, P_G, P_ALPHA, P_BADID = 0, 1, 2, 3, 4
+LIK_NORMAL, LIK_BERNOULLI = 0, 1
+
+EXPORTS = (
+    "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
+    "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
+    "vfm_adam_f32",
+)
+
+
+class Problem(C.Structure):
+    """Mirror of `vfm_problem_t`."""
+    _fields_ = [
+        ("B", C.c_int64), ("B_global", C.c_int64), ("T", C.c_int64), ("nb_train", C.c_int64),
+        ("F", C.c_int32), ("d", C.c_int32), ("likelihood", C.c_int32), ("id_bits", C.c_int32),
+        ("n_samples", C.c_int32), ("reserved", C.c_int32),
+        ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+    ]
+
+
+class VfmLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Open libvfm_hip.so (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VfmLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  vae_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    PP = C.POINTER(Problem)
+    lib.vfm_abi_version.restype = C.c_int
+    lib.vfm_abi_version.argtypes = []
+    lib.vfm_last_error.restype = C.c_char_p
+    lib.vfm_last_error.argtypes = []
+    lib.vfm_inv_occ_f32.argtypes = [vp, vp, i64, vp]
+    lib.vfm_batch_norms.argtypes = [PP, vp, vp, vp, vp]
+    lib.vfm_elbo_fwd_f32.argtypes = [PP] + [vp] * 15
+    lib.vfm_elbo_finalize_f32.argtypes = [PP, vp, vp, vp, vp]
+    lib.vfm_elbo_bwd_f32.argtypes = [PP] + [vp] * 18
+    lib.vfm_philox_eps_f32.argtypes = [PP, vp, vp, vp, vp]
+    lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 i64, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name != "vfm_last_error":
+            fn.restype = C.c_int
+    if lib.vfm_abi_version() != ABI_VERSION:
+        raise VfmLibraryError(f"ABI mismatch: library {lib.vfm_abi_version()}, package {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vfm_last_error().decode(errors="replace")
+        raise VfmLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,242 @@
+"""Host-side operators over the C ABI (include/vfm_hip.h).  Device memory, streams and
+autograd come from PyTorch-ROCm; all arithmetic of the hot path runs in the HIP kernels.
+
+`BatchPlan`  -- everything about one batch that does not depend on the parameters: the ids,
+               targets, the batch normalisers W (vfm-torch.py:305-306) and the inverted index
+               (entity -> rows) the backward kernel walks.  The reference's loader does not
+               shuffle (vfm-torch.py:121-122), so `fit()` builds each plan once and reuses it
+               every epoch.
+`elbo_forward / elbo_backward` -- thin launch wrappers.
+`ElboFunction` -- torch.autograd.Function: the drop-in for `CF.forward` + loss line
+               (vfm-torch.py:189-324,359) + autograd (:368-369).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import Problem, check, ptr, current_stream_ptr
+
+FLAG_NO_PRIOR_TERMS = 1
+FLAG_EPS_ZERO = 2
+
+
+@dataclass
+class Spec:
+    """Static description of the model / data set (the globals the reference's CF reads:
+    N, M, nb_occ, EMBEDDING_SIZE, vfm-torch.py:18,87-89)."""
+    T: int
+    F: int
+    d: int
+    group_hi: tuple      # exclusive id upper bound of each of the F groups
+    group_n: tuple       # n_g multipliers (N, M in the reference)
+    likelihood: int      # _lib.LIK_NORMAL / LIK_BERNOULLI
+    nb_train: int = 1
+
+
+def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, step: int = 0,
+             flags: int = 0) -> Problem:
+    p = Problem()
+    p.B, p.B_global, p.T, p.nb_train = B, B_global, spec.T, spec.nb_train
+    p.F, p.d, p.likelihood, p.id_bits = spec.F, spec.d, spec.likelihood, id_bits
+    p.n_samples, p.flags = 1, flags
+    for g in range(spec.F):
+        p.group_hi[g] = int(spec.group_hi[g])
+        p.group_n[g] = float(spec.group_n[g])
+    p.seed, p.step = seed & (2 ** 64 - 1), step & (2 ** 62 - 1)
+    return p
+
+
+def _need_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.VfmLibraryError(
+            f"{name} is on {t.device}: vae_amd runs on an MI355X only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def inv_occ_from_counts(nb_occ: torch.Tensor) -> torch.Tensor:
+    """1/nb_occ as fp32 (vfm-torch.py:89,298-306)."""
+    _need_cuda(nb_occ, "nb_occ")
+    assert nb_occ.dtype == torch.int64
+    out = torch.empty(nb_occ.numel(), dtype=torch.float32, device=nb_occ.device)
+    lib = _lib.load()
+    check(lib.vfm_inv_occ_f32(ptr(nb_occ), ptr(out), nb_occ.numel(), current_stream_ptr(nb_occ.device)),
+          "vfm_inv_occ_f32")
+    return out
+
+
+class BatchPlan:
+    """Parameter-independent state of one batch (or one rank's row shard of it)."""
+
+    def __init__(self, spec: Spec, x: torch.Tensor, y: Optional[torch.Tensor],
+                 inv_occ: Optional[torch.Tensor], B_global: Optional[int] = None,
+                 build_index: bool = True, validate: bool = True, process_group=None):
+        _need_cuda(x, "x")
+        if x.dim() != 2 or x.shape[1] != spec.F:
+            raise ValueError(f"x must be [B,{spec.F}], got {tuple(x.shape)}")
+        if x.dtype not in (torch.int64, torch.int32):
+            raise TypeError("x must be int64 or int32")
+        self.spec = spec
+        self.x = x
+        self.B = x.shape[0]
+        self.B_global = self.B if B_global is None else int(B_global)
+        self.id_bits = 64 if x.dtype == torch.int64 else 32
+        self.y = None
+        if y is not None:
+            _need_cuda(y, "y")
+            self.y = y.to(torch.float32).contiguous()
+            if self.y.shape != (self.B,):
+                raise ValueError("y must be [B]")
+        if validate and self.B > 0:
+            lo, hi = int(x.min()), int(x.max())
+            if lo < 0 or hi >= spec.T:     # nn.Embedding would raise IndexError (vfm-torch.py:207)
+                raise IndexError(f"entity id out of range [0,{spec.T}): min {lo}, max {hi}")
+        self.W = None
+        self.occ_ptr = self.occ_rows = None
+        dev = x.device
+        lib = _lib.load()
+        if inv_occ is not None and y is not None:
+            self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
+            p = _problem(spec, self.B, self.B_global, self.id_bits)
+            check(lib.vfm_batch_norms(C.byref(p), ptr(x), ptr(inv_occ), ptr(self.W),
+                                      current_stream_ptr(dev)), "vfm_batch_norms")
+            if process_group is not None:
+                torch.distributed.all_reduce(self.W, group=process_group)
+        if build_index and y is not None:
+            self.build_index()
+
+    def build_index(self):
+        """Inverted index entity -> batch rows (counting sort by id; torch device ops: this is
+        plumbing done once per batch, outside the per-step path)."""
+        flat = self.x.reshape(-1).to(torch.int64)
+        order = torch.argsort(flat, stable=True)
+        self.occ_rows = (order // self.spec.F).to(torch.int32).contiguous()
+        counts = torch.bincount(flat, minlength=self.spec.T)
+        occ_ptr = torch.zeros(self.spec.T + 1, dtype=torch.int64, device=self.x.device)
+        torch.cumsum(counts, 0, out=occ_ptr[1:])
+        self.occ_ptr = occ_ptr.to(torch.int32).contiguous()
+
+
+@dataclass
+class FwdState:
+    pred: torch.Tensor          # [B] unscaled prediction / logit
+    partials: torch.Tensor      # [8] fp64
+    sumz: Optional[torch.Tensor]
+    grow: Optional[torch.Tensor]
+    problem: Problem
+    eps: Optional[tuple]
+
+
+def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, *, eps=None,
+                 seed=0, step=0, train=True, flags=0, out_pred=None, out_sumz=None,
+                 out_grow=None, out_partials=None) -> FwdState:
+    """Launch vfm_elbo_fwd_f32 on the current stream.  `eps` = (eps_entity[T,d], eps_bias[T],
+    eps_global[1]) tables indexed by entity id, or None for the in-kernel Philox stream."""
+    spec = plan.spec
+    dev = plan.x.device
+    for t, n in ((entity_params, "entity_params"), (bias_params, "bias_params"), (scalars, "scalars")):
+        _need_cuda(t, n)
+    if entity_params.shape != (spec.T, 2 * spec.d) or bias_params.shape != (spec.T, 2):
+        raise ValueError("table shapes do not match the spec")
+    have_y = plan.y is not None
+    train = train and have_y
+    B = plan.B
+    pred = out_pred if out_pred is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    partials = out_partials if out_partials is not None else torch.empty(
+        _lib.N_PARTIALS, dtype=torch.float64, device=dev)
+    sumz = grow = None
+    if train:
+        sumz = out_sumz if out_sumz is not None else torch.empty(B, spec.d, dtype=torch.float32, device=dev)
+        grow = out_grow if out_grow is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    p = _problem(spec, B, plan.B_global, plan.id_bits, seed, step, flags)
+    e = eps if eps is not None else (None, None, None)
+    lib = _lib.load()
+    check(lib.vfm_elbo_fwd_f32(C.byref(p), ptr(plan.x), ptr(plan.y), ptr(entity_params), ptr(bias_params),
+                               ptr(inv_occ) if have_y else None, ptr(scalars),
+                               ptr(plan.W) if have_y else None, ptr(e[0]), ptr(e[1]), ptr(e[2]),
+                               ptr(pred), ptr(partials), ptr(sumz), ptr(grow), current_stream_ptr(dev)),
+          "vfm_elbo_fwd_f32")
+    return FwdState(pred, partials, sumz, grow, p, eps)
+
+
+def elbo_finalize(st: FwdState, scalars, out=None) -> torch.Tensor:
+    """loss[3] = (loss, likelihood term, KL term) from (rank-summed) partials."""
+    loss = out if out is not None else torch.empty(3, dtype=torch.float32, device=scalars.device)
+    lib = _lib.load()
+    check(lib.vfm_elbo_finalize_f32(C.byref(st.problem), ptr(st.partials), ptr(scalars), ptr(loss),
+                                    current_stream_ptr(scalars.device)), "vfm_elbo_finalize_f32")
+    return loss
+
+
+def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
+                  grad_out, g_entity=None, g_bias=None, g_scalars=None):
+    """Launch vfm_elbo_bwd_f32: dense gradients of both tables + the three scalars."""
+    dev = plan.x.device
+    if plan.occ_ptr is None:
+        plan.build_index()
+    if g_entity is None:
+        g_entity = torch.empty_like(entity_params)
+    if g_bias is None:
+        g_bias = torch.empty_like(bias_params)
+    if g_scalars is None:
+        g_scalars = torch.empty(3, dtype=torch.float32, device=dev)
+    e = st.eps if st.eps is not None else (None, None, None)
+    lib = _lib.load()
+    check(lib.vfm_elbo_bwd_f32(C.byref(st.problem), ptr(plan.occ_ptr), ptr(plan.occ_rows),
+                               ptr(entity_params), ptr(bias_params), ptr(inv_occ), ptr(scalars),
+                               ptr(plan.W), ptr(e[0]), ptr(e[1]), ptr(e[2]), ptr(st.sumz), ptr(st.grow),
+                               ptr(st.partials), ptr(grad_out), ptr(g_entity), ptr(g_bias),
+                               ptr(g_scalars), current_stream_ptr(dev)), "vfm_elbo_bwd_f32")
+    return g_entity, g_bias, g_scalars
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """In-place dense Adam (torch.optim.Adam defaults, vfm-torch.py:339,370) on one flat tensor."""
+    for t in (p, g, m, v):
+        _need_cuda(t, "adam tensor")
+    lib = _lib.load()
+    check(lib.vfm_adam_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, int(step),
+                           current_stream_ptr(p.device)), "vfm_adam_f32")
+
+
+def philox_eps(spec: Spec, seed: int, step: int, device):
+    """The eps tables the kernels generate for (seed, step) -- test helper."""
+    ee = torch.empty(spec.T, spec.d, dtype=torch.float32, device=device)
+    eb = torch.empty(spec.T, dtype=torch.float32, device=device)
+    eg = torch.empty(1, dtype=torch.float32, device=device)
+    p = _problem(spec, 0, 0, 64, seed, step)
+    lib = _lib.load()
+    check(lib.vfm_philox_eps_f32(C.byref(p), ptr(ee), ptr(eb), ptr(eg), current_stream_ptr(ee.device)),
+          "vfm_philox_eps_f32")
+    return ee, eb, eg
+
+
+class ElboFunction(torch.autograd.Function):
+    """loss, pred = ElboFunction.apply(entity_params, bias_params, alpha, m0, s0, plan, inv_occ,
+    eps, seed, step).  Differentiable in the five parameters (vfm-torch.py:136-138,152-153)."""
+
+    @staticmethod
+    def forward(ctx, entity_params, bias_params, alpha, global_bias_mean, global_bias_scale,
+                plan, inv_occ, eps, seed, step):
+        scalars = torch.cat([alpha.detach().reshape(1), global_bias_mean.detach().reshape(1),
+                             global_bias_scale.detach().reshape(1)]).contiguous()
+        ent, bia = entity_params.detach(), bias_params.detach()
+        st = elbo_forward(plan, ent, bia, scalars, inv_occ, eps=eps, seed=seed, step=step, train=True)
+        loss3 = elbo_finalize(st, scalars)
+        ctx.plan, ctx.st, ctx.inv_occ, ctx.scalars = plan, st, inv_occ, scalars
+        ctx.save_for_backward(ent, bia)
+        ctx.mark_non_differentiable(st.pred, loss3)
+        ctx.set_materialize_grads(True)
+        return loss3[0:1].clone(), st.pred, loss3
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pred, _g_loss3):
+        ent, bia = ctx.saved_tensors
+        gout = g_loss.to(torch.float32).reshape(1).contiguous()
+        g_ent, g_bias, g_sc = elbo_backward(ctx.plan, ctx.st, ent, bia, ctx.scalars, ctx.inv_occ, gout)
+        return (g_ent, g_bias, g_sc[0:1], g_sc[1:2], g_sc[2:3], None, None, None, None, None)
