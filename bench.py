@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- rating-triples/s of the Variational-FM ELBO training step on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one
+rank per GPU, RCCL).  One "step" = one full iteration of the reference loop body
+(vfm-torch.py:351-370) over one batch: fused forward kernel, loss, backward kernel, (all-reduce
+of the gradients when N>1,) dense Adam over every parameter.  Inputs (ids, targets, occurrence
+counts, per-batch normalisers and inverted index) are resident in HBM before the timed region.
+
+Workload (BASELINE.json configs[2]): synthetic ML-20M-shape triples, N=138,493 users x M=26,744
+items, d=128, batch B=100,000 rows per GPU (the reference's BATCH_SIZE, vfm-torch.py:77),
+uniform-random ids, ratings randint(1,6), eps generated in-kernel (Philox).
+N>1: every rank processes its own B rows of a global batch of N*B rows (weak scaling), tables
+replicated, one all-reduce of the flat gradient buffer per step.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the slower of the two ELBO kernels;
+`kernels` lists all of them.  `cpu_baseline` = the reference-shaped torch-CPU restatement
+(oracle/vfm_oracle.py, pinned to the reference by tests/golden) timed on this node's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ~6.3 TB/s
+
+WORKLOADS = {
+    # name: (field sizes, d, batch, nb_train, output)
+    "ml20m_d128": ([138493, 26744], 128, 100000, 16000210, "reg"),
+    "ml100k_d20": ([943, 1682], 20, 80000, 80000, "reg"),
+    "criteo_d256": ([31250] * 32, 256, 2048, 1 << 22, "class"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="ml20m_d128", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU per step (default: workload's)")
+    ap.add_argument("--n-batches", type=int, default=16, help="distinct batches cycled through")
+    ap.add_argument("--id32", action="store_true", help="int32 ids instead of the reference's int64")
+    ap.add_argument("--sort-items", action="store_true", help="order each batch's rows by item id")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+
+    sizes, d, B, nb_train, output = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    F = len(sizes)
+    nbt = max(1, min(args.n_batches, args.steps + args.warmup))
+
+    torch.manual_seed(42)
+    model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
+    # synthetic data resident on the device: this rank's rows of nbt global batches
+    X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev)
+    if args.id32:
+        X = X.to(torch.int32)
+    # occurrence counts of the (virtual) training set: expected counts of nb_train uniform triples,
+    # at least the counts seen in the generated rows (keeps 1/occ finite for every touched id)
+    occ = torch.bincount(X.reshape(-1).to(torch.int64), minlength=model.T)
+    if world > 1:
+        dist.all_reduce(occ, group=pg)
+    scale = max(1.0, nb_train / float(nbt * B * world))
+    occ = torch.clamp((occ.to(torch.float64) * scale).round().to(torch.int64), min=1)
+    model.set_training_data(X, nb_train=nb_train, nb_occ=occ)
+    model.lr = 1.0 / (1 + nb_train // (B * world))       # vfm-torch.py:92
+
+    plans, uniq = [], []
+    for i in range(nbt):
+        xb, yb = X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]
+        if args.sort_items and F == 2:
+            o = torch.argsort(xb[:, 1], stable=True)
+            xb, yb = xb[o].contiguous(), yb[o].contiguous()
+        p = model.plan(xb, yb, B_global=B * world, process_group=pg)
+        plans.append(p)
+        uniq.append(int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
+    U = sum(uniq) / len(uniq)
+
+    events = []
+
+    def run(n, record):
+        for s in range(n):
+            if record:
+                ev = {}
+                events.append(ev)
+
+                def mark(name, ev=ev):
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    ev[name] = e
+            else:
+                mark = None
+            model.train_step(plans[s % nbt], process_group=pg, mark=mark)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(group=pg)
+            torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, not args.no_events)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
+        dt = float(t.item())
+    loss = float(model._gflat[model._n_flat].item())
+
+    # ---- per-kernel durations from the HIP events recorded inside the timed region
+    kern = {}
+    if events:
+        order = ["start", "fwd", "finalize", "bwd"] + (["allreduce"] if world > 1 else []) + ["adam"]
+        acc = {k: 0.0 for k in order[1:]}
+        for ev in events:
+            for a, b in zip(order[:-1], order[1:]):
+                acc[b] += ev[a].elapsed_time(ev[b])
+        n_params = model._n_flat
+        bytes_fwd = U * (8 * d + 16) + B * (8 * F + 8)            # SURVEY 8(d), eps in-kernel
+        bytes_bwd = bytes_fwd + U * (8 * d + 8)
+        alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params,
+               "finalize": 0.0, "allreduce": 4.0 * n_params}
+        for k, ms in acc.items():
+            us = ms / len(events) * 1e3
+            gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0
+            kern[k] = {"avg_us": round(us, 2), "alg_bytes": int(alg[k]), "achieved_GBs": round(gbs, 1),
+                       "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    roof = None
+    if kern:
+        dom = max(("fwd", "bwd"), key=lambda k: kern[k]["avg_us"])
+        kname = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)"}[dom]
+        roof = {"kernel": kname, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac_hbm_peak"],
+                "traffic": None,
+                "elbo_fwd_bwd": {
+                    "alg_bytes": kern["fwd"]["alg_bytes"] + kern["bwd"]["alg_bytes"],
+                    "avg_us": round(kern["fwd"]["avg_us"] + kern["bwd"]["avg_us"], 2),
+                    "achieved": round((kern["fwd"]["alg_bytes"] + kern["bwd"]["alg_bytes"]) /
+                                      ((kern["fwd"]["avg_us"] + kern["bwd"]["avg_us"]) * 1e-6) / 1e9, 1)}}
+        roof["elbo_fwd_bwd"]["frac"] = round(roof["elbo_fwd_bwd"]["achieved"] / HBM_PEAK_GBS, 4)
+
+    # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sizes, d, B, nb_train, output, plans[0], occ, args.cpu_seconds)
+
+    if rank == 0:
+        value = args.steps * B * world / dt
+        out = {
+            "metric": "rating-triples/sec (ELBO step) at d=%d" % d,
+            "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
+                       "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
+                       "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
+                       "likelihood": output, "unique_entities_per_batch": round(U, 1),
+                       "row_order": "item-sorted" if args.sort_items else "as-generated",
+                       "step": "fwd+loss+bwd+" + ("allreduce+" if world > 1 else "") + "dense-adam",
+                       "parallelism": f"row-sharded dp{world}"},
+            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sizes, d, B, nb_train, output, plan, occ, budget_s):
+    """Time the oracle's reference-shaped step (same op graph as vfm-torch.py:189-324,359,368-370)
+    on the host cores: one warm-up step, then steps until ~budget_s seconds are used."""
+    import torch
+    from oracle import vfm_oracle as O
+    if len(sizes) != 2:
+        return None
+    N, M = sizes
+    torch.manual_seed(42)
+    P = O.make_params(N + M, d)
+    opt = torch.optim.Adam(list(P.values()), lr=1.0 / (1 + nb_train // B))
+    x = plan.x.to(torch.int64).cpu()
+    y = plan.y.cpu()
+    occ_c = occ.cpu()
+    O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {"value": round(n * B / el, 1), "unit": "triples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": round(el / n * 1e3, 2),
+            "sample": f"{n} full steps (fwd+loss+bwd+Adam) of the same batch shape B={B}, d={d}, "
+                      f"T={N + M} with the torch-CPU reference-shaped restatement "
+                      f"(oracle/vfm_oracle.py), after 1 warm-up step; host has {os.cpu_count()} logical CPUs"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""GPU: the VFM module (autograd path, train_step path, fit/predict) vs golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Case, GOLDEN, PARAM_KEYS, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_from_case(c, dev):
+    from vae_amd.model import VFM
+    torch.manual_seed(42)
+    m = VFM(c.N, c.M, c.d, output=c.output, device=dev)
+    P = c.params()
+    with torch.no_grad():
+        m.entity_params.weight.copy_(torch.tensor(P["entity_params"]))
+        m.bias_params.weight.copy_(torch.tensor(P["bias_params"]))
+        m.alpha.copy_(torch.tensor(P["alpha"]))
+        m.global_bias_mean.copy_(torch.tensor(P["global_bias_mean"]))
+        m.global_bias_scale.copy_(torch.tensor(P["global_bias_scale"]))
+    m.set_training_data(torch.tensor(c.x), nb_train=c.nb_train, nb_occ=torch.tensor(c.nb_occ))
+    return m
+
+
+def _eps(c, dev):
+    e0, ew, ev = c.eps("f32")
+    return (torch.tensor(ev, device=dev), torch.tensor(ew, device=dev), torch.tensor(e0, device=dev))
+
+
+def test_init_matches_reference_seed():
+    from vae_amd.model import VFM
+    c = Case("quirk_reg_d8")
+    torch.manual_seed(42)
+    m = VFM(c.N, c.M, c.d, device="cuda")
+    P = c.params()
+    assert np.array_equal(m.entity_params.weight.detach().cpu().numpy(), P["entity_params"])
+    assert np.array_equal(m.bias_params.weight.detach().cpu().numpy(), P["bias_params"])
+    assert m.alpha.item() == P["alpha"][0]
+    assert set(m.state_dict()) >= {"alpha", "global_bias_mean", "global_bias_scale",
+                                   "bias_params.weight", "entity_params.weight"}
+
+
+@pytest.mark.parametrize("name", ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20"])
+def test_autograd_path(name):
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    m = _model_from_case(c, dev)
+    loss, pred, detail = m.elbo(torch.tensor(c.x), torch.tensor(c.y), eps=_eps(c, dev))
+    loss.backward()
+    assert abs(loss.item() - c.expected("loss")[0]) / abs(c.expected("loss")[0]) < 1e-4
+    assert rel_err(m.entity_params.weight.grad.cpu().numpy(), c.expected("g_entity_params")) < 1e-4
+    assert rel_err(m.bias_params.weight.grad.cpu().numpy(), c.expected("g_bias_params")) < 1e-4
+    assert abs(m.global_bias_mean.grad.item() - c.expected("g_global_bias_mean")[0]) <= 1e-4 * abs(
+        c.expected("g_global_bias_mean")[0])
+    assert m.prec_global_bias_prior.grad is None        # unused params get no grad (reference quirk 7)
+
+
+def test_trajectory_train_step_and_torch_adam():
+    """6 Adam steps (3 batches x 2 epochs, short last batch): (a) train_step = HIP fwd/bwd + HIP
+    Adam, (b) autograd path + torch.optim.Adam; both must land on the reference's weights."""
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, "traj_reg_d16.npz"))
+    from vae_amd.model import VFM
+    N, M, d = int(z["N"]), int(z["M"]), int(z["d"])
+    nb, B, lr = int(z["nb_train"]), int(z["batch"]), float(z["lr"])
+    X, Y = torch.tensor(z["x"]), torch.tensor(z["y"])
+
+    def fresh():
+        torch.manual_seed(42)
+        m = VFM(N, M, d, device=dev)
+        for k in PARAM_KEYS:
+            assert np.array_equal(dict(m.state_dict())[k if "params" not in k else k + ".weight"].cpu().numpy(),
+                                  z["p0_" + k]), k
+        m.set_training_data(X, nb_train=nb)
+        assert np.array_equal(m.nb_occ.cpu().numpy(), z["nb_occ"])
+        return m
+
+    def eps_of(step):
+        T = N + M
+        ev = torch.zeros(T, d)
+        ew = torch.zeros(T)
+        u = torch.tensor(z[f"s{step}_uniq"])
+        ev[u] = torch.tensor(z[f"s{step}_eps_v"])
+        ew[u] = torch.tensor(z[f"s{step}_eps_w"])
+        return ev.to(dev), ew.to(dev), torch.tensor(z[f"s{step}_eps0"]).to(dev)
+
+    for mode in ("hip_adam", "torch_adam"):
+        m = fresh()
+        opt = torch.optim.Adam(m.parameters(), lr=lr) if mode == "torch_adam" else None
+        step = 0
+        for _ in range(int(z["n_epochs"])):
+            for lo in range(0, nb, B):
+                plan = m.plan(X[lo:lo + B], Y[lo:lo + B])
+                if mode == "hip_adam":
+                    loss3, pred = m.train_step(plan, lr=lr, eps=eps_of(step))
+                    loss = loss3[0].item()
+                else:
+                    l, pred, _ = m.elbo(plan=plan, eps=eps_of(step))
+                    opt.zero_grad()
+                    l.backward()
+                    opt.step()
+                    loss = l.item()
+                assert abs(loss - z["losses"][step]) / abs(z["losses"][step]) < 1e-4, (mode, step)
+                assert rel_err(pred.cpu().numpy(), z[f"s{step}_pred"]) < 1e-3
+                step += 1
+        sd = m.state_dict()
+        for k in PARAM_KEYS:
+            got = sd[k if "params" not in k else k + ".weight"].cpu().numpy()
+            assert rel_err(got, z["pT_" + k]) < 2e-3, (mode, k)
+
+
+def test_fit_predict_fraction_runs_and_learns(tmp_path):
+    """cfg 1 plumbing: the shipped toy data (copied fixture of data/fraction/data.csv), d=5, Bernoulli."""
+    from vae_amd.model import VFM
+    from vae_amd.data import load_fraction
+    N, M, Xtr, Xte, ytr, yte = load_fraction(os.path.join(GOLDEN, "fraction"))
+    torch.manual_seed(42)
+    m = VFM(N, M, 5, output="class", device="cuda")
+    hist = m.fit(Xtr, ytr, n_epochs=60, batch_size=100000, X_test=Xte, y_test=yte, display_every=20,
+                 verbose=False)
+    assert hist["elbo"][-1] < hist["elbo"][0]
+    assert hist["test"][-1]["auc"] > 0.70          # libFM MCMC reaches 0.80 on this set (table.py:21)
+    out = m.predict(Xte)
+    assert out["y_pred"].shape == (len(yte),) and out["y_pred"].min() >= 0 and out["y_pred"].max() <= 1
+
+
+def test_predict_reg_four_predictors():
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    torch.manual_seed(0)
+    X, y = synthetic_triples([200, 300], 6000, seed=3)
+    m = VFM(200, 300, 8, device="cuda")
+    m.fit(X[:5000], y[:5000], n_epochs=3, batch_size=2000, verbose=False)
+    out = m.predict(X[5000:])
+    for k in ("y_pred", "mean_pred", "y_pred_of_last", "y_pred_of_mean"):
+        assert out[k].shape == (1000,)
+        assert out[k].min() >= 1 - 1e-6 or k == "y_pred_of_last"
+    lik, last, mean, kl = m(X[5000:])
+    assert lik.mean.shape == (1, 1000) and lik.log_prob(y[5000:].cuda()).shape == (1, 1000)
+
+
+def test_out_of_range_ids_raise():
+    from vae_amd.model import VFM
+    m = VFM(10, 10, 4, device="cuda")
+    m.set_training_data(torch.tensor([[0, 10]]), nb_train=1)
+    with pytest.raises(IndexError):
+        m.plan(torch.tensor([[0, 20]]), torch.tensor([1.0]))
+
+
+def test_philox_mode_matches_table_mode_and_is_standard_normal():
+    from vae_amd import ops
+    dev = torch.device("cuda:0")
+    c = Case("ml100k_reg_d20")
+    m = _model_from_case(c, dev)
+    spec = m.spec()
+    ee, eb, eg = ops.philox_eps(spec, seed=99, step=5, device=dev)
+    assert abs(ee.mean().item()) < 0.02 and abs(ee.std().item() - 1) < 0.02
+    assert abs((ee ** 4).mean().item() - 3) < 0.15
+    ee2, _, _ = ops.philox_eps(spec, seed=99, step=6, device=dev)
+    assert abs((ee * ee2).mean().item()) < 0.02            # steps are independent streams
+    plan = m.plan(torch.tensor(c.x), torch.tensor(c.y))
+    ent, bia, scal = m._views(m._flat)
+    a = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, eps=None, seed=99, step=5)
+    b = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, eps=(ee, eb, eg))
+    la, lb = ops.elbo_finalize(a, scal)[0].item(), ops.elbo_finalize(b, scal)[0].item()
+    assert abs(la - lb) / abs(lb) < 1e-6
+    ga = ops.elbo_backward(plan, a, ent, bia, scal, m.inv_occ, torch.ones(1, device=dev))
+    gb = ops.elbo_backward(plan, b, ent, bia, scal, m.inv_occ, torch.ones(1, device=dev))
+    assert rel_err(ga[0].cpu().numpy(), gb[0].cpu().numpy()) < 1e-6

@@ -1,0 +1,402 @@
+"""`VFM` -- the reference's `CF` module + training / evaluation loop (vfm-torch.py:129-422) on
+the HIP hot path.
+
+What maps to what
+  CF.__init__ (vfm-torch.py:133-164)      -> VFM.__init__  (same parameter names, shapes, init order)
+  CF.forward  (:189-324) + loss (:359)    -> VFM.elbo(x, y)   differentiable (autograd.Function)
+                                             VFM.forward(x)   inference, likelihood-like result
+  loop body   (:351-370)                  -> VFM.train_step(plan)   fwd + bwd + Adam, no autograd
+  training loop / eval (:337-422)         -> VFM.fit(...)
+  eval block  (:402-417) + save_weights   -> VFM.predict(X)
+All arithmetic of forward / backward / Adam runs in libvfm_hip.so; torch provides device memory,
+streams, (optionally) autograd and torch.distributed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+
+class LikelihoodResult:
+    """Stand-in for the torch.distributions object `CF.forward` returns (vfm-torch.py:267-270):
+    `.mean` and `.log_prob(y)` with batch shape [1, B] (S = 1 sample)."""
+
+    def __init__(self, pred: torch.Tensor, output: str, alpha: torch.Tensor):
+        self.logits = pred.reshape(1, -1)
+        self.output = output
+        self._alpha = alpha
+
+    @property
+    def mean(self):
+        return self.logits if self.output == "reg" else torch.sigmoid(self.logits)
+
+    def log_prob(self, y):
+        y = y.to(self.logits.dtype).reshape(1, -1)
+        if self.output == "reg":
+            a = self._alpha.abs()
+            return -0.5 * a * (y - self.logits) ** 2 + 0.5 * torch.log(a) - 0.5 * math.log(2 * math.pi)
+        return y * self.logits - torch.nn.functional.softplus(self.logits)
+
+
+def _round4(n):
+    return (n + 3) // 4 * 4
+
+
+class VFM(nn.Module):
+    """Variational Factorization Machine.
+
+    Reference mode: `VFM(N, M, embedding_size, output)` -- two fields (user, item+N), the
+    `<= N` group test of vfm-torch.py:316 reproduced (`quirk_le_N=True`).
+    General mode: `VFM(field_sizes=[n_0, ..., n_{F-1}], ...)` -- F fields with consecutive id ranges.
+    Build it under `torch.manual_seed(s)` to get the initial weights the reference gets under the
+    same seed (alpha ~ U(0,1), then the two N(0,1) embedding tables, drawn on the CPU).
+    """
+
+    def __init__(self, N: Optional[int] = None, M: Optional[int] = None, embedding_size: int = 20,
+                 output: str = "reg", field_sizes: Optional[Sequence[int]] = None,
+                 quirk_le_N: bool = True, device="cuda", rng_seed: int = 0):
+        super().__init__()
+        if field_sizes is None:
+            if N is None or M is None:
+                raise ValueError("give N and M, or field_sizes")
+            field_sizes = [int(N), int(M)]
+        self.field_sizes = [int(s) for s in field_sizes]
+        self.F = len(self.field_sizes)
+        self.T = int(sum(self.field_sizes))
+        self.N, self.M = self.field_sizes[0], (self.field_sizes[1] if self.F > 1 else 0)
+        self.d = int(embedding_size)
+        if output not in ("reg", "class"):
+            raise ValueError("output must be 'reg' or 'class'")
+        self.output = output
+        hi = np.cumsum(self.field_sizes).astype(np.int64)
+        if quirk_le_N and self.F == 2:
+            hi[0] += 1                      # `uniq_entities <= N` (vfm-torch.py:316)
+        self.group_hi = tuple(int(h) for h in hi)
+        self.group_n = tuple(float(s) for s in self.field_sizes)
+        self.rng_seed = int(rng_seed)
+        self.global_step = 0
+
+        # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
+        alpha = torch.rand(1)                                   # nn.init.uniform_ (:145)
+        self.prec_global_bias_prior = nn.Parameter(torch.ones(1))    # unused, as in the reference (:139-143)
+        self.prec_user_bias_prior = nn.Parameter(torch.ones(1))
+        self.prec_item_bias_prior = nn.Parameter(torch.ones(1))
+        self.prec_user_entity_prior = nn.Parameter(torch.ones(self.d))
+        self.prec_item_entity_prior = nn.Parameter(torch.ones(self.d))
+        bias = torch.randn(self.T, 2)                           # nn.Embedding default init (:152)
+        entity = torch.randn(self.T, 2 * self.d)                # (:153)
+
+        # one flat fp32 buffer [entity | bias | alpha, m0, s0 | pad]; the nn.Parameters are views
+        # (a single fused Adam launch and a single all-reduce cover everything)
+        self._n_ent, self._n_bias = self.T * 2 * self.d, self.T * 2
+        self._off_bias = _round4(self._n_ent)
+        self._off_scal = self._off_bias + _round4(self._n_bias)
+        self._n_flat = self._off_scal + 4
+        flat = torch.zeros(self._n_flat)
+        flat[: self._n_ent] = entity.reshape(-1)
+        flat[self._off_bias: self._off_bias + self._n_bias] = bias.reshape(-1)
+        flat[self._off_scal: self._off_scal + 3] = torch.tensor([alpha.item(), 0.0, 1.0])
+        self.alpha = nn.Parameter(torch.empty(1))
+        self.global_bias_mean = nn.Parameter(torch.empty(1))
+        self.global_bias_scale = nn.Parameter(torch.empty(1))
+        self.bias_params = nn.Embedding(self.T, 2, _weight=torch.empty(self.T, 2))
+        self.entity_params = nn.Embedding(self.T, 2 * self.d, _weight=torch.empty(self.T, 2 * self.d))
+        self._flat = flat.to(device)
+        self._tie()
+
+        # training state set by set_training_data()
+        self.nb_train = 1
+        self.inv_occ = None
+        self.nb_occ = None
+        self.lr = None
+        self._adam_m = self._adam_v = self._gflat = None
+        self._adam_t = 0
+        # epoch-averaged posterior means (save_weights, vfm-torch.py:179-185)
+        self._n_saved = 0
+        self._mean_flat = None
+        self._last_flat = None
+        self._all_preds_sum = None
+        self._all_preds_n = 0
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _tie(self):
+        f = self._flat
+        self.entity_params.weight.data = f[: self._n_ent].view(self.T, 2 * self.d)
+        self.bias_params.weight.data = f[self._off_bias: self._off_bias + self._n_bias].view(self.T, 2)
+        self.alpha.data = f[self._off_scal: self._off_scal + 1]
+        self.global_bias_mean.data = f[self._off_scal + 1: self._off_scal + 2]
+        self.global_bias_scale.data = f[self._off_scal + 2: self._off_scal + 3]
+
+    def _views(self, flat):
+        return (flat[: self._n_ent].view(self.T, 2 * self.d),
+                flat[self._off_bias: self._off_bias + self._n_bias].view(self.T, 2),
+                flat[self._off_scal: self._off_scal + 3])
+
+    def _apply(self, fn, *a, **k):
+        # keep the parameters tied to the flat buffer across .to()/.cuda()
+        with torch.no_grad():
+            cur = torch.cat([self.entity_params.weight.reshape(-1),
+                             torch.zeros(self._off_bias - self._n_ent, device=self._flat.device),
+                             self.bias_params.weight.reshape(-1),
+                             torch.zeros(self._off_scal - self._off_bias - self._n_bias, device=self._flat.device),
+                             self.alpha, self.global_bias_mean, self.global_bias_scale,
+                             torch.zeros(1, device=self._flat.device)])
+        out = super()._apply(fn, *a, **k)
+        self._flat = fn(cur)
+        self._tie()
+        for name in ("inv_occ", "nb_occ", "_adam_m", "_adam_v", "_gflat", "_mean_flat", "_last_flat"):
+            t = getattr(self, name, None)
+            if t is not None:
+                setattr(self, name, fn(t))
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self._tie()
+        return out
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    def spec(self) -> ops.Spec:
+        lik = _lib.LIK_NORMAL if self.output == "reg" else _lib.LIK_BERNOULLI
+        return ops.Spec(T=self.T, F=self.F, d=self.d, group_hi=self.group_hi, group_n=self.group_n,
+                        likelihood=lik, nb_train=int(self.nb_train))
+
+    # ------------------------------------------------------------------ data-dependent state
+    def set_training_data(self, X_train: torch.Tensor, nb_train: Optional[int] = None,
+                          nb_occ: Optional[torch.Tensor] = None):
+        """nb_occ = bincount(X_train.flatten()) (vfm-torch.py:89) and nb_train (:91)."""
+        X_train = torch.as_tensor(X_train)
+        self.nb_train = int(nb_train if nb_train is not None else X_train.shape[0])
+        if nb_occ is None:
+            nb_occ = torch.bincount(X_train.reshape(-1).to(self.device).to(torch.int64), minlength=self.T)
+        self.nb_occ = torch.as_tensor(nb_occ).to(self.device).to(torch.int64).contiguous()
+        if self.nb_occ.numel() != self.T:
+            raise ValueError("nb_occ must have one entry per entity")
+        self.inv_occ = ops.inv_occ_from_counts(self.nb_occ)
+
+    def plan(self, x, y=None, B_global=None, build_index=True, process_group=None) -> ops.BatchPlan:
+        x = torch.as_tensor(x).to(self.device)
+        if x.dtype not in (torch.int32, torch.int64):
+            x = x.to(torch.int64)
+        x = x.contiguous()
+        if y is not None:
+            y = torch.as_tensor(y).to(self.device)
+            if self.inv_occ is None:
+                raise RuntimeError("call set_training_data() before building training plans")
+        return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
+                             build_index=build_index and y is not None, process_group=process_group)
+
+    # ------------------------------------------------------------------ forward surfaces
+    def _scalars(self):
+        return self._flat[self._off_scal: self._off_scal + 3]
+
+    def elbo(self, x=None, y=None, plan: Optional[ops.BatchPlan] = None, eps=None):
+        """Differentiable ELBO loss of one batch: `-log_prob(y).mean()*nb_train + kl`
+        (vfm-torch.py:353-359).  Returns (loss[1], pred[B], detail[3] = loss, nll, kl)."""
+        if plan is None:
+            plan = self.plan(x, y)
+        step = self.global_step
+        self.global_step += 1
+        return ops.ElboFunction.apply(self.entity_params.weight, self.bias_params.weight, self.alpha,
+                                      self.global_bias_mean, self.global_bias_scale, plan, self.inv_occ,
+                                      eps, self.rng_seed, step)
+
+    @torch.no_grad()
+    def forward(self, x, eps=None, sample=True):
+        """Inference surface of `CF.forward(x)` (vfm-torch.py:189-324): returns
+        (likelihood, last_logits, mean_logits, kl_term).  `likelihood.mean` is the prediction from
+        a fresh posterior sample; last/mean logits are the deterministic predictions from the last /
+        epoch-averaged posterior means once `save_weights()` has run (None before).  The KL branch
+        is not evaluated on inference inputs (kl_term is None)."""
+        plan = self.plan(x, None) if not isinstance(x, ops.BatchPlan) else x
+        ent, bia, scal = self._views(self._flat)
+        step = self.global_step
+        self.global_step += 1
+        st = ops.elbo_forward(plan, ent, bia, scal, None, eps=eps, seed=self.rng_seed, step=step,
+                              train=False, flags=0 if sample else ops.FLAG_EPS_ZERO)
+        lik = LikelihoodResult(st.pred, self.output, self.alpha.detach())
+        last = mean = None
+        if self._n_saved > 0:
+            last = self._mean_logits(plan, self._last_flat)
+            mean = self._mean_logits(plan, self._mean_flat)
+        return lik, last, mean, None
+
+    def _mean_logits(self, plan, flat):
+        ent, bia, scal = self._views(flat)
+        st = ops.elbo_forward(plan, ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
+        return st.pred
+
+    @torch.no_grad()
+    def save_weights(self):
+        """Snapshot the posterior means and update their running average over epochs
+        (vfm-torch.py:179-185; the reference keeps every snapshot and re-averages, the running
+        mean is the same quantity)."""
+        cur = self._flat.detach().clone()
+        self._last_flat = cur
+        self._n_saved += 1
+        if self._mean_flat is None:
+            self._mean_flat = cur.clone()
+        else:
+            self._mean_flat += (cur - self._mean_flat) / self._n_saved
+
+    # ------------------------------------------------------------------ training
+    def _ensure_opt_state(self):
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self._flat)
+            self._adam_v = torch.zeros_like(self._flat)
+            self._gflat = torch.zeros(self._n_flat + 4, dtype=torch.float32, device=self.device)
+            self._adam_t = 0
+            self._gout = torch.ones(1, dtype=torch.float32, device=self.device)
+
+    def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
+                   process_group=None, adam: bool = True, mark=None):
+        """One iteration of vfm-torch.py:351-370 without autograd: forward, loss, backward, dense
+        Adam (betas (0.9, 0.999), eps 1e-8).  Everything is enqueued on the current stream; nothing
+        synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B])."""
+        self._ensure_opt_state()
+        lr = self.lr if lr is None else lr
+        if lr is None:
+            raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
+        ent, bia, scal = self._views(self._flat)
+        g_ent, g_bias, g_scal = self._views(self._gflat)
+        loss3 = self._gflat[self._n_flat: self._n_flat + 3]
+        rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        flags = ops.FLAG_NO_PRIOR_TERMS if rank != 0 else 0
+        step = self.global_step
+        self.global_step += 1
+        mark = mark or (lambda name: None)      # bench.py records HIP events at these points
+        mark("start")
+        st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
+                              train=True, flags=flags, out_pred=out_pred)
+        mark("fwd")
+        ops.elbo_finalize(st, scal, out=loss3)
+        mark("finalize")
+        ops.elbo_backward(plan, st, ent, bia, scal, self.inv_occ, self._gout, g_ent, g_bias, g_scal)
+        mark("bwd")
+        if process_group is not None:
+            # the ONE collective of the step: [g_entity | g_bias | g_scalars | loss] summed over ranks
+            torch.distributed.all_reduce(self._gflat, group=process_group)
+            mark("allreduce")
+        if adam:
+            self._adam_t += 1
+            ops.adam_step(self._flat, self._gflat, self._adam_m, self._adam_v, lr, self._adam_t)
+            mark("adam")
+        return loss3, st.pred
+
+    def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,
+            y_test=None, display_every: int = 1, lr: Optional[float] = None, verbose: bool = True,
+            process_group=None):
+        """The training loop of vfm-torch.py:337-422: sequential batches without shuffling
+        (:121-122), lr = 1/(1 + nb_train // batch_size) (:92), dense Adam, per-epoch train metrics,
+        `save_weights()` each epoch for 'reg' (:380), test metrics every `display_every` epochs.
+        With a process group, every batch is split in contiguous row blocks over the ranks.
+        Returns a history dict (lists per evaluated epoch)."""
+        X_train = torch.as_tensor(X_train)
+        y_train = torch.as_tensor(y_train, dtype=torch.float32)
+        nb_train = X_train.shape[0]
+        self.set_training_data(X_train, nb_train)
+        self.lr = lr if lr is not None else 1.0 / (1 + nb_train // batch_size)
+        world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        Xd = X_train.to(self.device)
+        yd = y_train.to(self.device)
+        plans, spans = [], []
+        for lo in range(0, nb_train, batch_size):
+            hi = min(lo + batch_size, nb_train)
+            a, b = shard_rows(lo, hi, rank, world)
+            plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group))
+            spans.append((a, b))
+        train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
+        hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
+        losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
+        for epoch in range(n_epochs):
+            for i, (plan, (a, b)) in enumerate(zip(plans, spans)):
+                loss3, _ = self.train_step(plan, out_pred=train_pred[a:b], process_group=process_group)
+                losses[i] = loss3[0]
+            # ---- end of epoch (vfm-torch.py:378-384)
+            if self.output == "reg":
+                self.save_weights()
+            if epoch % display_every == 0:
+                rec = {"epoch": epoch, "elbo": float(losses.mean())}
+                tp = train_pred
+                if world > 1:       # each rank only wrote its own row blocks (the rest stays 0)
+                    tp = train_pred.clone()
+                    torch.distributed.all_reduce(tp, group=process_group)
+                if self.output == "reg":
+                    pr = tp.clamp(1, 5)
+                    rec["train_rmse"] = float(torch.sqrt(torch.mean((pr - yd) ** 2)))
+                else:
+                    rec["train_auc"], rec["train_map"] = _auc_map(yd, torch.sigmoid(tp))
+                if X_test is not None:
+                    rec["test"] = self.evaluate(X_test, y_test)
+                hist["epoch"].append(epoch)
+                hist["elbo"].append(rec["elbo"])
+                hist["train_rmse"].append(rec.get("train_rmse"))
+                hist["train_auc"].append(rec.get("train_auc"))
+                hist["test"].append(rec.get("test"))
+                if verbose and rank == 0:
+                    print(f"Epoch {epoch}: Elbo {rec['elbo']:.4f} " +
+                          (f"Minibatch train RMSE {rec['train_rmse']:.4f}" if self.output == "reg" else
+                           f"Minibatch train AUC {rec['train_auc']:.4f} Minibatch train MAP {rec['train_map']:.4f}"),
+                          rec.get("test", ""))
+        return hist
+
+    @torch.no_grad()
+    def predict(self, X):
+        """The four predictors of the evaluation block (vfm-torch.py:402-417):
+        y_pred (fresh posterior sample), mean_pred (average of y_pred over the calls so far --
+        "Test RMSE all"), y_pred_of_last / y_pred_of_mean (deterministic, from the last /
+        epoch-averaged posterior means; None until save_weights() has run).  'reg' outputs are
+        clipped to [1, 5] like the reference (:405-406); 'class' outputs are probabilities."""
+        lik, last, mean, _ = self.forward(X)
+        y_pred = lik.mean.reshape(-1)
+        if self.output == "reg":
+            y_pred = y_pred.clamp(1, 5)
+            mean = mean.clamp(1, 5) if mean is not None else None
+        else:
+            last = torch.sigmoid(last) if last is not None else None
+            mean = torch.sigmoid(mean) if mean is not None else None
+        if self._all_preds_sum is None or self._all_preds_sum.shape != y_pred.shape:
+            self._all_preds_sum = torch.zeros_like(y_pred)
+            self._all_preds_n = 0
+        self._all_preds_sum += y_pred
+        self._all_preds_n += 1
+        return {"y_pred": y_pred, "mean_pred": self._all_preds_sum / self._all_preds_n,
+                "y_pred_of_last": last, "y_pred_of_mean": mean}
+
+    @torch.no_grad()
+    def evaluate(self, X_test, y_test):
+        """Test metrics of vfm-torch.py:410-422."""
+        out = self.predict(X_test)
+        y = torch.as_tensor(y_test, dtype=torch.float32).to(self.device)
+        if self.output == "reg":
+            rm = lambda p: None if p is None else float(torch.sqrt(torch.mean((p - y) ** 2)))
+            return {"rmse": rm(out["y_pred"]), "rmse_all": rm(out["mean_pred"]),
+                    "rmse_of_last": rm(out["y_pred_of_last"]), "rmse_of_mean": rm(out["y_pred_of_mean"])}
+        auc, ap = _auc_map(y, out["y_pred"])
+        return {"auc": auc, "map": ap}
+
+
+def shard_rows(lo: int, hi: int, rank: int, world: int):
+    """Contiguous row block of batch [lo, hi) owned by `rank`."""
+    n = hi - lo
+    per = (n + world - 1) // world
+    a = min(lo + rank * per, hi)
+    return a, min(a + per, hi)
+
+
+def _auc_map(y, p):
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    yy, pp = y.detach().cpu().numpy(), p.detach().cpu().numpy()
+    if len(np.unique(yy)) < 2:
+        return float("nan"), float("nan")
+    return float(roc_auc_score(yy, pp)), float(average_precision_score(yy, pp))
