@@ -13,8 +13,8 @@ uniform-random ids, ratings randint(1,6), eps generated in-kernel (Philox).
 N>1: every rank processes its own B rows of a global batch of N*B rows (weak scaling), tables
 replicated, one all-reduce of the flat gradient buffer per step.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the slower of the two ELBO kernels;
-`kernels` lists all of them.  `cpu_baseline` = the reference-shaped torch-CPU restatement
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel that takes the most time per
+step (its `elbo_fwd_kernel` entry is the fused forward ELBO kernel); `kernels` lists all of them.  `cpu_baseline` = the reference-shaped torch-CPU restatement
 (oracle/vfm_oracle.py, pinned to the reference by tests/golden) timed on this node's host cores.
 """
 import argparse
@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--sync-each-step", action="store_true", help="debug: host sync after every step")
+    ap.add_argument("--unfused", action="store_true", help="separate backward and Adam kernels (as N>1 does)")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +107,7 @@ def main():
     U = sum(uniq) / len(uniq)
 
     events = []
+    dummy = torch.zeros(1, device=dev)
 
     def run(n, record):
         for s in range(n):
@@ -118,7 +121,11 @@ def main():
                     ev[name] = e
             else:
                 mark = None
-            model.train_step(plans[s % nbt], process_group=pg, mark=mark)
+            model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused)
+            if args.sync_each_step:
+                torch.cuda.synchronize()
+            if os.environ.get("VFM_DBG_TORCHOP"):
+                dummy.add_(1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,38 +144,41 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
         dt = float(t.item())
     loss = float(model._gflat[model._n_flat].item())
+    nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region
     kern = {}
+    roof = None
     if events:
-        order = ["start", "fwd", "finalize", "bwd"] + (["allreduce"] if world > 1 else []) + ["adam"]
+        order = list(events[0].keys())           # marks in launch order: start, fwd, finalize, ...
         acc = {k: 0.0 for k in order[1:]}
         for ev in events:
-            for a, b in zip(order[:-1], order[1:]):
-                acc[b] += ev[a].elapsed_time(ev[b])
+            for a_, b_ in zip(order[:-1], order[1:]):
+                acc[b_] += ev[a_].elapsed_time(ev[b_])
         n_params = model._n_flat
-        bytes_fwd = U * (8 * d + 16) + B * (8 * F + 8)            # SURVEY 8(d), eps in-kernel
-        bytes_bwd = bytes_fwd + U * (8 * d + 8)
-        alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params,
-               "finalize": 0.0, "allreduce": 4.0 * n_params}
+        # ALGORITHMIC bytes per launch (fp32 params, ids as given, eps in-kernel):
+        idb = 4 if args.id32 else 8
+        bytes_fwd = U * (8 * d + 16) + B * (idb * F + 8)          # touched rows once + ids, y, pred
+        bytes_bwd = bytes_fwd + U * (8 * d + 8)                   # re-read + one write per touched row
+        alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
+               "allreduce": 4.0 * n_params,
+               # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
+               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params}
+        names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
+                 "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
+                 "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat gradient"}
         for k, ms in acc.items():
             us = ms / len(events) * 1e3
             gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0
-            kern[k] = {"avg_us": round(us, 2), "alg_bytes": int(alg[k]), "achieved_GBs": round(gbs, 1),
-                       "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-    roof = None
-    if kern:
-        dom = max(("fwd", "bwd"), key=lambda k: kern[k]["avg_us"])
-        kname = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)"}[dom]
-        roof = {"kernel": kname, "bound": "hbm", "achieved": kern[dom]["achieved_GBs"],
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac_hbm_peak"],
-                "traffic": None,
-                "elbo_fwd_bwd": {
-                    "alg_bytes": kern["fwd"]["alg_bytes"] + kern["bwd"]["alg_bytes"],
-                    "avg_us": round(kern["fwd"]["avg_us"] + kern["bwd"]["avg_us"], 2),
-                    "achieved": round((kern["fwd"]["alg_bytes"] + kern["bwd"]["alg_bytes"]) /
-                                      ((kern["fwd"]["avg_us"] + kern["bwd"]["avg_us"]) * 1e-6) / 1e9, 1)}}
-        roof["elbo_fwd_bwd"]["frac"] = round(roof["elbo_fwd_bwd"]["achieved"] / HBM_PEAK_GBS, 4)
+            kern[k] = {"kernel": names[k], "avg_us": round(us, 2), "alg_bytes": int(alg[k]),
+                       "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        cand = [k for k in kern if k not in ("finalize", "allreduce")]
+        dom = max(cand, key=lambda k: kern[k]["avg_us"])
+        roof = {"kernel": kern[dom]["kernel"], "bound": "hbm", "achieved": kern[dom]["achieved_GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac_hbm_peak"], "traffic": None,
+                "avg_us": kern[dom]["avg_us"], "alg_bytes": kern[dom]["alg_bytes"],
+                "elbo_fwd_kernel": {"achieved": kern["fwd"]["achieved_GBs"], "frac": kern["fwd"]["frac_hbm_peak"],
+                                    "avg_us": kern["fwd"]["avg_us"], "alg_bytes": kern["fwd"]["alg_bytes"]}}
 
     # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
     cpu = None
@@ -188,9 +198,10 @@ def main():
                        "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "item-sorted" if args.sort_items else "as-generated",
-                       "step": "fwd+loss+bwd+" + ("allreduce+" if world > 1 else "") + "dense-adam",
+                       "step": ("fwd+loss+bwd+" + ("allreduce+" if world > 1 else "") + "dense-adam") if
+                               (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
                        "parallelism": f"row-sharded dp{world}"},
-            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss,
+            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
         }
         print(json.dumps(out))
     if world > 1:

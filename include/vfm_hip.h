@@ -101,13 +101,16 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
  * per-row terms of the loss :359): gathers, reparameterised sample z = mu + |s| * eps,
  * FM prediction  pred_r = w0 + sum_f w_f + 1/2 sum_k[(sum_f z_fk)^2 - sum_f z_fk^2],
  * log-likelihood, KL-to-prior with occurrence re-weighting.
- *  in : x [B,F], y [B] (may be NULL => prediction only: no likelihood / KL / training state)
+ *  in : x [B,F], y [B] (NULL => prediction only: no likelihood / KL / training state; then
+ *       inv_occ, W, sumz, grow may be NULL too.  With y, all of them are required.)
  *       W [F] batch-global normalisers, eps_* tables indexed BY ENTITY ID
  *       (eps_entity [T,d], eps_bias [T], eps_global [1]) or all three NULL => Philox.
  *  out: pred [B]      unscaled prediction (logit for Bernoulli)
  *       partials [VFM_N_PARTIALS] fp64, zeroed by the call (see VFM_P_*)
- *       sumz [B,d] and grow [B] (both may be NULL together): training state for the
- *       backward call: sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.        */
+ *       sumz [B,d] and grow [B]: training state for the backward call:
+ *       sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.
+ *  eps: Philox mode draws, per entity and step, d embedding normals + 1 first-order-weight
+ *       normal from Philox4x32-10(ctr = (k/4, e, step), key = seed) (see vfm_philox_eps_f32).  */
 int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      const float* entity_params, const float* bias_params,
                      const float* inv_occ, const float* scalars, const double* W,
@@ -134,6 +137,21 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
                      const float* sumz, const float* grow, const double* partials,
                      const float* grad_out, float* g_entity, float* g_bias, float* g_scalars,
                      void* stream);
+
+/* Backward with the dense Adam update fused in (single rank): the same gradient as
+ * vfm_elbo_bwd_f32 with grad_out = 1, applied at once to (param, m, v) of every table row and of
+ * the three scalars with torch.optim.Adam's update (defaults of vfm-torch.py:339; `step` is the
+ * 1-based update count).  The gradient never reaches HBM.  In place on entity_params, bias_params,
+ * scalars and the six moment buffers (same shapes as their parameters).  Rows not in the batch
+ * still move through their momentum, exactly like the reference's dense Adam. */
+int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+                          float* entity_params, float* bias_params, float* scalars,
+                          const float* inv_occ, const double* W,
+                          const float* eps_entity, const float* eps_bias, const float* eps_global,
+                          const float* sumz, const float* grow, const double* partials,
+                          float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                          float* m_scalars, float* v_scalars,
+                          float lr, float beta1, float beta2, float eps_adam, int64_t step, void* stream);
 
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of

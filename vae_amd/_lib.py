@@ -25,7 +25,7 @@ LIK_NORMAL, LIK_BERNOULLI = 0, 1
 EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
-    "vfm_adam_f32",
+    "vfm_adam_f32", "vfm_elbo_bwd_adam_f32",
 )
 
 
@@ -69,6 +69,8 @@ def load():
     lib.vfm_elbo_finalize_f32.argtypes = [PP, vp, vp, vp, vp]
     lib.vfm_elbo_bwd_f32.argtypes = [PP] + [vp] * 18
     lib.vfm_philox_eps_f32.argtypes = [PP, vp, vp, vp, vp]
+    lib.vfm_elbo_bwd_adam_f32.argtypes = ([PP] + [vp] * 19 +
+                                          [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                  i64, vp]
     for name in EXPORTS:

@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "vfm_hip.h"
 
@@ -76,14 +77,20 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-enum { TAG_ENTITY = 0, TAG_BIAS = 1, TAG_GLOBAL = 2 };
-
-__device__ __forceinline__ void normal4(const RngKey& k, uint32_t e, uint32_t j, uint32_t tag,
-                                        float n[4]) {
+// Philox4x32-10 with counter (j, e, step_lo, step_hi) and key (seed_lo, seed_hi) gives, for
+// entity e at this step: the 4 normals of coordinates 4j..4j+3 (24-bit Box-Muller on the high
+// bits of the 4 words) and -- from the 32 spare low bits of the same 4 words, used for j == 0 only
+// -- one more normal `nb`, the eps of the entity's first-order weight (20-bit radius, 12-bit
+// angle).  The global-bias eps is n[0] of the reserved id e = 0xFFFFFFFF.
+__device__ __forceinline__ void normal4b(const RngKey& k, uint32_t e, uint32_t j, float n[4], float& nb) {
   uint32_t o[4];
-  philox4x32_10(j, e, k.step_lo, k.step_hi ^ (tag << 30), k.seed_lo, k.seed_hi, o);
+  philox4x32_10(j, e, k.step_lo, k.step_hi, k.seed_lo, k.seed_hi, o);
   box_muller(o[0], o[1], n[0], n[1]);
   box_muller(o[2], o[3], n[2], n[3]);
+  const uint32_t w = (o[0] & 0xFFu) | ((o[1] & 0xFFu) << 8) | ((o[2] & 0xFFu) << 16) | (o[3] << 24);
+  const float u1 = ((float)(w >> 12) + 0.5f) * 9.5367431640625e-7f;   // 2^-20
+  const float u2 = (float)(w & 0xFFFu) * 2.44140625e-4f;              // 2^-12 revolutions
+  nb = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -153,50 +160,22 @@ __device__ __forceinline__ void st_chunk(float* p, const Chunk<VEC>& c) {
   }
 }
 
-// eps for chunk j (coordinates j*VEC ..) of entity e: table or Philox
-template <int VEC>
-__device__ __forceinline__ Chunk<VEC> eps_chunk(const KArgs& a, uint32_t e, int j) {
-  if (a.flags & VFM_FLAG_EPS_ZERO) {
-    Chunk<VEC> z;
-#pragma unroll
-    for (int t = 0; t < VEC; ++t) z.v[t] = 0.f;
-    return z;
-  }
-  if (a.eps_entity) return ld_chunk<VEC>(a.eps_entity + (size_t)e * a.d + (size_t)j * VEC);
-  Chunk<VEC> c;
-  float n[4];
-  if constexpr (VEC == 4) {
-    normal4(a.key, e, (uint32_t)j, TAG_ENTITY, n);
-    c.v[0] = n[0]; c.v[1] = n[1]; c.v[2] = n[2]; c.v[3] = n[3];
-  } else {
-    normal4(a.key, e, (uint32_t)j >> 2, TAG_ENTITY, n);
-    c.v[0] = n[j & 3];
-  }
-  return c;
-}
-
-__device__ __forceinline__ float eps_bias_of(const KArgs& a, uint32_t e) {
-  if (a.flags & VFM_FLAG_EPS_ZERO) return 0.f;
-  if (a.eps_bias) return a.eps_bias[e];
-  float n[4];
-  normal4(a.key, e, 0u, TAG_BIAS, n);
-  return n[0];
-}
-
-__device__ __forceinline__ float eps_global_of(const KArgs& a) {
-  if (a.flags & VFM_FLAG_EPS_ZERO) return 0.f;
-  if (a.eps_global) return a.eps_global[0];
-  float n[4];
-  normal4(a.key, 0xFFFFFFFFu, 0u, TAG_GLOBAL, n);
-  return n[0];
-}
+// Guard for the |.| link (vfm-torch.py:126): a scale parameter that an Adam update lands on
+// EXACTLY 0.0f makes -log|s| and 1/|s| infinite (the reference would raise in
+// Normal(scale=0) / produce NaN).  With 2*10^7 scale parameters and lr-sized steps this exact
+// cancellation does happen within ~100 steps at ML-20M shape, so: log and 1/sigma use
+// max(|s|, SIGMA_MIN) and sign(0) := +1.  Identical to the reference wherever the reference is finite
+// and |s| >= SIGMA_MIN.
+constexpr float SIGMA_MIN = 1e-12f;
 
 __device__ __forceinline__ float kl_std_normal(float mu, float sg) {
   // KL(N(mu, sg) || N(0,1)) = 1/2 (sg^2 + mu^2 - 1) - log sg   (torch kl.py _kl_normal_normal)
-  return 0.5f * (sg * sg + mu * mu - 1.0f) - LN2 * __builtin_amdgcn_logf(sg);
+  return 0.5f * (sg * sg + mu * mu - 1.0f) - LN2 * __builtin_amdgcn_logf(fmaxf(sg, SIGMA_MIN));
 }
 
-__device__ __forceinline__ float signf(float s) { return (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float inv_sigma(float sg) { return 1.0f / fmaxf(sg, SIGMA_MIN); }
+
+__device__ __forceinline__ float signf(float s) { return (s < 0.f) ? -1.f : 1.f; }
 
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
@@ -232,6 +211,10 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV * 4] 
 // ---------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------
+__global__ void k_zero_f64(double* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.0;
+}
+
 __global__ void k_inv_occ(const int64_t* __restrict__ occ, float* __restrict__ inv, int64_t T) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < T;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -247,10 +230,10 @@ __global__ __launch_bounds__(BLOCK) void k_norms(const void* __restrict__ x, int
   // each thread walks occurrences o = t, t + stride...; stride is a multiple of F so the
   // field of a thread is fixed
   const int64_t stride0 = (int64_t)gridDim.x * BLOCK;
-  const int64_t stride = (stride0 + F - 1) / F * F;
+  const int64_t stride = stride0 / F * F;   // (threads t >= stride stay idle)
   const int64_t t = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
   float acc = 0.f;
-  for (int64_t o = t; o < n_occ; o += stride) {
+  for (int64_t o = (t < stride ? t : n_occ); o < n_occ; o += stride) {
     int64_t id = id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
     if (id >= 0 && id < T) acc += inv_occ[id];
   }
@@ -265,7 +248,7 @@ __global__ void k_finalize(const double* __restrict__ partials, const float* __r
   const double m0 = scalars[1], s0 = scalars[2];
   const double kl0 = (flags & VFM_FLAG_NO_PRIOR_TERMS)
                          ? 0.0
-                         : 0.5 * (s0 * s0 + m0 * m0 - 1.0) - log(fabs(s0));
+                         : 0.5 * (s0 * s0 + m0 * m0 - 1.0) - log(fmax(fabs(s0), (double)SIGMA_MIN));
   const double nll = -ll_scale * partials[VFM_P_LL];
   const double kl = kl0 + partials[VFM_P_KL];
   const bool bad = partials[VFM_P_BADID] != 0.0;
@@ -277,157 +260,328 @@ __global__ void k_finalize(const double* __restrict__ partials, const float* __r
 
 // ---------------------------------------------------------------------------------------
 // forward
+//
+// A lane group of LPE lanes owns one batch row at a time (rows are dealt round-robin over all
+// groups of the grid); lane `lig` owns chunks j = lig + i*LPE (i < CPL) of VEC coordinates.
+// Nothing is shared between groups: no LDS staging, no barrier in the row loop.  The dependent
+// chain per row is  ids -> table rows  and it is software-pipelined three deep:
+//     ids of row i+2  |  table-row loads of row i+1 (registers)  |  arithmetic of row i
+// so that every wave keeps 8d*F bytes per row in flight while the Philox / Box-Muller /
+// KL arithmetic of the previous row runs.  FF = 2 keeps both fields of a row in registers
+// (the reference's user/item case); FF = 0 streams a runtime number of fields.
 // ---------------------------------------------------------------------------------------
-template <int LPE, int CPL, int VEC>
+enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2 };
+enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
+
+template <int CPL, int VEC, int EPS>
+struct FieldRegs {            // everything one (row, field) occurrence needs, in registers
+  uint32_t e;
+  Chunk<VEC> mu[CPL], s[CPL], ep[CPL];
+  float2 th;                  // bias row (mu_w, s_w)
+  float io;                   // 1/occ
+  float epw;                  // bias eps (table mode)
+};
+
+template <int LPE, int CPL, int VEC, int EPS, int MODE>
+__device__ __forceinline__ void load_field(const KArgs& a, uint32_t e, int lig, int C,
+                                           FieldRegs<CPL, VEC, EPS>& R) {
+  const int d = a.d;
+  R.e = e;
+  const float* row = a.entity + (size_t)e * (2 * (size_t)d);
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int j = lig + i * LPE;
+    if (CPL == 1 && LPE * VEC == 0) {}
+    if (j < C) {
+      R.mu[i] = ld_chunk<VEC>(row + (size_t)j * VEC);
+      R.s[i] = ld_chunk<VEC>(row + d + (size_t)j * VEC);
+      if constexpr (EPS == EPS_TABLE) R.ep[i] = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
+    }
+  }
+  R.th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
+  if constexpr (MODE == MODE_TRAIN) R.io = a.inv_occ[e];
+  if constexpr (EPS == EPS_TABLE) R.epw = a.eps_bias[e];
+}
+
+__device__ __forceinline__ uint32_t load_id(const KArgs& a, int64_t pos, float& bad) {
+  int64_t id = a.id64 ? ((const int64_t*)a.x)[pos] : (int64_t)((const int32_t*)a.x)[pos];
+  if (id < 0 || id >= a.T) { bad += 1.f; id = 0; }
+  return (uint32_t)id;
+}
+
+// per-row running sums of one lane
+template <int CPL, int VEC>
+struct RowAcc {
+  Chunk<VEC> sz[CPL];
+  float zz, part, kl;
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) sz[i].v[t] = 0.f;
+    zz = 0.f; part = 0.f; kl = 0.f;
+  }
+};
+
+// arithmetic of one occurrence: sample, FM partial sums, KL
+template <int LPE, int CPL, int VEC, int EPS, int MODE>
+__device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CPL, VEC, EPS>& R, int lig,
+                                              int C, float cs, RowAcc<CPL, VEC>& acc) {
+  float klv = 0.f;
+  float epw = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int j = lig + i * LPE;
+    if (j < C) {
+      Chunk<VEC> ep;
+      if constexpr (EPS == EPS_TABLE) {
+        ep = R.ep[i];
+      } else if constexpr (EPS == EPS_ZERO) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) ep.v[t] = 0.f;
+      } else {
+        float n[4], nb;
+        normal4b(a.key, R.e, (uint32_t)(VEC == 4 ? j : (j >> 2)), n, nb);
+        if constexpr (VEC == 4) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ep.v[t] = n[t];
+        } else {
+          ep.v[0] = n[j & 3];
+        }
+        if (i == 0) epw = nb;   // only the lane that owns coordinate 0 (lig == 0) uses it
+      }
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) {
+        const float sg = fabsf(R.s[i].v[t]);
+        const float z = fmaf(sg, ep.v[t], R.mu[i].v[t]);
+        acc.sz[i].v[t] += z;
+        acc.zz = fmaf(z, z, acc.zz);
+        if constexpr (MODE == MODE_TRAIN) klv += kl_std_normal(R.mu[i].v[t], sg);
+      }
+    }
+  }
+  if constexpr (EPS == EPS_TABLE) epw = R.epw;
+  if (lig == 0) {
+    const float sgw = fabsf(R.th.y);
+    acc.part += fmaf(sgw, epw, R.th.x);
+    if constexpr (MODE == MODE_TRAIN) klv += kl_std_normal(R.th.x, sgw);
+  }
+  if constexpr (MODE == MODE_TRAIN) acc.kl = fmaf(cs * R.io, klv, acc.kl);
+}
+
+// finish a row: FM reduction over the group, likelihood, outputs
+template <int LPE, int CPL, int VEC, int MODE>
+__device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, int64_t r, int lig, int C,
+                                           float w0, float aabs, float half_log_a, float y,
+                                           RowAcc<CPL, VEC>& acc, float (&tot)[5]) {
+  float q = -acc.zz;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) q = fmaf(acc.sz[i].v[t], acc.sz[i].v[t], q);
+  const float pred = w0 + group_sum<LPE>(fmaf(0.5f, q, acc.part));
+  if constexpr (MODE == MODE_TRAIN) {
+    tot[1] += acc.kl;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int j = lig + i * LPE;
+      if (j < C) st_chunk<VEC>(out.sumz + (size_t)r * a.d + (size_t)j * VEC, acc.sz[i]);
+    }
+  }
+  if (lig == 0) {
+    out.pred[r] = pred;
+    if constexpr (MODE == MODE_TRAIN) {
+      float ll, dll;
+      if (a.lik == VFM_LIK_NORMAL) {
+        const float diff = y - pred;
+        ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
+        dll = aabs * diff;
+        tot[3] += 0.5f * diff * diff - 0.5f / aabs;
+      } else {
+        const float e1 = __expf(-fabsf(pred));
+        ll = y * pred - (fmaxf(pred, 0.f) + log1pf(e1));
+        dll = y - ((pred >= 0.f) ? 1.f / (1.f + e1) : e1 / (1.f + e1));
+      }
+      const float g = -a.ll_scale * dll;
+      tot[0] += ll;
+      tot[2] += g;
+      out.grow[r] = g;
+    }
+  }
+}
+
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF>
 __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) {
   constexpr int GPB = BLOCK / LPE;
-  __shared__ uint32_t sh_id[OCC_CAP];
-  __shared__ float sh_c[OCC_CAP];
-  __shared__ float sh_w[OCC_CAP];
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
   __shared__ float sh_red[5 * 4];
 
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
-  const int gi = tid / LPE;
-  const int F = a.F, d = a.d;
-  const int C = (d + VEC - 1) / VEC;
-  const bool have_y = a.y != nullptr;
-  const bool train = out.sumz != nullptr;
+  const int F = (FF > 0) ? FF : a.F;
+  const int C = (a.d + VEC - 1) / VEC;
 
-  if (tid < a.G) {
-    sh_cs[tid] = have_y ? (float)(a.group_n[tid] / a.W[tid]) : 0.f;
+  if (MODE == MODE_TRAIN && tid < a.G) {
+    sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = fabsf(alpha);
-  const float w0 = m0 + fabsf(s0) * eps_global_of(a);
+  float e0 = 0.f;
+  if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
+  if constexpr (EPS == EPS_PHILOX) {
+    float n[4], nb;
+    normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+    e0 = n[0];
+  }
+  const float w0 = fmaf(fabsf(s0), e0, m0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
+  if (MODE == MODE_TRAIN) __syncthreads();
 
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids
+  float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids
+  const int64_t ngroups = (int64_t)gridDim.x * GPB;
+  const int64_t g0 = (int64_t)blockIdx.x * GPB + tid / LPE;
 
-  const int64_t ntiles = (a.B + a.TR - 1) / a.TR;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();
-    const int64_t row0 = tile * a.TR;
-    const int nrows = (int)((a.B - row0 < a.TR) ? (a.B - row0) : a.TR);
-    const int nocc = nrows * F;
-    // ---- stage the tile: one thread per (row, field) occurrence ----
-    for (int o = tid; o < nocc; o += BLOCK) {
-      const int64_t go = row0 * F + o;
-      int64_t id = a.id64 ? ((const int64_t*)a.x)[go] : (int64_t)((const int32_t*)a.x)[go];
-      if (id < 0 || id >= a.T) { acc[4] += 1.f; id = 0; }
-      const uint32_t e = (uint32_t)id;
-      const float2 th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
-      const float sg = fabsf(th.y);
-      const float w = th.x + sg * eps_bias_of(a, e);
-      float c = 0.f;
-      if (have_y) {
-        c = sh_cs[group_index(sh_hi, a.G, id)] * a.inv_occ[e];
-        acc[1] += c * kl_std_normal(th.x, sg);
+  if constexpr (FF == 2) {
+    // ---- two fields per row, both in registers; double buffer across rows ----
+    float cs0 = 0.f, cs1 = 0.f;
+    int64_t hi0 = 0;
+    if constexpr (MODE == MODE_TRAIN) { cs0 = sh_cs[0]; cs1 = sh_cs[1]; hi0 = sh_hi[0]; }
+    FieldRegs<CPL, VEC, EPS> A0, A1, B0, B1;
+    float yA = 0.f, yB = 0.f;
+    int64_t r = g0;
+    uint32_t n0 = 0, n1 = 0;            // ids of the row after the loaded one
+    if (r < a.B) {
+      const uint32_t e0i = load_id(a, r * 2, tot[4]), e1i = load_id(a, r * 2 + 1, tot[4]);
+      load_field<LPE, CPL, VEC, EPS, MODE>(a, e0i, lig, C, A0);
+      load_field<LPE, CPL, VEC, EPS, MODE>(a, e1i, lig, C, A1);
+      if constexpr (MODE == MODE_TRAIN) yA = a.y[r];
+      if (r + ngroups < a.B) {
+        n0 = load_id(a, (r + ngroups) * 2, tot[4]);
+        n1 = load_id(a, (r + ngroups) * 2 + 1, tot[4]);
       }
-      sh_id[o] = e;
-      sh_c[o] = c;
-      sh_w[o] = w;
     }
-    __syncthreads();
-    // ---- one lane group per row ----
-    for (int rr = gi; rr < nrows; rr += GPB) {
-      const int64_t r = row0 + rr;
-      Chunk<VEC> sz[CPL];
-#pragma unroll
-      for (int i = 0; i < CPL; ++i)
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) sz[i].v[t] = 0.f;
-      float zz = 0.f, bsum = 0.f, klacc = 0.f;
-      for (int f = 0; f < F; ++f) {
-        const uint32_t e = sh_id[rr * F + f];
-        const float c = sh_c[rr * F + f];
-        bsum += sh_w[rr * F + f];
-        const float* row = a.entity + (size_t)e * (2 * (size_t)d);
-        float klv = 0.f;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int j = lig + i * LPE;
-          if (j < C) {
-            const Chunk<VEC> mu = ld_chunk<VEC>(row + (size_t)j * VEC);
-            const Chunk<VEC> s = ld_chunk<VEC>(row + d + (size_t)j * VEC);
-            const Chunk<VEC> ep = eps_chunk<VEC>(a, e, j);
-#pragma unroll
-            for (int t = 0; t < VEC; ++t) {
-              const float sg = fabsf(s.v[t]);
-              const float z = fmaf(sg, ep.v[t], mu.v[t]);
-              sz[i].v[t] += z;
-              zz = fmaf(z, z, zz);
-              if (have_y) klv += kl_std_normal(mu.v[t], sg);
-            }
-          }
-        }
-        klacc = fmaf(c, klv, klacc);
-      }
-      float q = -zz;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i)
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) q = fmaf(sz[i].v[t], sz[i].v[t], q);
-      q = 0.5f * group_sum<LPE>(q);
-      acc[1] += klacc;
-      const float pred = w0 + bsum + q;
-      float g = 0.f;
-      if (lig == 0) {
-        out.pred[r] = pred;
-        if (have_y) {
-          const float y = a.y[r];
-          float ll, dll;
-          if (a.lik == VFM_LIK_NORMAL) {
-            const float diff = y - pred;
-            ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
-            dll = aabs * diff;
-            acc[3] += 0.5f * diff * diff - 0.5f / aabs;
-          } else {
-            const float ax = fabsf(pred);
-            const float e1 = __expf(-ax);
-            ll = y * pred - (fmaxf(pred, 0.f) + log1pf(e1));
-            const float sig = (pred >= 0.f) ? 1.f / (1.f + e1) : e1 / (1.f + e1);
-            dll = y - sig;
-          }
-          g = -a.ll_scale * dll;
-          acc[0] += ll;
-          acc[2] += g;
-          if (train) out.grow[r] = g;
+    RowAcc<CPL, VEC> acc;
+    while (r < a.B) {
+      // --- stage: issue the loads of row r + ngroups into B, ids of r + 2*ngroups
+      const int64_t rn = r + ngroups;
+      if (rn < a.B) {
+        load_field<LPE, CPL, VEC, EPS, MODE>(a, n0, lig, C, B0);
+        load_field<LPE, CPL, VEC, EPS, MODE>(a, n1, lig, C, B1);
+        if constexpr (MODE == MODE_TRAIN) yB = a.y[rn];
+        if (rn + ngroups < a.B) {
+          n0 = load_id(a, (rn + ngroups) * 2, tot[4]);
+          n1 = load_id(a, (rn + ngroups) * 2 + 1, tot[4]);
         }
       }
-      if (train) {
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int j = lig + i * LPE;
-          if (j < C) st_chunk<VEC>(out.sumz + (size_t)r * d + (size_t)j * VEC, sz[i]);
+      // --- arithmetic of row r from A
+      acc.reset();
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A0, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1, acc);
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A1, lig, C, ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
+      finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yA, acc, tot);
+      r = rn;
+      if (r >= a.B) break;
+      // --- same with the roles of A and B swapped (static register naming, no copies)
+      const int64_t rm = r + ngroups;
+      if (rm < a.B) {
+        load_field<LPE, CPL, VEC, EPS, MODE>(a, n0, lig, C, A0);
+        load_field<LPE, CPL, VEC, EPS, MODE>(a, n1, lig, C, A1);
+        if constexpr (MODE == MODE_TRAIN) yA = a.y[rm];
+        if (rm + ngroups < a.B) {
+          n0 = load_id(a, (rm + ngroups) * 2, tot[4]);
+          n1 = load_id(a, (rm + ngroups) * 2 + 1, tot[4]);
         }
       }
+      acc.reset();
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, B0, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1, acc);
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, B1, lig, C, ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
+      finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yB, acc, tot);
+      r = rm;
+    }
+  } else {
+    // ---- runtime number of fields: stream the occurrences (r, f), double buffer across them ----
+    FieldRegs<CPL, VEC, EPS> A, Bq;
+    RowAcc<CPL, VEC> acc;
+    int64_t r = g0;
+    int f = 0;
+    if (r < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, r * F, tot[4]), lig, C, A);
+    acc.reset();
+    auto cs_of = [&](uint32_t e, int fcol) -> float {
+      if constexpr (MODE != MODE_TRAIN) return 0.f;
+      const int64_t id = (int64_t)e;
+      const int64_t lo = fcol > 0 ? sh_hi[fcol - 1] : 0;
+      if (id >= lo && id < sh_hi[fcol]) return sh_cs[fcol];   // the usual case: column f <-> group f
+      return sh_cs[group_index(sh_hi, a.G, id)];
+    };
+    while (r < a.B) {
+      // next occurrence
+      int fn = f + 1;
+      int64_t rn = r;
+      if (fn == F) { fn = 0; rn = r + ngroups; }
+      if (rn < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, rn * F + fn, tot[4]), lig, C, Bq);
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A, lig, C, cs_of(A.e, f), acc);
+      if (f == F - 1) {
+        float y = 0.f;
+        if constexpr (MODE == MODE_TRAIN) y = a.y[r];
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+        acc.reset();
+      }
+      r = rn; f = fn;
+      if (r >= a.B) break;
+      fn = f + 1; rn = r;
+      if (fn == F) { fn = 0; rn = r + ngroups; }
+      if (rn < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, rn * F + fn, tot[4]), lig, C, A);
+      consume_field<LPE, CPL, VEC, EPS, MODE>(a, Bq, lig, C, cs_of(Bq.e, f), acc);
+      if (f == F - 1) {
+        float y = 0.f;
+        if constexpr (MODE == MODE_TRAIN) y = a.y[r];
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+        acc.reset();
+      }
+      r = rn; f = fn;
     }
   }
-  block_sum<5>(acc, sh_red);
+  block_sum<5>(tot, sh_red);
   if (tid == 0) {
-    if (acc[0] != 0.f) atomicAdd(&out.partials[VFM_P_LL], (double)acc[0]);
-    if (acc[1] != 0.f) atomicAdd(&out.partials[VFM_P_KL], (double)acc[1]);
-    if (acc[2] != 0.f) atomicAdd(&out.partials[VFM_P_G], (double)acc[2]);
-    if (acc[3] != 0.f) atomicAdd(&out.partials[VFM_P_ALPHA], (double)acc[3]);
-    if (acc[4] != 0.f) atomicAdd(&out.partials[VFM_P_BADID], (double)acc[4]);
+    if (tot[0] != 0.f) atomicAdd(&out.partials[VFM_P_LL], (double)tot[0]);
+    if (tot[1] != 0.f) atomicAdd(&out.partials[VFM_P_KL], (double)tot[1]);
+    if (tot[2] != 0.f) atomicAdd(&out.partials[VFM_P_G], (double)tot[2]);
+    if (tot[3] != 0.f) atomicAdd(&out.partials[VFM_P_ALPHA], (double)tot[3]);
+    if (tot[4] != 0.f) atomicAdd(&out.partials[VFM_P_BADID], (double)tot[4]);
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// backward (entity-centric, dense gradient rows, no atomics)
+// backward (entity-centric, dense gradient rows, no atomics) -- optionally with the dense Adam
+// update fused in (ADAM = 1): the gradient row never leaves registers.
+//
+// A lane group owns one TABLE row e: it sums grow[r] * sumz[r,:] over the batch rows that contain
+// e (inverted index occ_ptr / occ_rows), adds the KL part, and either stores the dense gradient
+// row (zeros when e is not in the batch: the reference's nn.Embedding gradients are dense) or
+// applies torch.optim.Adam's update to (p, m, v) of that row in place.  Only e's own parameters
+// are read, so the in-place update is race free.  All loads that do not depend on the index
+// chain (own row, Adam moments, next entity's offsets) are issued before walking it.
 // ---------------------------------------------------------------------------------------
-template <int LPE, int CPL, int VEC>
-__global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b) {
+struct AdamArgs {
+  float* m_entity; float* v_entity; float* m_bias; float* v_bias; float* m_scal; float* v_scal;
+  float b1, b2, eps, step_size, bc2_sqrt;
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamArgs& ad) {
+  m = m + (g - m) * (1.0f - ad.b1);
+  v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
+  const float denom = __fsqrt_rn(v) / ad.bc2_sqrt + ad.eps;
+  return p + (-ad.step_size * m) / denom;
+}
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM>
+__global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
-  const int gi = tid / LPE;
   const int d = a.d;
   const int C = (d + VEC - 1) / VEC;
   if (tid < a.G) {
@@ -435,25 +589,123 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b) {
     sh_hi[tid] = a.group_hi[tid];
   }
   __syncthreads();
-  const float gout = b.grad_out[0];
+  const float gout = ADAM ? 1.0f : b.grad_out[0];
 
   if (blockIdx.x == 0 && tid == 0) {
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
     const float sum_g = (float)b.partials[VFM_P_G];
-    const float e0 = eps_global_of(a);
+    float e0 = 0.f;
+    if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
+    if constexpr (EPS == EPS_PHILOX) {
+      float n[4], nb;
+      normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      e0 = n[0];
+    }
     const float as0 = fabsf(s0);
-    b.g_scalars[0] = (a.lik == VFM_LIK_NORMAL)
-                         ? gout * signf(alpha) * a.ll_scale * (float)b.partials[VFM_P_ALPHA]
-                         : 0.f;
     const float prior = (a.flags & VFM_FLAG_NO_PRIOR_TERMS) ? 0.f : 1.f;
-    b.g_scalars[1] = gout * (sum_g + prior * m0);
-    b.g_scalars[2] = gout * signf(s0) * (e0 * sum_g + prior * (as0 - 1.0f / as0));
+    const float ga = (a.lik == VFM_LIK_NORMAL)
+                         ? gout * signf(alpha) * a.ll_scale * (float)b.partials[VFM_P_ALPHA] : 0.f;
+    const float gm = gout * (sum_g + prior * m0);
+    const float gs = gout * signf(s0) * (e0 * sum_g + prior * (as0 - inv_sigma(as0)));
+    if constexpr (ADAM) {
+      float* sc = const_cast<float*>(a.scalars);
+      const float gg[3] = {ga, gm, gs};
+      for (int i = 0; i < 3; ++i) {
+        float m = ad.m_scal[i], v = ad.v_scal[i];
+        // alpha has no gradient under the Bernoulli likelihood (reference: grad None, Adam skips it)
+        if (i == 0 && a.lik != VFM_LIK_NORMAL) continue;
+        sc[i] = adam_update(sc[i], gg[i], m, v, ad);
+        ad.m_scal[i] = m; ad.v_scal[i] = v;
+      }
+    } else {
+      b.g_scalars[0] = ga; b.g_scalars[1] = gm; b.g_scalars[2] = gs;
+    }
   }
 
-  for (int64_t e = (int64_t)blockIdx.x * GPB + gi; e < a.T; e += (int64_t)gridDim.x * GPB) {
-    const int beg = b.occ_ptr[e], end = b.occ_ptr[e + 1];
-    float* grow_e = b.g_entity + (size_t)e * (2 * (size_t)d);
-    if (beg == end) {  // entity not in the batch: dense zero row (vfm-torch.py:152-153 dense grads)
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  int64_t e = (int64_t)blockIdx.x * GPB + tid / LPE;
+  int2 pq = make_int2(0, 0);
+  if (e < a.T) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
+  for (; e < a.T; e += stride) {
+    const int beg = pq.x, end = pq.y;
+    const int64_t en = e + stride;
+    if (en < a.T) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+    float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
+    float* grow_e = ADAM ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
+    const bool touched = beg != end;
+
+    // loads that do not depend on the index chain
+    Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
+    float2 th = make_float2(0.f, 1.f), mb = make_float2(0.f, 0.f), vb = make_float2(0.f, 0.f);
+    float io = 0.f, epw = 0.f;
+    if (ADAM || touched) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          mu[i] = ld_chunk<VEC>(prow + (size_t)j * VEC);
+          s[i] = ld_chunk<VEC>(prow + d + (size_t)j * VEC);
+          if constexpr (ADAM) {
+            const size_t o = (size_t)e * (2 * (size_t)d) + (size_t)j * VEC;
+            mm[i] = ld_chunk<VEC>(ad.m_entity + o); ms[i] = ld_chunk<VEC>(ad.m_entity + o + d);
+            vm[i] = ld_chunk<VEC>(ad.v_entity + o); vs[i] = ld_chunk<VEC>(ad.v_entity + o + d);
+          }
+          if constexpr (EPS == EPS_TABLE)
+            if (touched) ep[i] = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
+        }
+      }
+      if (lig == 0) {
+        th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
+        if constexpr (ADAM) {
+          mb = *reinterpret_cast<const float2*>(ad.m_bias + 2 * (size_t)e);
+          vb = *reinterpret_cast<const float2*>(ad.v_bias + 2 * (size_t)e);
+        }
+      }
+      if (touched) {
+        io = a.inv_occ[e];
+        if constexpr (EPS == EPS_TABLE) epw = a.eps_bias[e];
+      }
+    }
+
+    // walk the inverted index: A = sum_r g_r * sumz_r, gs = sum_r g_r
+    Chunk<VEC> A[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
+    float gs = 0.f;
+    int o = beg;
+    for (; o + 1 < end; o += 2) {       // two occurrences in flight
+      const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
+      const float g0 = b.grow[r0], g1 = b.grow[r1];
+      gs += g0 + g1;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
+          const Chunk<VEC> s1v = ld_chunk<VEC>(b.sumz + (size_t)r1 * d + (size_t)j * VEC);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g1, s1v.v[t], fmaf(g0, s0v.v[t], A[i].v[t]));
+        }
+      }
+    }
+    if (o < end) {
+      const int r0 = b.occ_rows[o];
+      const float g0 = b.grow[r0];
+      gs += g0;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g0, s0v.v[t], A[i].v[t]);
+        }
+      }
+    }
+
+    if (!touched && !ADAM) {   // entity not in the batch: dense zero row
       Chunk<VEC> zc;
 #pragma unroll
       for (int t = 0; t < VEC; ++t) zc.v[t] = 0.f;
@@ -468,55 +720,85 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b) {
       if (lig == 0) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
       continue;
     }
-    Chunk<VEC> A[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
-    float gs = 0.f;
-    for (int o = beg; o < end; ++o) {
-      const int r = b.occ_rows[o];
-      const float g = b.grow[r];
-      gs += g;
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int j = lig + i * LPE;
-        if (j < C) {
-          const Chunk<VEC> sv = ld_chunk<VEC>(b.sumz + (size_t)r * d + (size_t)j * VEC);
-#pragma unroll
-          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g, sv.v[t], A[i].v[t]);
-        }
-      }
+
+    float c = 0.f;
+    if (touched) {
+      const int64_t lo = 0;
+      (void)lo;
+      c = sh_cs[group_index(sh_hi, a.G, e)] * io * (float)(end - beg);
     }
-    const float c = sh_cs[group_index(sh_hi, a.G, e)] * a.inv_occ[e] * (float)(end - beg);
-    const float* row = a.entity + (size_t)e * (2 * (size_t)d);
+    float nb_eps = 0.f;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int j = lig + i * LPE;
       if (j < C) {
-        const Chunk<VEC> mu = ld_chunk<VEC>(row + (size_t)j * VEC);
-        const Chunk<VEC> s = ld_chunk<VEC>(row + d + (size_t)j * VEC);
-        const Chunk<VEC> ep = eps_chunk<VEC>(a, (uint32_t)e, j);
         Chunk<VEC> gm, gv;
+        if (touched) {
+          Chunk<VEC> epc;
+          if constexpr (EPS == EPS_TABLE) {
+            epc = ep[i];
+          } else if constexpr (EPS == EPS_ZERO) {
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-          const float sg = fabsf(s.v[t]);
-          const float z = fmaf(sg, ep.v[t], mu.v[t]);
-          const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
-          gm.v[t] = gout * (gz + c * mu.v[t]);
-          gv.v[t] = gout * signf(s.v[t]) * (gz * ep.v[t] + c * (sg - 1.0f / sg));
+            for (int t = 0; t < VEC; ++t) epc.v[t] = 0.f;
+          } else {
+            float n[4], nb;
+            normal4b(a.key, (uint32_t)e, (uint32_t)(VEC == 4 ? j : (j >> 2)), n, nb);
+            if constexpr (VEC == 4) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) epc.v[t] = n[t];
+            } else {
+              epc.v[0] = n[j & 3];
+            }
+            if (i == 0) nb_eps = nb;
+          }
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            const float sg = fabsf(s[i].v[t]);
+            const float z = fmaf(sg, epc.v[t], mu[i].v[t]);
+            const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
+            gm.v[t] = gout * (gz + c * mu[i].v[t]);
+            gv.v[t] = gout * signf(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) { gm.v[t] = 0.f; gv.v[t] = 0.f; }
         }
-        st_chunk<VEC>(grow_e + (size_t)j * VEC, gm);
-        st_chunk<VEC>(grow_e + d + (size_t)j * VEC, gv);
+        if constexpr (ADAM) {
+          Chunk<VEC> pm, ps;
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            pm.v[t] = adam_update(mu[i].v[t], gm.v[t], mm[i].v[t], vm[i].v[t], ad);
+            ps.v[t] = adam_update(s[i].v[t], gv.v[t], ms[i].v[t], vs[i].v[t], ad);
+          }
+          const size_t o2 = (size_t)e * (2 * (size_t)d) + (size_t)j * VEC;
+          st_chunk<VEC>(prow + (size_t)j * VEC, pm);
+          st_chunk<VEC>(prow + d + (size_t)j * VEC, ps);
+          st_chunk<VEC>(ad.m_entity + o2, mm[i]); st_chunk<VEC>(ad.m_entity + o2 + d, ms[i]);
+          st_chunk<VEC>(ad.v_entity + o2, vm[i]); st_chunk<VEC>(ad.v_entity + o2 + d, vs[i]);
+        } else {
+          st_chunk<VEC>(grow_e + (size_t)j * VEC, gm);
+          st_chunk<VEC>(grow_e + d + (size_t)j * VEC, gv);
+        }
       }
     }
     if (lig == 0) {
-      const float2 th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
-      const float sg = fabsf(th.y);
-      const float ew = eps_bias_of(a, (uint32_t)e);
-      *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) =
-          make_float2(gout * (gs + c * th.x),
-                      gout * signf(th.y) * (gs * ew + c * (sg - 1.0f / sg)));
+      float g0 = 0.f, g1 = 0.f;
+      if (touched) {
+        if constexpr (EPS == EPS_TABLE) nb_eps = epw;
+        const float sg = fabsf(th.y);
+        g0 = gout * (gs + c * th.x);
+        g1 = gout * signf(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
+      }
+      if constexpr (ADAM) {
+        float2 pn;
+        pn.x = adam_update(th.x, g0, mb.x, vb.x, ad);
+        pn.y = adam_update(th.y, g1, mb.y, vb.y, ad);
+        *reinterpret_cast<float2*>(const_cast<float*>(a.bias) + 2 * (size_t)e) = pn;
+        *reinterpret_cast<float2*>(ad.m_bias + 2 * (size_t)e) = mb;
+        *reinterpret_cast<float2*>(ad.v_bias + 2 * (size_t)e) = vb;
+      } else {
+        *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(g0, g1);
+      }
     }
   }
 }
@@ -566,18 +848,15 @@ __global__ void k_philox_dump(const KArgs a, float* eps_entity, float* eps_bias,
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = i / n4;
     const int j = (int)(i % n4);
-    float n[4];
-    normal4(a.key, (uint32_t)e, (uint32_t)j, TAG_ENTITY, n);
+    float n[4], nb;
+    normal4b(a.key, (uint32_t)e, (uint32_t)j, n, nb);
     for (int t = 0; t < 4; ++t)
       if (j * 4 + t < a.d) eps_entity[e * a.d + j * 4 + t] = n[t];
-    if (j == 0) {
-      normal4(a.key, (uint32_t)e, 0u, TAG_BIAS, n);
-      eps_bias[e] = n[0];
-    }
+    if (j == 0) eps_bias[e] = nb;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float n[4];
-    normal4(a.key, 0xFFFFFFFFu, 0u, TAG_GLOBAL, n);
+    float n[4], nb;
+    normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
     eps_global[0] = n[0];
   }
 }
@@ -622,6 +901,14 @@ int check_problem(const vfm_problem_t* p) {
   return 0;
 }
 
+// eps source of a call: VFM_FLAG_EPS_ZERO > tables > Philox
+int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const float* eg, int* mode) {
+  const int neps = (ee != nullptr) + (eb != nullptr) + (eg != nullptr);
+  if (neps != 0 && neps != 3) return fail(VFM_E_INVALID, "give all three eps tables or none");
+  *mode = (p->flags & VFM_FLAG_EPS_ZERO) ? EPS_ZERO : (neps == 3 ? EPS_TABLE : EPS_PHILOX);
+  return 0;
+}
+
 KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const float* entity,
                 const float* bias, const float* inv_occ, const float* scalars, const double* W,
                 const float* ee, const float* eb, const float* eg) {
@@ -631,58 +918,100 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
   a.ll_scale = (float)((double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1));
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
-  a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32) & 0x3FFFFFFFu;
+  a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32);
   a.x = x; a.y = y; a.entity = entity; a.bias = bias; a.inv_occ = inv_occ; a.scalars = scalars;
   a.W = W; a.eps_entity = ee; a.eps_bias = eb; a.eps_global = eg;
   for (int g = 0; g < p->F; ++g) { a.group_hi[g] = p->group_hi[g]; a.group_n[g] = p->group_n[g]; }
   return a;
 }
 
-template <template <int, int, int> class L, typename... Args>
-int dispatch(const Shape& s, Args&&... args) {
-#define CASE(L_, C_, V_) \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return L<L_, C_, V_>::run(args...);
-  CASE(1, 1, 4) CASE(2, 1, 4) CASE(4, 1, 4) CASE(8, 1, 4) CASE(16, 1, 4) CASE(32, 1, 4)
-  CASE(64, 1, 4) CASE(64, 2, 4) CASE(64, 4, 4)
-  CASE(8, 1, 1) CASE(64, 1, 1) CASE(64, 4, 1)
-#undef CASE
-  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// ---- forward dispatch: shape x eps source x mode x (F == 2 ?) ----
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF>
+int launch_fwd_t(KArgs& a, const FwdOut& o, hipStream_t st) {
+  constexpr int GPB = BLOCK / LPE;
+  // persistent-ish grid: enough groups that each owns a few rows (pipelined), capped at
+  // VFM_FWD_BLOCKS_PER_CU resident workgroups on each of the 256 CUs
+  const int per_cu = env_int("VFM_FWD_BLOCKS_PER_CU", 6);
+  int64_t nb = (a.B + GPB - 1) / GPB;
+  const int64_t cap = 256LL * per_cu;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((k_fwd<LPE, CPL, VEC, EPS, MODE, FF>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
+  return 0;
 }
 
 template <int LPE, int CPL, int VEC>
-struct LaunchFwd {
-  static int run(KArgs& a, const FwdOut& o, hipStream_t st) {
-    constexpr int GPB = BLOCK / LPE;
-    // tile rows: fill the LDS tile, but keep >= ~2048 tiles so every CU of the 8 XCDs gets work
-    int64_t tr = OCC_CAP / a.F;
-    const int64_t want = (a.B + 2047) / 2048;
-    if (tr > want) tr = want;
-    if (tr < GPB) tr = GPB;
-    if (tr * a.F > OCC_CAP) tr = OCC_CAP / a.F;
-    if (tr < 1) tr = 1;
-    a.TR = (int)tr;
-    const int64_t ntiles = (a.B + tr - 1) / tr;
-    const int grid = (int)(ntiles < 2048 ? (ntiles > 0 ? ntiles : 1) : 2048);
-    hipLaunchKernelGGL((k_fwd<LPE, CPL, VEC>), dim3(grid), dim3(BLOCK), 0, st, a, o);
-    return 0;
+int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream_t st) {
+#define FWD(E_, M_)                                                              \
+  if (eps == E_ && mode == M_) {                                                 \
+    if constexpr (VEC == 4) {                                                    \
+      if (ff == 2) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2>(a, o, st);      \
+    }                                                                            \
+    return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0>(a, o, st);                     \
   }
-};
+  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN)
+  FWD(EPS_PHILOX, MODE_PREDICT) FWD(EPS_TABLE, MODE_PREDICT) FWD(EPS_ZERO, MODE_PREDICT)
+#undef FWD
+  return fail(VFM_E_UNSUPPORTED, "forward: unsupported eps source / mode combination");
+}
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM>
+int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  constexpr int GPB = BLOCK / LPE;
+  const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
+  int64_t nb = (a.T + GPB - 1) / GPB;
+  const int64_t cap = 256LL * per_cu;
+  if (nb > cap) nb = cap;
+  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+  return 0;
+}
 
 template <int LPE, int CPL, int VEC>
-struct LaunchBwd {
-  static int run(KArgs& a, const BwdArgs& b, hipStream_t st) {
-    constexpr int GPB = BLOCK / LPE;
-    const int64_t nb = (a.T + GPB - 1) / GPB;
-    const int grid = (int)(nb < 4096 ? nb : 4096);
-    hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC>), dim3(grid), dim3(BLOCK), 0, st, a, b);
-    return 0;
-  }
-};
+int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  if (eps == EPS_PHILOX && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 0>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 0>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
+  return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
+}
+
+#define FOR_SHAPES(X)                                                                          \
+  X(1, 1, 4) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(32, 1, 4) X(64, 1, 4) X(64, 2, 4) \
+  X(64, 4, 4) X(8, 1, 1) X(64, 1, 1) X(64, 4, 1)
+
+int dispatch_fwd(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream_t st) {
+#define X(L_, C_, V_) \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return launch_fwd_s<L_, C_, V_>(eps, mode, ff, a, o, st);
+  FOR_SHAPES(X)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+}
+
+int dispatch_bwd(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad,
+                 hipStream_t st) {
+#define X(L_, C_, V_) \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return launch_bwd_s<L_, C_, V_>(eps, adam, a, b, ad, st);
+  FOR_SHAPES(X)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+}
 
 int after_launch(const char* where) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, where);
   return 0;
+}
+
+void adam_consts(float lr, float beta1, float beta2, int64_t step, float* step_size, float* bc2_sqrt) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  *step_size = (float)((double)lr / bc1);
+  *bc2_sqrt = (float)sqrt(bc2);
 }
 
 }  // namespace
@@ -704,8 +1033,7 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
   if (int rc = check_problem(p)) return rc;
   if (!x || !inv_occ || !W) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(W, 0, sizeof(double) * p->F, st);
-  if (e != hipSuccess) return fail_hip(e, "vfm_batch_norms memset");
+  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);
   const int64_t n_occ = p->B * p->F;
   if (n_occ == 0) return 0;
   const int64_t nb = (n_occ + BLOCK - 1) / BLOCK;
@@ -723,21 +1051,22 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (int rc = check_problem(p)) return rc;
   if (!x || !entity_params || !bias_params || !scalars || !pred || !partials)
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: NULL pointer");
-  if (y && (!inv_occ || !W)) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: y given but inv_occ / W NULL");
-  if ((sumz == nullptr) != (grow == nullptr) || (sumz && !y))
-    return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: sumz and grow go together and need y");
-  const int neps = (eps_entity != nullptr) + (eps_bias != nullptr) + (eps_global != nullptr);
-  if (neps != 0 && neps != 3) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: give all three eps tables or none");
+  const bool train = y != nullptr;
+  if (train && (!inv_occ || !W || !sumz || !grow))
+    return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: y given, so inv_occ, W, sumz and grow are required");
+  if (!train && (sumz || grow)) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: sumz / grow need y");
+  int eps;
+  if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
+  if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(partials, 0, sizeof(double) * VFM_N_PARTIALS, st);
-  if (e != hipSuccess) return fail_hip(e, "vfm_elbo_fwd_f32 memset");
+  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, partials, (int)VFM_N_PARTIALS);
   if (p->B == 0) return 0;
   KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
   FwdOut o{pred, partials, sumz, grow};
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch<LaunchFwd>(s, a, o, st)) return rc;
+  if (int rc = dispatch_fwd(s, eps, train ? MODE_TRAIN : MODE_PREDICT, p->F == 2 ? 2 : 0, a, o, st)) return rc;
   return after_launch("vfm_elbo_fwd_f32");
 }
 
@@ -762,15 +1091,47 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
   if (!occ_ptr || !occ_rows || !entity_params || !bias_params || !inv_occ || !scalars || !W ||
       !sumz || !grow || !partials || !grad_out || !g_entity || !g_bias || !g_scalars)
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_f32: NULL pointer");
-  const int neps = (eps_entity != nullptr) + (eps_bias != nullptr) + (eps_global != nullptr);
-  if (neps != 0 && neps != 3) return fail(VFM_E_INVALID, "vfm_elbo_bwd_f32: give all three eps tables or none");
+  int eps;
+  if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
+  if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, grad_out, g_entity, g_bias, g_scalars};
+  AdamArgs ad;
+  memset(&ad, 0, sizeof(ad));
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch<LaunchBwd>(s, a, b, (hipStream_t)stream)) return rc;
+  if (int rc = dispatch_bwd(s, eps, 0, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_f32");
+}
+
+int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+                          float* entity_params, float* bias_params, float* scalars,
+                          const float* inv_occ, const double* W,
+                          const float* eps_entity, const float* eps_bias, const float* eps_global,
+                          const float* sumz, const float* grow, const double* partials,
+                          float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                          float* m_scalars, float* v_scalars,
+                          float lr, float beta1, float beta2, float eps_adam, int64_t step, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (!occ_ptr || !occ_rows || !entity_params || !bias_params || !inv_occ || !scalars || !W ||
+      !sumz || !grow || !partials || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
+      !v_scalars || step < 1)
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: bad argument");
+  if (p->flags & VFM_FLAG_NO_PRIOR_TERMS)
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: single-rank only (gradients never leave the kernel)");
+  int eps;
+  if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
+  if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
+                      eps_bias, eps_global);
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr};
+  AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
+  adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = dispatch_bwd(s, eps, 1, a, b, ad, (hipStream_t)stream)) return rc;
+  return after_launch("vfm_elbo_bwd_adam_f32");
 }
 
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
@@ -779,10 +1140,8 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
   if (n == 0) return 0;
   if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0)
     return fail(VFM_E_INVALID, "vfm_adam_f32: pointers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
+  float step_size, bc2_sqrt;
+  adam_consts(lr, beta1, beta2, step, &step_size, &bc2_sqrt);
   const int64_t n4 = n / 4;
   int64_t nb = (n4 + BLOCK - 1) / BLOCK;
   if (nb < 1) nb = 1;

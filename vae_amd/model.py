@@ -81,6 +81,7 @@ class VFM(nn.Module):
         self.group_n = tuple(float(s) for s in self.field_sizes)
         self.rng_seed = int(rng_seed)
         self.global_step = 0
+        self.fuse_adam = True      # single-rank train_step uses the fused backward+Adam kernel
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
         alpha = torch.rand(1)                                   # nn.init.uniform_ (:145)
@@ -256,9 +257,24 @@ class VFM(nn.Module):
             self._gflat = torch.zeros(self._n_flat + 4, dtype=torch.float32, device=self.device)
             self._adam_t = 0
             self._gout = torch.ones(1, dtype=torch.float32, device=self.device)
+            self._partials = torch.zeros(_lib.N_PARTIALS, dtype=torch.float64, device=self.device)
+            self._state_bufs = {}
+
+    def _step_buffers(self, B):
+        """Persistent per-step training state (sumz [B,d], grow [B], pred [B]) -- no allocator
+        traffic inside the step."""
+        b = self._state_bufs.get(B)
+        if b is None:
+            b = (torch.empty(B, self.d, dtype=torch.float32, device=self.device),
+                 torch.empty(B, dtype=torch.float32, device=self.device),
+                 torch.empty(B, dtype=torch.float32, device=self.device))
+            if len(self._state_bufs) > 4:
+                self._state_bufs.clear()
+            self._state_bufs[B] = b
+        return b
 
     def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
-                   process_group=None, adam: bool = True, mark=None):
+                   process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None):
         """One iteration of vfm-torch.py:351-370 without autograd: forward, loss, backward, dense
         Adam (betas (0.9, 0.999), eps 1e-8).  Everything is enqueued on the current stream; nothing
         synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B])."""
@@ -275,11 +291,22 @@ class VFM(nn.Module):
         self.global_step += 1
         mark = mark or (lambda name: None)      # bench.py records HIP events at these points
         mark("start")
+        sumz, grow, pred = self._step_buffers(plan.B)
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
-                              train=True, flags=flags, out_pred=out_pred)
+                              train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
+                              out_sumz=sumz, out_grow=grow, out_partials=self._partials)
         mark("fwd")
         ops.elbo_finalize(st, scal, out=loss3)
         mark("finalize")
+        if fused is None:
+            fused = self.fuse_adam
+        if fused and adam and process_group is None:
+            # backward + dense Adam in ONE kernel: the gradient rows never reach HBM
+            self._adam_t += 1
+            ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                   self._views(self._adam_v), lr, self._adam_t)
+            mark("bwd_adam")
+            return loss3, st.pred
         ops.elbo_backward(plan, st, ent, bia, scal, self.inv_occ, self._gout, g_ent, g_bias, g_scal)
         mark("bwd")
         if process_group is not None:

@@ -195,6 +195,22 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
     return g_entity, g_bias, g_scalars
 
 
+def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
+                       m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8):
+    """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
+    m_views / v_views = (entity, bias, scalars) moment tensors."""
+    if plan.occ_ptr is None:
+        plan.build_index()
+    e = st.eps if st.eps is not None else (None, None, None)
+    lib = _lib.load()
+    check(lib.vfm_elbo_bwd_adam_f32(
+        C.byref(st.problem), ptr(plan.occ_ptr), ptr(plan.occ_rows), ptr(entity_params), ptr(bias_params),
+        ptr(scalars), ptr(inv_occ), ptr(plan.W), ptr(e[0]), ptr(e[1]), ptr(e[2]), ptr(st.sumz),
+        ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
+        ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step),
+        current_stream_ptr(plan.x.device)), "vfm_elbo_bwd_adam_f32")
+
+
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     """In-place dense Adam (torch.optim.Adam defaults, vfm-torch.py:339,370) on one flat tensor."""
     for t in (p, g, m, v):
