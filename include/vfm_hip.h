@@ -57,6 +57,11 @@ extern "C" {
 #define VFM_P_ALPHA 3   /* sum_r [(y-pred)^2/2 - 1/(2|alpha|)]                          */
 #define VFM_P_BADID 4   /* number of ids outside [0,T) met (they are clamped to 0)      */
 #define VFM_N_PARTIALS 8
+/* `partials` is a caller-owned fp64 workspace of VFM_PARTIALS_LEN entries: [0..7] the sums
+ * above (valid after vfm_elbo_finalize_f32; [7] = number of forward blocks), followed by one
+ * 8-entry slot per forward workgroup (written with plain stores: deterministic sums, no atomics) */
+#define VFM_MAX_FWD_BLOCKS 4096
+#define VFM_PARTIALS_LEN (VFM_N_PARTIALS * (1 + VFM_MAX_FWD_BLOCKS))
 
 /* Problem description shared by all kernels of one step (host memory). */
 typedef struct vfm_problem {
@@ -106,7 +111,8 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
  *       W [F] batch-global normalisers, eps_* tables indexed BY ENTITY ID
  *       (eps_entity [T,d], eps_bias [T], eps_global [1]) or all three NULL => Philox.
  *  out: pred [B]      unscaled prediction (logit for Bernoulli)
- *       partials [VFM_N_PARTIALS] fp64, zeroed by the call (see VFM_P_*)
+ *       partials [VFM_PARTIALS_LEN] fp64 workspace: per-workgroup partial sums; call
+ *       vfm_elbo_finalize_f32 to reduce them into partials[0..7] (see VFM_P_*)
  *       sumz [B,d] and grow [B]: training state for the backward call:
  *       sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.
  *  eps: Philox mode draws, per entity and step, d embedding normals + 1 first-order-weight
@@ -117,10 +123,13 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      const float* eps_entity, const float* eps_bias, const float* eps_global,
                      float* pred, double* partials, float* sumz, float* grow, void* stream);
 
-/* loss[0] = -(nb_train/B_global) * partials[LL] + KL(q(w0)||N(0,1)) + partials[KL]
+/* Reduces the per-workgroup slots of `partials` into partials[0..7] and forms
+ * loss[0] = -(nb_train/B_global) * partials[LL] + KL(q(w0)||N(0,1)) + partials[KL]
  * (vfm-torch.py:322,359), loss[1] = the likelihood term, loss[2] = the KL term.  NaN when
- * partials[BADID] != 0.  With several ranks, sum `partials` over ranks first. */
-int vfm_elbo_finalize_f32(const vfm_problem_t* p, const double* partials, const float* scalars,
+ * partials[BADID] != 0.  MUST run after vfm_elbo_fwd_f32 and before either backward call (they
+ * read partials[G], partials[ALPHA]).  With several ranks every rank finalises its own shard
+ * (VFM_FLAG_NO_PRIOR_TERMS on all ranks but one) and loss / scalar gradients are summed. */
+int vfm_elbo_finalize_f32(const vfm_problem_t* p, double* partials, const float* scalars,
                           float* loss, void* stream);
 
 /* Backward (replaces autograd through vfm-torch.py:189-324,359; :368-369).  Entity-centric:

@@ -19,6 +19,8 @@ OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
 ABI_VERSION = 1
 MAX_FIELDS = 64
 N_PARTIALS = 8
+MAX_FWD_BLOCKS = 4096
+PARTIALS_LEN = N_PARTIALS * (1 + MAX_FWD_BLOCKS)
 P_LL, P_KL, P_G, P_ALPHA, P_BADID = 0, 1, 2, 3, 4
 LIK_NORMAL, LIK_BERNOULLI = 0, 1
 

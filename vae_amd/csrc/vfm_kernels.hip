@@ -69,28 +69,49 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-  const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0,1)
-  const float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;           // [0,1) revolutions
+// Box-Muller pair from one 24-bit field: 16-bit radius, 8-bit angle (v_sin/v_cos take revolutions).
+__device__ __forceinline__ void bm24(uint32_t f, float& n0, float& n1) {
+  const float u1 = fmaf((float)((f >> 8) & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);  // (k+1/2)/2^16
+  const float u2 = (float)(f & 0xFFu) * 0.00390625f;                                          // k/2^8
   const float r = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(u1));
-  n0 = r * __builtin_amdgcn_cosf(u2);  // v_cos_f32 / v_sin_f32 take revolutions
+  n0 = r * __builtin_amdgcn_cosf(u2);
   n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
-// Philox4x32-10 with counter (j, e, step_lo, step_hi) and key (seed_lo, seed_hi) gives, for
-// entity e at this step: the 4 normals of coordinates 4j..4j+3 (24-bit Box-Muller on the high
-// bits of the 4 words) and -- from the 32 spare low bits of the same 4 words, used for j == 0 only
-// -- one more normal `nb`, the eps of the entity's first-order weight (20-bit radius, 12-bit
-// angle).  The global-bias eps is n[0] of the reserved id e = 0xFFFFFFFF.
-__device__ __forceinline__ void normal4b(const RngKey& k, uint32_t e, uint32_t j, float n[4], float& nb) {
+// One Philox4x32-10 call with counter (p, e, step_lo, step_hi) and key (seed_lo, seed_hi) yields
+// 128 bits = five 24-bit fields -> five Box-Muller pairs:
+//   n[0..7] : eps of embedding coordinates 8p .. 8p+7 of entity e at this step
+//   nb      : (first normal of the fifth pair) eps of the entity's first-order weight, used for p == 0
+// The global-bias eps is n[0] of the reserved id e = 0xFFFFFFFF, p = 0.  Every row -- and every
+// rank -- that touches e regenerates the same draw (one draw per entity per step, as the
+// reference's per-unique-entity rsample, vfm-torch.py:207-208,238-245).
+__device__ __forceinline__ void normal8b(const RngKey& k, uint32_t e, uint32_t p, float n[8], float& nb) {
   uint32_t o[4];
-  philox4x32_10(j, e, k.step_lo, k.step_hi, k.seed_lo, k.seed_hi, o);
-  box_muller(o[0], o[1], n[0], n[1]);
-  box_muller(o[2], o[3], n[2], n[3]);
-  const uint32_t w = (o[0] & 0xFFu) | ((o[1] & 0xFFu) << 8) | ((o[2] & 0xFFu) << 16) | (o[3] << 24);
-  const float u1 = ((float)(w >> 12) + 0.5f) * 9.5367431640625e-7f;   // 2^-20
-  const float u2 = (float)(w & 0xFFFu) * 2.44140625e-4f;              // 2^-12 revolutions
-  nb = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+  philox4x32_10(p, e, k.step_lo, k.step_hi, k.seed_lo, k.seed_hi, o);
+  bm24(o[0], n[0], n[1]);
+  bm24(__builtin_amdgcn_alignbit(o[1], o[0], 24), n[2], n[3]);
+  bm24(__builtin_amdgcn_alignbit(o[2], o[1], 16), n[4], n[5]);
+  bm24(o[2] >> 8, n[6], n[7]);
+  float unused;
+  bm24(o[3], nb, unused);
+}
+
+// eps of chunk j (VEC coordinates from j*VEC) for the lane that owns it, plus the bias eps
+template <int VEC>
+__device__ __forceinline__ void eps_of_chunk(const RngKey& k, uint32_t e, int j, float (&ep)[VEC], float& nb) {
+  float n[8];
+  if constexpr (VEC == 4) {
+    normal8b(k, e, (uint32_t)j >> 1, n, nb);
+    const bool odd = j & 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ep[t] = odd ? n[4 + t] : n[t];
+  } else {
+    normal8b(k, e, (uint32_t)j >> 3, n, nb);
+    float v = n[0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v = ((j & 7) == t) ? n[t] : v;
+    ep[0] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -177,10 +198,29 @@ __device__ __forceinline__ float inv_sigma(float sg) { return 1.0f / fmaxf(sg, S
 
 __device__ __forceinline__ float signf(float s) { return (s < 0.f) ? -1.f : 1.f; }
 
+// all-reduce (sum) over aligned groups of W lanes, on the VALU: DPP row operations inside a
+// 16-lane row, v_permlane16/32_swap (gfx950) across rows -- no LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  if constexpr (W >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if constexpr (W >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if constexpr (W >= 32) {
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+  }
+  if constexpr (W >= 64) {
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+    v = __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+  }
   return v;
 }
 
@@ -242,16 +282,39 @@ __global__ __launch_bounds__(BLOCK) void k_norms(const void* __restrict__ x, int
   if (threadIdx.x < F) atomicAdd(&W[threadIdx.x], (double)sh[threadIdx.x]);
 }
 
-__global__ void k_finalize(const double* __restrict__ partials, const float* __restrict__ scalars,
-                           double ll_scale, int flags, float* __restrict__ loss) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partials,
+                                                    const float* __restrict__ scalars, double ll_scale,
+                                                    int flags, float* __restrict__ loss) {
+  __shared__ double sh[5][BLOCK / 64];
+  const int nblk = (int)partials[7];
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblk; b += BLOCK) {
+    const double* slot = partials + VFM_N_PARTIALS * (1 + (size_t)b);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] += slot[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
+    if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double tot[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    tot[i] = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) tot[i] += sh[i][w];
+    partials[i] = tot[i];
+  }
   const double m0 = scalars[1], s0 = scalars[2];
   const double kl0 = (flags & VFM_FLAG_NO_PRIOR_TERMS)
                          ? 0.0
                          : 0.5 * (s0 * s0 + m0 * m0 - 1.0) - log(fmax(fabs(s0), (double)SIGMA_MIN));
-  const double nll = -ll_scale * partials[VFM_P_LL];
-  const double kl = kl0 + partials[VFM_P_KL];
-  const bool bad = partials[VFM_P_BADID] != 0.0;
+  const double nll = -ll_scale * tot[VFM_P_LL];
+  const double kl = kl0 + tot[VFM_P_KL];
+  const bool bad = tot[VFM_P_BADID] != 0.0;
   const float nanv = __builtin_nanf("");
   loss[0] = bad ? nanv : (float)(nll + kl);
   loss[1] = bad ? nanv : (float)nll;
@@ -290,23 +353,41 @@ __device__ __forceinline__ void load_field(const KArgs& a, uint32_t e, int lig, 
   const float* row = a.entity + (size_t)e * (2 * (size_t)d);
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
-    const int j = lig + i * LPE;
-    if (CPL == 1 && LPE * VEC == 0) {}
-    if (j < C) {
-      R.mu[i] = ld_chunk<VEC>(row + (size_t)j * VEC);
-      R.s[i] = ld_chunk<VEC>(row + d + (size_t)j * VEC);
-      if constexpr (EPS == EPS_TABLE) R.ep[i] = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
-    }
+    // lanes past the last chunk re-load the last chunk (same lines, no branch); consume_field masks them
+    int j = lig + i * LPE;
+    j = j < C ? j : C - 1;
+    R.mu[i] = ld_chunk<VEC>(row + (size_t)j * VEC);
+    R.s[i] = ld_chunk<VEC>(row + d + (size_t)j * VEC);
+    if constexpr (EPS == EPS_TABLE) R.ep[i] = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
   }
   R.th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
   if constexpr (MODE == MODE_TRAIN) R.io = a.inv_occ[e];
   if constexpr (EPS == EPS_TABLE) R.epw = a.eps_bias[e];
 }
 
-__device__ __forceinline__ uint32_t load_id(const KArgs& a, int64_t pos, float& bad) {
-  int64_t id = a.id64 ? ((const int64_t*)a.x)[pos] : (int64_t)((const int32_t*)a.x)[pos];
-  if (id < 0 || id >= a.T) { bad += 1.f; id = 0; }
-  return (uint32_t)id;
+// Raw id of occurrence `pos` (not inspected here: looking at the value would force a wait on
+// every load in flight; the range check happens one pipeline stage later, in check_id).
+template <bool ID64>
+struct RawId { uint32_t lo, hi; };
+
+template <bool ID64>
+__device__ __forceinline__ RawId<ID64> load_raw_id(const KArgs& a, int64_t pos) {
+  RawId<ID64> r;
+  if constexpr (ID64) {
+    const uint2 v = reinterpret_cast<const uint2*>(a.x)[pos];
+    r.lo = v.x; r.hi = v.y;
+  } else {
+    r.lo = reinterpret_cast<const uint32_t*>(a.x)[pos];
+    r.hi = (r.lo >> 31) ? 0xFFFFFFFFu : 0u;   // sign extension of an int32 id
+  }
+  return r;
+}
+
+template <bool ID64>
+__device__ __forceinline__ uint32_t check_id(const KArgs& a, const RawId<ID64>& r, float& bad) {
+  const bool ok = (r.hi == 0u) && ((int64_t)r.lo < a.T);
+  if (!ok) bad += 1.f;
+  return ok ? r.lo : 0u;
 }
 
 // per-row running sums of one lane
@@ -323,7 +404,53 @@ struct RowAcc {
   }
 };
 
-// arithmetic of one occurrence: sample, FM partial sums, KL
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// z = mu + |s| eps for one chunk, FM partial sums and the KL polynomial / log parts.
+// VEC == 4 uses packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two coordinates per
+// instruction).  `valid` masks the lanes past the last chunk (they hold a re-loaded copy).
+template <int VEC, int MODE>
+__device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC>& s, const float (&ep)[VEC],
+                                           bool valid, Chunk<VEC>& sz, float& zz, float& klv) {
+  if constexpr (VEC == 4) {
+    v2f zq = {0.f, 0.f}, kq = {0.f, 0.f};
+    float lg = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const v2f m2 = {mu.v[2 * h], mu.v[2 * h + 1]};
+      const v2f g2 = {fabsf(s.v[2 * h]), fabsf(s.v[2 * h + 1])};
+      const v2f e2 = {ep[2 * h], ep[2 * h + 1]};
+      const v2f z2 = g2 * e2 + m2;
+      v2f a2 = {sz.v[2 * h], sz.v[2 * h + 1]};
+      a2 = valid ? a2 + z2 : a2;
+      sz.v[2 * h] = a2.x; sz.v[2 * h + 1] = a2.y;
+      zq = z2 * z2 + zq;
+      if constexpr (MODE == MODE_TRAIN) {
+        kq = g2 * g2 + kq;
+        kq = m2 * m2 + kq;
+        lg += __builtin_amdgcn_logf(fmaxf(g2.x, SIGMA_MIN)) + __builtin_amdgcn_logf(fmaxf(g2.y, SIGMA_MIN));
+      }
+    }
+    zz += valid ? zq.x + zq.y : 0.f;
+    if constexpr (MODE == MODE_TRAIN) klv += valid ? fmaf(0.5f, kq.x + kq.y, fmaf(-LN2, lg, -2.0f)) : 0.f;
+  } else {
+    const float sg = fabsf(s.v[0]);
+    const float z = valid ? fmaf(sg, ep[0], mu.v[0]) : 0.f;
+    sz.v[0] += z;
+    zz = fmaf(z, z, zz);
+    if constexpr (MODE == MODE_TRAIN) klv += valid ? kl_std_normal(mu.v[0], sg) : 0.f;
+  }
+}
+
+// first-order weight of one occurrence (the lane that owns it): sample + KL
+template <int MODE>
+__device__ __forceinline__ void bias_math(const float2 th, float epw, bool owner, float& part, float& klv) {
+  const float sgw = fabsf(th.y);
+  part += owner ? fmaf(sgw, epw, th.x) : 0.f;
+  if constexpr (MODE == MODE_TRAIN) klv += owner ? kl_std_normal(th.x, sgw) : 0.f;
+}
+
+// arithmetic of one occurrence (generic path): every lane draws its own chunk's eps
 template <int LPE, int CPL, int VEC, int EPS, int MODE>
 __device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CPL, VEC, EPS>& R, int lig,
                                               int C, float cs, RowAcc<CPL, VEC>& acc) {
@@ -331,42 +458,75 @@ __device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CP
   float epw = 0.f;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
-    const int j = lig + i * LPE;
-    if (j < C) {
-      Chunk<VEC> ep;
-      if constexpr (EPS == EPS_TABLE) {
-        ep = R.ep[i];
-      } else if constexpr (EPS == EPS_ZERO) {
+    int j = lig + i * LPE;
+    const bool valid = j < C;
+    j = valid ? j : C - 1;
+    float ep[VEC];
+    if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) ep.v[t] = 0.f;
-      } else {
-        float n[4], nb;
-        normal4b(a.key, R.e, (uint32_t)(VEC == 4 ? j : (j >> 2)), n, nb);
-        if constexpr (VEC == 4) {
+      for (int t = 0; t < VEC; ++t) ep[t] = R.ep[i].v[t];
+    } else if constexpr (EPS == EPS_ZERO) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ep.v[t] = n[t];
-        } else {
-          ep.v[0] = n[j & 3];
-        }
-        if (i == 0) epw = nb;   // only the lane that owns coordinate 0 (lig == 0) uses it
-      }
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) {
-        const float sg = fabsf(R.s[i].v[t]);
-        const float z = fmaf(sg, ep.v[t], R.mu[i].v[t]);
-        acc.sz[i].v[t] += z;
-        acc.zz = fmaf(z, z, acc.zz);
-        if constexpr (MODE == MODE_TRAIN) klv += kl_std_normal(R.mu[i].v[t], sg);
-      }
+      for (int t = 0; t < VEC; ++t) ep[t] = 0.f;
+    } else {
+      float nb;
+      eps_of_chunk<VEC>(a.key, R.e, j, ep, nb);
+      if (i == 0) epw = nb;   // only the lane that owns coordinate 0 (lig == 0) uses it
     }
+    chunk_math<VEC, MODE>(R.mu[i], R.s[i], ep, valid, acc.sz[i], acc.zz, klv);
   }
   if constexpr (EPS == EPS_TABLE) epw = R.epw;
-  if (lig == 0) {
-    const float sgw = fabsf(R.th.y);
-    acc.part += fmaf(sgw, epw, R.th.x);
-    if constexpr (MODE == MODE_TRAIN) klv += kl_std_normal(R.th.x, sgw);
-  }
+  bias_math<MODE>(R.th, epw, lig == 0, acc.part, klv);
   if constexpr (MODE == MODE_TRAIN) acc.kl = fmaf(cs * R.io, klv, acc.kl);
+}
+
+// arithmetic of a two-field row (VEC == 4): ONE Philox call per lane serves both fields.  Lanes
+// pair up (2m, 2m+1): the even lane draws the 8 normals of chunks (2m, 2m+1) of field 0's entity,
+// the odd lane those of field 1's entity, and they exchange one half over DPP (quad_perm
+// [1,0,3,2]).  Lane 0 / lane 1 own the first-order weights of field 0 / field 1 (their calls have
+// p == 0 and carry the bias normal).
+template <int LPE, int CPL, int EPS, int MODE>
+__device__ __forceinline__ void consume_row2(const KArgs& a, const FieldRegs<CPL, 4, EPS>& R0,
+                                             const FieldRegs<CPL, 4, EPS>& R1, int lig, int C, float cs0,
+                                             float cs1, RowAcc<CPL, 4>& acc) {
+  static_assert(LPE >= 2, "lane pairing needs at least two lanes per row");
+  const bool odd = lig & 1;
+  float kl0 = 0.f, kl1 = 0.f, epw = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    int j = lig + i * LPE;
+    const bool valid = j < C;
+    j = valid ? j : C - 1;
+    float ep0[4], ep1[4];
+    if constexpr (EPS == EPS_TABLE) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { ep0[t] = R0.ep[i].v[t]; ep1[t] = R1.ep[i].v[t]; }
+    } else if constexpr (EPS == EPS_ZERO) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { ep0[t] = 0.f; ep1[t] = 0.f; }
+    } else {
+      float n[8], nb;
+      // pair index of chunk j is j >> 1 (LPE is even, so both lanes of a pair agree on it)
+      normal8b(a.key, odd ? R1.e : R0.e, (uint32_t)j >> 1, n, nb);
+      if (i == 0) epw = nb;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float send = odd ? n[t] : n[4 + t];     // what the partner lane needs from me
+        const float recv = dpp_f<0xB1>(send);
+        ep0[t] = odd ? recv : n[t];                   // field 0, my chunk
+        ep1[t] = odd ? n[4 + t] : recv;               // field 1, my chunk
+      }
+    }
+    chunk_math<4, MODE>(R0.mu[i], R0.s[i], ep0, valid, acc.sz[i], acc.zz, kl0);
+    chunk_math<4, MODE>(R1.mu[i], R1.s[i], ep1, valid, acc.sz[i], acc.zz, kl1);
+  }
+  if constexpr (EPS == EPS_TABLE) epw = odd ? R1.epw : R0.epw;
+  float klb = 0.f;
+  bias_math<MODE>(odd ? R1.th : R0.th, epw, lig < 2, acc.part, klb);
+  if constexpr (MODE == MODE_TRAIN) {
+    const float c0 = cs0 * R0.io, c1 = cs1 * R1.io;
+    acc.kl = fmaf(c0, kl0, fmaf(c1, kl1, fmaf(odd ? c1 : c0, klb, acc.kl)));
+  }
 }
 
 // finish a row: FM reduction over the group, likelihood, outputs
@@ -376,9 +536,12 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
                                            RowAcc<CPL, VEC>& acc, float (&tot)[5]) {
   float q = -acc.zz;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i)
+  for (int i = 0; i < CPL; ++i) {
+    float qi = 0.f;
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) q = fmaf(acc.sz[i].v[t], acc.sz[i].v[t], q);
+    for (int t = 0; t < VEC; ++t) qi = fmaf(acc.sz[i].v[t], acc.sz[i].v[t], qi);
+    q += (lig + i * LPE < C) ? qi : 0.f;
+  }
   const float pred = w0 + group_sum<LPE>(fmaf(0.5f, q, acc.part));
   if constexpr (MODE == MODE_TRAIN) {
     tot[1] += acc.kl;
@@ -398,9 +561,11 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
         dll = aabs * diff;
         tot[3] += 0.5f * diff * diff - 0.5f / aabs;
       } else {
-        const float e1 = __expf(-fabsf(pred));
-        ll = y * pred - (fmaxf(pred, 0.f) + log1pf(e1));
-        dll = y - ((pred >= 0.f) ? 1.f / (1.f + e1) : e1 / (1.f + e1));
+        // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
+        const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
+        ll = y * pred - (fmaxf(pred, 0.f) + LN2 * __builtin_amdgcn_logf(1.0f + e1));
+        const float inv = __builtin_amdgcn_rcpf(1.0f + e1);
+        dll = y - ((pred >= 0.f) ? inv : e1 * inv);
       }
       const float g = -a.ll_scale * dll;
       tot[0] += ll;
@@ -410,7 +575,7 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
   }
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF>
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF, bool ID64>
 __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
@@ -431,8 +596,8 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
   if constexpr (EPS == EPS_PHILOX) {
-    float n[4], nb;
-    normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+    float n[8], nb;
+    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
     e0 = n[0];
   }
   const float w0 = fmaf(fabsf(s0), e0, m0);
@@ -442,71 +607,79 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids
   const int64_t ngroups = (int64_t)gridDim.x * GPB;
   const int64_t g0 = (int64_t)blockIdx.x * GPB + tid / LPE;
+  const int64_t Bm1 = a.B - 1;
 
-  if constexpr (FF == 2) {
-    // ---- two fields per row, both in registers; double buffer across rows ----
+  if constexpr (FF == 2 && VEC == 4 && LPE >= 2) {
+    // ---- two fields per row, both in registers; double buffer across rows.  Rows past the end
+    // are clamped to the last row for the (harmless, branch-free) prefetches. ----
     float cs0 = 0.f, cs1 = 0.f;
     int64_t hi0 = 0;
     if constexpr (MODE == MODE_TRAIN) { cs0 = sh_cs[0]; cs1 = sh_cs[1]; hi0 = sh_hi[0]; }
     FieldRegs<CPL, VEC, EPS> A0, A1, B0, B1;
     float yA = 0.f, yB = 0.f;
     int64_t r = g0;
-    uint32_t n0 = 0, n1 = 0;            // ids of the row after the loaded one
     if (r < a.B) {
-      const uint32_t e0i = load_id(a, r * 2, tot[4]), e1i = load_id(a, r * 2 + 1, tot[4]);
-      load_field<LPE, CPL, VEC, EPS, MODE>(a, e0i, lig, C, A0);
-      load_field<LPE, CPL, VEC, EPS, MODE>(a, e1i, lig, C, A1);
+      RawId<ID64> i0 = load_raw_id<ID64>(a, r * 2), i1 = load_raw_id<ID64>(a, r * 2 + 1);
+      const int64_t r1 = (r + ngroups < a.B) ? r + ngroups : Bm1;
+      RawId<ID64> n0 = load_raw_id<ID64>(a, r1 * 2), n1 = load_raw_id<ID64>(a, r1 * 2 + 1);
+      load_field<LPE, CPL, VEC, EPS, MODE>(a, check_id<ID64>(a, i0, tot[4]), lig, C, A0);
+      load_field<LPE, CPL, VEC, EPS, MODE>(a, check_id<ID64>(a, i1, tot[4]), lig, C, A1);
       if constexpr (MODE == MODE_TRAIN) yA = a.y[r];
-      if (r + ngroups < a.B) {
-        n0 = load_id(a, (r + ngroups) * 2, tot[4]);
-        n1 = load_id(a, (r + ngroups) * 2 + 1, tot[4]);
-      }
-    }
-    RowAcc<CPL, VEC> acc;
-    while (r < a.B) {
-      // --- stage: issue the loads of row r + ngroups into B, ids of r + 2*ngroups
-      const int64_t rn = r + ngroups;
-      if (rn < a.B) {
-        load_field<LPE, CPL, VEC, EPS, MODE>(a, n0, lig, C, B0);
-        load_field<LPE, CPL, VEC, EPS, MODE>(a, n1, lig, C, B1);
-        if constexpr (MODE == MODE_TRAIN) yB = a.y[rn];
-        if (rn + ngroups < a.B) {
-          n0 = load_id(a, (rn + ngroups) * 2, tot[4]);
-          n1 = load_id(a, (rn + ngroups) * 2 + 1, tot[4]);
+      RowAcc<CPL, VEC> acc;
+      while (true) {
+        // stage 1: table rows of row r+ng into B (ids arrived a stage ago), ids of row r+2ng
+        int64_t rn = r + ngroups;
+        {
+          const int64_t rc = rn < a.B ? rn : Bm1;
+          const int64_t r2 = (rn + ngroups < a.B) ? rn + ngroups : Bm1;
+          const bool live = rn < a.B;
+          float badn = 0.f;
+          const uint32_t e0n = check_id<ID64>(a, n0, badn), e1n = check_id<ID64>(a, n1, badn);
+          if (live) tot[4] += badn;
+          n0 = load_raw_id<ID64>(a, r2 * 2);
+          n1 = load_raw_id<ID64>(a, r2 * 2 + 1);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, e0n, lig, C, B0);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, e1n, lig, C, B1);
+          if constexpr (MODE == MODE_TRAIN) yB = a.y[rc];
         }
-      }
-      // --- arithmetic of row r from A
-      acc.reset();
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A0, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1, acc);
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A1, lig, C, ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
-      finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yA, acc, tot);
-      r = rn;
-      if (r >= a.B) break;
-      // --- same with the roles of A and B swapped (static register naming, no copies)
-      const int64_t rm = r + ngroups;
-      if (rm < a.B) {
-        load_field<LPE, CPL, VEC, EPS, MODE>(a, n0, lig, C, A0);
-        load_field<LPE, CPL, VEC, EPS, MODE>(a, n1, lig, C, A1);
-        if constexpr (MODE == MODE_TRAIN) yA = a.y[rm];
-        if (rm + ngroups < a.B) {
-          n0 = load_id(a, (rm + ngroups) * 2, tot[4]);
-          n1 = load_id(a, (rm + ngroups) * 2 + 1, tot[4]);
+        // stage 2: arithmetic of row r from A while B's loads are in flight
+        acc.reset();
+        consume_row2<LPE, CPL, EPS, MODE>(a, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
+                                          ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yA, acc, tot);
+        r = rn;
+        if (r >= a.B) break;
+        // the same with the roles of A and B swapped (static register naming, no copies)
+        rn = r + ngroups;
+        {
+          const int64_t rc = rn < a.B ? rn : Bm1;
+          const int64_t r2 = (rn + ngroups < a.B) ? rn + ngroups : Bm1;
+          const bool live = rn < a.B;
+          float badn = 0.f;
+          const uint32_t e0n = check_id<ID64>(a, n0, badn), e1n = check_id<ID64>(a, n1, badn);
+          if (live) tot[4] += badn;
+          n0 = load_raw_id<ID64>(a, r2 * 2);
+          n1 = load_raw_id<ID64>(a, r2 * 2 + 1);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, e0n, lig, C, A0);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, e1n, lig, C, A1);
+          if constexpr (MODE == MODE_TRAIN) yA = a.y[rc];
         }
+        acc.reset();
+        consume_row2<LPE, CPL, EPS, MODE>(a, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
+                                          ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yB, acc, tot);
+        r = rn;
+        if (r >= a.B) break;
       }
-      acc.reset();
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, B0, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1, acc);
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, B1, lig, C, ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
-      finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yB, acc, tot);
-      r = rm;
     }
   } else {
     // ---- runtime number of fields: stream the occurrences (r, f), double buffer across them ----
-    FieldRegs<CPL, VEC, EPS> A, Bq;
-    RowAcc<CPL, VEC> acc;
-    int64_t r = g0;
-    int f = 0;
-    if (r < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, r * F, tot[4]), lig, C, A);
-    acc.reset();
+    auto raw = [&](int64_t pos) -> RawId<true> {
+      RawId<true> v;
+      if (a.id64) { const uint2 t = reinterpret_cast<const uint2*>(a.x)[pos]; v.lo = t.x; v.hi = t.y; }
+      else { v.lo = reinterpret_cast<const uint32_t*>(a.x)[pos]; v.hi = (v.lo >> 31) ? 0xFFFFFFFFu : 0u; }
+      return v;
+    };
     auto cs_of = [&](uint32_t e, int fcol) -> float {
       if constexpr (MODE != MODE_TRAIN) return 0.f;
       const int64_t id = (int64_t)e;
@@ -514,41 +687,76 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
       if (id >= lo && id < sh_hi[fcol]) return sh_cs[fcol];   // the usual case: column f <-> group f
       return sh_cs[group_index(sh_hi, a.G, id)];
     };
-    while (r < a.B) {
-      // next occurrence
-      int fn = f + 1;
-      int64_t rn = r;
-      if (fn == F) { fn = 0; rn = r + ngroups; }
-      if (rn < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, rn * F + fn, tot[4]), lig, C, Bq);
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, A, lig, C, cs_of(A.e, f), acc);
-      if (f == F - 1) {
-        float y = 0.f;
-        if constexpr (MODE == MODE_TRAIN) y = a.y[r];
-        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
-        acc.reset();
+    FieldRegs<CPL, VEC, EPS> A, Bq;
+    RowAcc<CPL, VEC> acc;
+    int64_t r = g0;
+    int f = 0;
+    if (r < a.B) {
+      const int64_t last = a.B * F - 1;
+      load_field<LPE, CPL, VEC, EPS, MODE>(a, check_id<true>(a, raw(r * F), tot[4]), lig, C, A);
+      // position of the occurrence after the current one (clamped), its id prefetched
+      auto next_pos = [&](int64_t rr, int ff, int64_t& rn, int& fn) {
+        fn = ff + 1; rn = rr;
+        if (fn == F) { fn = 0; rn = rr + ngroups; }
+      };
+      int64_t rn; int fn;
+      next_pos(r, f, rn, fn);
+      RawId<true> nid = raw(rn < a.B ? rn * F + fn : last);
+      acc.reset();
+      while (true) {
+        // stage 1: table row of the next occurrence, id of the one after
+        {
+          const bool live = rn < a.B;
+          float badn = 0.f;
+          const uint32_t en = check_id<true>(a, nid, badn);
+          if (live) tot[4] += badn;
+          int64_t r2; int f2;
+          next_pos(rn, fn, r2, f2);
+          nid = raw(r2 < a.B ? r2 * F + f2 : last);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, Bq);
+        }
+        consume_field<LPE, CPL, VEC, EPS, MODE>(a, A, lig, C, cs_of(A.e, f), acc);
+        if (f == F - 1) {
+          float y = 0.f;
+          if constexpr (MODE == MODE_TRAIN) y = a.y[r];
+          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+          acc.reset();
+        }
+        r = rn; f = fn;
+        if (r >= a.B) break;
+        next_pos(r, f, rn, fn);
+        {
+          const bool live = rn < a.B;
+          float badn = 0.f;
+          const uint32_t en = check_id<true>(a, nid, badn);
+          if (live) tot[4] += badn;
+          int64_t r2; int f2;
+          next_pos(rn, fn, r2, f2);
+          nid = raw(r2 < a.B ? r2 * F + f2 : last);
+          load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, A);
+        }
+        consume_field<LPE, CPL, VEC, EPS, MODE>(a, Bq, lig, C, cs_of(Bq.e, f), acc);
+        if (f == F - 1) {
+          float y = 0.f;
+          if constexpr (MODE == MODE_TRAIN) y = a.y[r];
+          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+          acc.reset();
+        }
+        r = rn; f = fn;
+        if (r >= a.B) break;
+        next_pos(r, f, rn, fn);
       }
-      r = rn; f = fn;
-      if (r >= a.B) break;
-      fn = f + 1; rn = r;
-      if (fn == F) { fn = 0; rn = r + ngroups; }
-      if (rn < a.B) load_field<LPE, CPL, VEC, EPS, MODE>(a, load_id(a, rn * F + fn, tot[4]), lig, C, A);
-      consume_field<LPE, CPL, VEC, EPS, MODE>(a, Bq, lig, C, cs_of(Bq.e, f), acc);
-      if (f == F - 1) {
-        float y = 0.f;
-        if constexpr (MODE == MODE_TRAIN) y = a.y[r];
-        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
-        acc.reset();
-      }
-      r = rn; f = fn;
     }
   }
+  // per-block partial sums go to the block's own slot (plain stores: no same-address atomics --
+  // 5 fp64 atomics from each of ~10^3 blocks finishing together serialised for tens of
+  // microseconds -- and the sums become bitwise reproducible); k_finalize adds the slots up.
   block_sum<5>(tot, sh_red);
   if (tid == 0) {
-    if (tot[0] != 0.f) atomicAdd(&out.partials[VFM_P_LL], (double)tot[0]);
-    if (tot[1] != 0.f) atomicAdd(&out.partials[VFM_P_KL], (double)tot[1]);
-    if (tot[2] != 0.f) atomicAdd(&out.partials[VFM_P_G], (double)tot[2]);
-    if (tot[3] != 0.f) atomicAdd(&out.partials[VFM_P_ALPHA], (double)tot[3]);
-    if (tot[4] != 0.f) atomicAdd(&out.partials[VFM_P_BADID], (double)tot[4]);
+    double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) slot[i] = (double)tot[i];
+    if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
   }
 }
 
@@ -597,8 +805,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     float e0 = 0.f;
     if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
     if constexpr (EPS == EPS_PHILOX) {
-      float n[4], nb;
-      normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      float n[8], nb;
+      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
       e0 = n[0];
     }
     const float as0 = fabsf(s0);
@@ -741,14 +949,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 #pragma unroll
             for (int t = 0; t < VEC; ++t) epc.v[t] = 0.f;
           } else {
-            float n[4], nb;
-            normal4b(a.key, (uint32_t)e, (uint32_t)(VEC == 4 ? j : (j >> 2)), n, nb);
-            if constexpr (VEC == 4) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t) epc.v[t] = n[t];
-            } else {
-              epc.v[0] = n[j & 3];
-            }
+            float nb;
+            eps_of_chunk<VEC>(a.key, (uint32_t)e, j, epc.v, nb);
             if (i == 0) nb_eps = nb;
           }
 #pragma unroll
@@ -842,21 +1044,21 @@ __global__ __launch_bounds__(BLOCK) void k_adam(float* __restrict__ p, const flo
 
 // eps dump (tests)
 __global__ void k_philox_dump(const KArgs a, float* eps_entity, float* eps_bias, float* eps_global) {
-  const int64_t n4 = ((int64_t)a.d + 3) / 4;
-  const int64_t total = a.T * n4;
+  const int64_t n8 = ((int64_t)a.d + 7) / 8;
+  const int64_t total = a.T * n8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i / n4;
-    const int j = (int)(i % n4);
-    float n[4], nb;
-    normal4b(a.key, (uint32_t)e, (uint32_t)j, n, nb);
-    for (int t = 0; t < 4; ++t)
-      if (j * 4 + t < a.d) eps_entity[e * a.d + j * 4 + t] = n[t];
-    if (j == 0) eps_bias[e] = nb;
+    const int64_t e = i / n8;
+    const int p = (int)(i % n8);
+    float n[8], nb;
+    normal8b(a.key, (uint32_t)e, (uint32_t)p, n, nb);
+    for (int t = 0; t < 8; ++t)
+      if (p * 8 + t < a.d) eps_entity[e * a.d + p * 8 + t] = n[t];
+    if (p == 0) eps_bias[e] = nb;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float n[4], nb;
-    normal4b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+    float n[8], nb;
+    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
     eps_global[0] = n[0];
   }
 }
@@ -901,6 +1103,11 @@ int check_problem(const vfm_problem_t* p) {
   return 0;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 // eps source of a call: VFM_FLAG_EPS_ZERO > tables > Philox
 int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const float* eg, int* mode) {
   const int neps = (ee != nullptr) + (eb != nullptr) + (eg != nullptr);
@@ -925,23 +1132,19 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   return a;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 // ---- forward dispatch: shape x eps source x mode x (F == 2 ?) ----
-template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF>
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF, bool ID64>
 int launch_fwd_t(KArgs& a, const FwdOut& o, hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
   // persistent-ish grid: enough groups that each owns a few rows (pipelined), capped at
   // VFM_FWD_BLOCKS_PER_CU resident workgroups on each of the 256 CUs
-  const int per_cu = env_int("VFM_FWD_BLOCKS_PER_CU", 6);
+  const int per_cu = env_int("VFM_FWD_BLOCKS_PER_CU", 4);
   int64_t nb = (a.B + GPB - 1) / GPB;
-  const int64_t cap = 256LL * per_cu;
+  int64_t cap = 256LL * per_cu;
+  if (cap > VFM_MAX_FWD_BLOCKS) cap = VFM_MAX_FWD_BLOCKS;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((k_fwd<LPE, CPL, VEC, EPS, MODE, FF>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
+  hipLaunchKernelGGL((k_fwd<LPE, CPL, VEC, EPS, MODE, FF, ID64>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
   return 0;
 }
 
@@ -950,9 +1153,12 @@ int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream
 #define FWD(E_, M_)                                                              \
   if (eps == E_ && mode == M_) {                                                 \
     if constexpr (VEC == 4) {                                                    \
-      if (ff == 2) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2>(a, o, st);      \
+      if constexpr (LPE >= 2) {                                                              \
+        if (ff == 2 && a.id64) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2, true>(a, o, st);  \
+        if (ff == 2) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2, false>(a, o, st);           \
+      }                                                                                      \
     }                                                                            \
-    return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0>(a, o, st);                     \
+    return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0, true>(a, o, st);               \
   }
   FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN)
   FWD(EPS_PHILOX, MODE_PREDICT) FWD(EPS_TABLE, MODE_PREDICT) FWD(EPS_ZERO, MODE_PREDICT)
@@ -1059,8 +1265,10 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
   if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, partials, (int)VFM_N_PARTIALS);
-  if (p->B == 0) return 0;
+  if (p->B == 0) {  // empty shard: zero sums, zero blocks
+    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, partials, (int)VFM_N_PARTIALS);
+    return after_launch("vfm_elbo_fwd_f32");
+  }
   KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
   FwdOut o{pred, partials, sumz, grow};
@@ -1070,12 +1278,12 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   return after_launch("vfm_elbo_fwd_f32");
 }
 
-int vfm_elbo_finalize_f32(const vfm_problem_t* p, const double* partials, const float* scalars,
+int vfm_elbo_finalize_f32(const vfm_problem_t* p, double* partials, const float* scalars,
                           float* loss, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!partials || !scalars || !loss) return fail(VFM_E_INVALID, "vfm_elbo_finalize_f32: NULL pointer");
   const double ll_scale = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, scalars, ll_scale,
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, partials, scalars, ll_scale,
                      (int)p->flags, loss);
   return after_launch("vfm_elbo_finalize_f32");
 }

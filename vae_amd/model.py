@@ -257,7 +257,7 @@ class VFM(nn.Module):
             self._gflat = torch.zeros(self._n_flat + 4, dtype=torch.float32, device=self.device)
             self._adam_t = 0
             self._gout = torch.ones(1, dtype=torch.float32, device=self.device)
-            self._partials = torch.zeros(_lib.N_PARTIALS, dtype=torch.float64, device=self.device)
+            self._partials = torch.zeros(_lib.PARTIALS_LEN, dtype=torch.float64, device=self.device)
             self._state_bufs = {}
 
     def _step_buffers(self, B):

@@ -148,7 +148,7 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
     B = plan.B
     pred = out_pred if out_pred is not None else torch.empty(B, dtype=torch.float32, device=dev)
     partials = out_partials if out_partials is not None else torch.empty(
-        _lib.N_PARTIALS, dtype=torch.float64, device=dev)
+        _lib.PARTIALS_LEN, dtype=torch.float64, device=dev)
     sumz = grow = None
     if train:
         sumz = out_sumz if out_sumz is not None else torch.empty(B, spec.d, dtype=torch.float32, device=dev)
