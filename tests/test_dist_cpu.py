@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the row-sharded step reproduces the single-process step.
+
+The per-rank arithmetic is done by the fp64 row-wise oracle (test infrastructure); the exchange
+logic under test is the product's: vae_amd.dist.shard_rows / sum_normalisers / allreduce_flat /
+prior_terms_flag, used exactly as VFM.fit / VFM.train_step use them."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from golden_util import Case, PARAM_KEYS, rel_err
+from oracle import vfm_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import shard_rows, sum_normalisers, allreduce_flat, prior_terms_flag
+    c = Case(name)
+    P = c.params(np.float64)
+    e0, ew, ev = c.eps("f64" if f"f64_eps0" in c.z.files else "f32")
+    B = len(c.y)
+    a, b = shard_rows(0, B, rank, world)
+    x, y = c.x[a:b], c.y[a:b].astype(np.float64)
+    # 1. batch normalisers: local partial sums -> SUM over ranks
+    W = torch.tensor(O.batch_norms(x, c.nb_occ))
+    sum_normalisers(W)
+    # 2. local ELBO pieces with global W and B_global
+    r = O.rowwise_elbo(P, x, y, c.nb_occ, c.group_hi, c.group_n, c.nb_train, e0, ew, ev, c.output,
+                       W=W.numpy(), B_global=B)
+    no_prior = prior_terms_flag(rank)
+    m0, s0 = float(P["global_bias_mean"][0]), float(P["global_bias_scale"][0])
+    loss = r["loss"] - (r["kl0"] if no_prior else 0.0)
+    g_m0 = r["g_global_bias_mean"][0] - (m0 if no_prior else 0.0)
+    g_s0 = r["g_global_bias_scale"][0] - (np.sign(s0) * (abs(s0) - 1 / abs(s0)) if no_prior else 0.0)
+    flat = torch.tensor(np.concatenate([r["g_entity_params"].reshape(-1), r["g_bias_params"].reshape(-1),
+                                        r["g_alpha"], [g_m0], [g_s0], [loss]]))
+    # 3. the one collective
+    allreduce_flat(flat)
+    np.save(os.path.join(out_dir, f"flat_{rank}.npy"), flat.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["quirk_reg_d8", "fraction_class_d5"])
+def test_two_rank_step_equals_single_process(name, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    c = Case(name)
+    tag = "f64"
+    e0, ew, ev = c.eps(tag)
+    full = O.rowwise_elbo(c.params(np.float64), c.x, c.y.astype(np.float64), c.nb_occ, c.group_hi,
+                          c.group_n, c.nb_train, e0, ew, ev, c.output)
+    want = np.concatenate([full["g_entity_params"].reshape(-1), full["g_bias_params"].reshape(-1),
+                           full["g_alpha"], full["g_global_bias_mean"], full["g_global_bias_scale"],
+                           [full["loss"]]])
+    got0 = np.load(tmp_path / "flat_0.npy")
+    got1 = np.load(tmp_path / "flat_1.npy")
+    assert np.array_equal(got0, got1)                       # replicas stay identical
+    assert rel_err(got0, want) < 1e-12
+    # and both equal the reference's own numbers
+    assert abs(got0[-1] - c.expected("loss", tag)[0]) / abs(c.expected("loss", tag)[0]) < 1e-7
+
+
+def test_shard_rows_partitions_every_batch():
+    from vae_amd.dist import shard_rows
+    for lo, hi in ((0, 10), (7, 8), (100, 100), (3, 1000003)):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(lo, hi, r, world) for r in range(world)]
+            assert spans[0][0] == lo and spans[-1][1] == hi
+            for (a, b), (c_, d) in zip(spans[:-1], spans[1:]):
+                assert b == c_ and a <= b
+            assert sum(b - a for a, b in spans) == hi - lo

@@ -1,0 +1,71 @@
+"""GPU, 2 processes sharing cuda:0 (gloo transport): the real HIP step, row-sharded over two ranks
+with W all-reduce + one flat all-reduce + NO_PRIOR_TERMS on rank 1, equals the 1-rank step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from golden_util import Case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(c, dev):
+    from vae_amd.model import VFM
+    torch.manual_seed(42)
+    m = VFM(c.N, c.M, c.d, output=c.output, device=dev, rng_seed=77)
+    m.set_training_data(torch.tensor(c.x), nb_train=c.nb_train, nb_occ=torch.tensor(c.nb_occ))
+    return m
+
+
+def _worker(rank, world, port, name, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import shard_rows
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    m = _make_model(c, dev)
+    B = len(c.y)
+    losses = []
+    for step in range(3):
+        a, b = shard_rows(0, B, rank, world)
+        plan = m.plan(torch.tensor(c.x[a:b]), torch.tensor(c.y[a:b]), B_global=B, process_group=dist.group.WORLD)
+        loss3, _ = m.train_step(plan, lr=0.05, process_group=dist.group.WORLD)
+        losses.append(loss3.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"params_{rank}.npy"), m._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"loss_{rank}.npy"), np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ml100k_reg_d20"])
+def test_two_ranks_match_one_rank(name, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    c = Case(name)
+    dev = torch.device("cuda:0")
+    m = _make_model(c, dev)
+    plan = m.plan(torch.tensor(c.x), torch.tensor(c.y))
+    ref_losses = []
+    for step in range(3):
+        loss3, _ = m.train_step(plan, lr=0.05, fused=False)
+        ref_losses.append(loss3.cpu().numpy().copy())
+    want = m._flat.cpu().numpy()
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    assert np.array_equal(p0, p1)                         # replicas stay bit-identical
+    assert rel_err(p0, want) < 1e-5
+    l0 = np.load(tmp_path / "loss_0.npy")
+    assert rel_err(l0, np.array(ref_losses)) < 1e-5

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import _lib, ops
+from .dist import shard_rows, allreduce_flat, prior_terms_flag
 
 
 class LikelihoodResult:
@@ -286,7 +287,7 @@ class VFM(nn.Module):
         g_ent, g_bias, g_scal = self._views(self._gflat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
         rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
-        flags = ops.FLAG_NO_PRIOR_TERMS if rank != 0 else 0
+        flags = prior_terms_flag(rank)
         step = self.global_step
         self.global_step += 1
         mark = mark or (lambda name: None)      # bench.py records HIP events at these points
@@ -311,7 +312,7 @@ class VFM(nn.Module):
         mark("bwd")
         if process_group is not None:
             # the ONE collective of the step: [g_entity | g_bias | g_scalars | loss] summed over ranks
-            torch.distributed.all_reduce(self._gflat, group=process_group)
+            allreduce_flat(self._gflat, process_group)
             mark("allreduce")
         if adam:
             self._adam_t += 1
@@ -411,14 +412,6 @@ class VFM(nn.Module):
                     "rmse_of_last": rm(out["y_pred_of_last"]), "rmse_of_mean": rm(out["y_pred_of_mean"])}
         auc, ap = _auc_map(y, out["y_pred"])
         return {"auc": auc, "map": ap}
-
-
-def shard_rows(lo: int, hi: int, rank: int, world: int):
-    """Contiguous row block of batch [lo, hi) owned by `rank`."""
-    n = hi - lo
-    per = (n + world - 1) // world
-    a = min(lo + rank * per, hi)
-    return a, min(a + per, hi)
 
 
 def _auc_map(y, p):

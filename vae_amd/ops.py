@@ -106,7 +106,8 @@ class BatchPlan:
             check(lib.vfm_batch_norms(C.byref(p), ptr(x), ptr(inv_occ), ptr(self.W),
                                       current_stream_ptr(dev)), "vfm_batch_norms")
             if process_group is not None:
-                torch.distributed.all_reduce(self.W, group=process_group)
+                from .dist import sum_normalisers
+                sum_normalisers(self.W, process_group)
         if build_index and y is not None:
             self.build_index()
 
