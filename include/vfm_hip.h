@@ -152,15 +152,18 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
  * the three scalars with torch.optim.Adam's update (defaults of vfm-torch.py:339; `step` is the
  * 1-based update count).  The gradient never reaches HBM.  In place on entity_params, bias_params,
  * scalars and the six moment buffers (same shapes as their parameters).  Rows not in the batch
- * still move through their momentum, exactly like the reference's dense Adam. */
+ * still move through their momentum, exactly like the reference's dense Adam.
+ * `loss` (3 floats) may be NULL; when given, the launch also does the work of
+ * vfm_elbo_finalize_f32 (slot reduction + loss triple), saving that launch. */
 int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
                           float* entity_params, float* bias_params, float* scalars,
                           const float* inv_occ, const double* W,
                           const float* eps_entity, const float* eps_bias, const float* eps_global,
-                          const float* sumz, const float* grow, const double* partials,
+                          const float* sumz, const float* grow, double* partials,
                           float* m_entity, float* v_entity, float* m_bias, float* v_bias,
                           float* m_scalars, float* v_scalars,
-                          float lr, float beta1, float beta2, float eps_adam, int64_t step, void* stream);
+                          float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                          void* stream);
 
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library and the torch.ops shim load and export everything include/vfm_hip.h
+declares (no compute without a GPU); argument errors are reported, not crashed on."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "vfm_hip.h")).read()
+    return sorted(set(re.findall(r"\b(vfm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_are_exported():
+    from vae_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.EXPORTS)
+    assert lib.vfm_abi_version() == _lib.ABI_VERSION
+
+
+def test_problem_struct_layout_matches_header():
+    from vae_amd._lib import Problem
+    # 4*8 + 6*4 + 64*8 + 64*8 + 2*8
+    assert C.sizeof(Problem) == 32 + 24 + 512 + 512 + 16
+
+
+def test_bad_arguments_return_errors_not_crashes():
+    from vae_amd import _lib
+    lib = _lib.load()
+    p = _lib.Problem()
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) != 0
+    assert b"bad B or T" in lib.vfm_last_error() or len(lib.vfm_last_error()) > 0
+    p.B, p.B_global, p.T, p.F, p.d, p.id_bits, p.n_samples = 4, 4, 10, 2, 8, 64, 1
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1          # NULL pointers
+    p.n_samples = 3
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -2          # unsupported S > 1
+    p.n_samples, p.d = 1, 1027
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -2          # unsupported d
+    assert lib.vfm_adam_f32(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, 1, None) == -1
+
+
+def test_torch_ops_shim_registers_schemas():
+    from vae_amd import _lib
+    ops = _lib.ops()
+    assert ops.abi_version() == _lib.ABI_VERSION
+    for name in ("elbo_fwd", "elbo_finalize", "elbo_bwd", "elbo_bwd_adam", "adam"):
+        assert hasattr(ops, name)
+    # CPU tensors are rejected loudly (no fallback)
+    x = torch.zeros(4, 2, dtype=torch.int64)
+    t = torch.zeros(10, 16)
+    with pytest.raises(RuntimeError):
+        ops.elbo_fwd(x, None, t, torch.zeros(10, 2), None, torch.zeros(3), None, None, None, None,
+                     torch.zeros(4), torch.zeros(8 * 4097, dtype=torch.float64), None, None,
+                     [5, 10], [5.0, 5.0], 1, 4, 0, 0, 0, 0)
+
+
+def test_cpu_model_ops_fail_loudly():
+    from vae_amd.model import VFM
+    from vae_amd._lib import VfmLibraryError
+    m = VFM(5, 5, 4, device="cpu")
+    with pytest.raises(VfmLibraryError):
+        m.set_training_data(torch.tensor([[0, 5]]), nb_train=1)

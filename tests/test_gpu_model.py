@@ -189,3 +189,24 @@ def test_zero_scale_parameter_is_guarded():
     for p in (m.entity_params.weight, m.bias_params.weight, m.alpha, m.global_bias_mean, m.global_bias_scale):
         assert torch.isfinite(p.grad).all()
     assert m.entity_params.weight.grad[e, c.d + 3] < 0      # pushed away from 0 (towards +)
+
+
+def test_sort_within_batch_keeps_batches_and_results():
+    from vae_amd.model import VFM, sort_rows_within_batches
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([300, 200], 5000, seed=4, device="cuda")
+    Xs, ys = sort_rows_within_batches(X, y, 2000)
+    for lo in range(0, 5000, 2000):
+        a = torch.cat([X[lo:lo + 2000], y[lo:lo + 2000, None].long()], 1)
+        b = torch.cat([Xs[lo:lo + 2000], ys[lo:lo + 2000, None].long()], 1)
+        assert torch.equal(a[torch.argsort(a[:, 0] * 1000003 + a[:, 1] * 7 + a[:, 2], stable=True)],
+                           b[torch.argsort(b[:, 0] * 1000003 + b[:, 1] * 7 + b[:, 2], stable=True)])
+        assert (Xs[lo:lo + 2000, 1][1:] >= Xs[lo:lo + 2000, 1][:-1]).all()
+    res = []
+    for sort in (False, True):
+        torch.manual_seed(1)
+        m = VFM(300, 200, 16, device="cuda", rng_seed=5)
+        h = m.fit(X, y, n_epochs=2, batch_size=2000, verbose=False, sort_within_batch=sort)
+        res.append((h["elbo"], m._flat.clone()))
+    assert abs(res[0][0][-1] - res[1][0][-1]) / abs(res[0][0][-1]) < 1e-4
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-3)

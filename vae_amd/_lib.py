@@ -72,7 +72,7 @@ def load():
     lib.vfm_elbo_bwd_f32.argtypes = [PP] + [vp] * 18
     lib.vfm_philox_eps_f32.argtypes = [PP, vp, vp, vp, vp]
     lib.vfm_elbo_bwd_adam_f32.argtypes = ([PP] + [vp] * 19 +
-                                          [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
+                                          [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                  i64, vp]
     for name in EXPORTS:
@@ -83,6 +83,25 @@ def load():
         raise VfmLibraryError(f"ABI mismatch: library {lib.vfm_abi_version()}, package {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+_ops = None
+
+
+def ops():
+    """`torch.ops.vfm_hip` -- the TORCH_LIBRARY shim over the same C ABI (libvfm_torch_ops.so).
+    The per-step calls (forward, finalize, backward, Adam) go through it."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    load()
+    if not os.path.exists(OPS_PATH):
+        raise VfmLibraryError(f"{OPS_PATH} not found: run __graft_entry__.build()")
+    torch.ops.load_library(OPS_PATH)
+    if torch.ops.vfm_hip.abi_version() != ABI_VERSION:
+        raise VfmLibraryError("ABI mismatch between libvfm_torch_ops.so and the package")
+    _ops = torch.ops.vfm_hip
+    return _ops
 
 
 def check(rc, what):

@@ -121,6 +121,7 @@ struct KArgs {
   int64_t B, T;
   int32_t F, d, lik, id64, G, TR, flags;
   float ll_scale;  // nb_train / B_global
+  double ll_scale_d;
   RngKey key;
   const void* x;
   const float* y;
@@ -148,11 +149,12 @@ struct BwdArgs {
   const int32_t* occ_rows;
   const float* sumz;
   const float* grow;
-  const double* partials;
+  double* partials;
   const float* grad_out;
   float* g_entity;
   float* g_bias;
   float* g_scalars;
+  float* loss;   // non-NULL: this launch also reduces the forward's partial slots and forms the loss
 };
 
 template <int VEC>
@@ -282,10 +284,12 @@ __global__ __launch_bounds__(BLOCK) void k_norms(const void* __restrict__ x, int
   if (threadIdx.x < F) atomicAdd(&W[threadIdx.x], (double)sh[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partials,
-                                                    const float* __restrict__ scalars, double ll_scale,
-                                                    int flags, float* __restrict__ loss) {
-  __shared__ double sh[5][BLOCK / 64];
+// Reduce the forward's per-workgroup slots into partials[0..4] and form the loss triple.  Called by
+// all BLOCK threads of ONE workgroup; the totals are valid in thread 0 (and in memory) afterwards.
+__device__ __forceinline__ void reduce_slots_and_loss(double* __restrict__ partials,
+                                                      const float* __restrict__ scalars, double ll_scale,
+                                                      int flags, float* __restrict__ loss, double (*sh)[BLOCK / 64],
+                                                      double (&tot)[5]) {
   const int nblk = (int)partials[7];
   double acc[5] = {0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblk; b += BLOCK) {
@@ -300,14 +304,14 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partial
     if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = acc[i];
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  double tot[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     tot[i] = 0;
     for (int w = 0; w < BLOCK / 64; ++w) tot[i] += sh[i][w];
-    partials[i] = tot[i];
   }
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) partials[i] = tot[i];
   const double m0 = scalars[1], s0 = scalars[2];
   const double kl0 = (flags & VFM_FLAG_NO_PRIOR_TERMS)
                          ? 0.0
@@ -319,6 +323,14 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partial
   loss[0] = bad ? nanv : (float)(nll + kl);
   loss[1] = bad ? nanv : (float)nll;
   loss[2] = bad ? nanv : (float)kl;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partials,
+                                                    const float* __restrict__ scalars, double ll_scale,
+                                                    int flags, float* __restrict__ loss) {
+  __shared__ double sh[5][BLOCK / 64];
+  double tot[5];
+  reduce_slots_and_loss(partials, scalars, ll_scale, flags, loss, sh, tot);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -788,6 +800,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
+  __shared__ double sh_fin[5][BLOCK / 64];
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int d = a.d;
@@ -799,9 +812,14 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   __syncthreads();
   const float gout = ADAM ? 1.0f : b.grad_out[0];
 
+  double fin[5] = {0, 0, 0, 0, 0};
+  const bool fold = b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 into this launch
+  if (blockIdx.x == 0 && fold)
+    reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
   if (blockIdx.x == 0 && tid == 0) {
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
-    const float sum_g = (float)b.partials[VFM_P_G];
+    const float sum_g = (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
+    const float sum_a = (float)(fold ? fin[VFM_P_ALPHA] : b.partials[VFM_P_ALPHA]);
     float e0 = 0.f;
     if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
     if constexpr (EPS == EPS_PHILOX) {
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     const float as0 = fabsf(s0);
     const float prior = (a.flags & VFM_FLAG_NO_PRIOR_TERMS) ? 0.f : 1.f;
     const float ga = (a.lik == VFM_LIK_NORMAL)
-                         ? gout * signf(alpha) * a.ll_scale * (float)b.partials[VFM_P_ALPHA] : 0.f;
+                         ? gout * signf(alpha) * a.ll_scale * sum_a : 0.f;
     const float gm = gout * (sum_g + prior * m0);
     const float gs = gout * signf(s0) * (e0 * sum_g + prior * (as0 - inv_sigma(as0)));
     if constexpr (ADAM) {
@@ -1123,7 +1141,8 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   memset(&a, 0, sizeof(a));
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.lik = p->likelihood;
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
-  a.ll_scale = (float)((double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1));
+  a.ll_scale_d = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
+  a.ll_scale = (float)a.ll_scale_d;
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
   a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32);
   a.x = x; a.y = y; a.entity = entity; a.bias = bias; a.inv_occ = inv_occ; a.scalars = scalars;
@@ -1237,7 +1256,7 @@ int vfm_inv_occ_f32(const int64_t* nb_occ, float* inv_occ, int64_t T, void* stre
 int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ, double* W,
                     void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!x || !inv_occ || !W) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
+  if (!W || (p->B > 0 && (!x || !inv_occ))) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);
   const int64_t n_occ = p->B * p->F;
@@ -1255,7 +1274,13 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      const float* eps_entity, const float* eps_bias, const float* eps_global,
                      float* pred, double* partials, float* sumz, float* grow, void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!x || !entity_params || !bias_params || !scalars || !pred || !partials)
+  if (!partials) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: partials is NULL");
+  hipStream_t st0 = (hipStream_t)stream;
+  if (p->B == 0) {  // empty shard (a rank without rows): zero sums, zero blocks; buffers may be NULL
+    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st0, partials, (int)VFM_N_PARTIALS);
+    return after_launch("vfm_elbo_fwd_f32");
+  }
+  if (!x || !entity_params || !bias_params || !scalars || !pred)
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: NULL pointer");
   const bool train = y != nullptr;
   if (train && (!inv_occ || !W || !sumz || !grow))
@@ -1265,10 +1290,6 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
   if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   hipStream_t st = (hipStream_t)stream;
-  if (p->B == 0) {  // empty shard: zero sums, zero blocks
-    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, partials, (int)VFM_N_PARTIALS);
-    return after_launch("vfm_elbo_fwd_f32");
-  }
   KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
   FwdOut o{pred, partials, sumz, grow};
@@ -1296,15 +1317,15 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
                      const float* grad_out, float* g_entity, float* g_bias, float* g_scalars,
                      void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!occ_ptr || !occ_rows || !entity_params || !bias_params || !inv_occ || !scalars || !W ||
-      !sumz || !grow || !partials || !grad_out || !g_entity || !g_bias || !g_scalars)
+  if (!occ_ptr || !entity_params || !bias_params || !inv_occ || !scalars || !W || !partials || !grad_out ||
+      !g_entity || !g_bias || !g_scalars || (p->B > 0 && (!occ_rows || !sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_f32: NULL pointer");
   int eps;
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, grad_out, g_entity, g_bias, g_scalars};
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias, g_scalars, nullptr};
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
   Shape s;
@@ -1317,14 +1338,15 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
                           float* entity_params, float* bias_params, float* scalars,
                           const float* inv_occ, const double* W,
                           const float* eps_entity, const float* eps_bias, const float* eps_global,
-                          const float* sumz, const float* grow, const double* partials,
+                          const float* sumz, const float* grow, double* partials,
                           float* m_entity, float* v_entity, float* m_bias, float* v_bias,
                           float* m_scalars, float* v_scalars,
-                          float lr, float beta1, float beta2, float eps_adam, int64_t step, void* stream) {
+                          float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                          void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!occ_ptr || !occ_rows || !entity_params || !bias_params || !inv_occ || !scalars || !W ||
-      !sumz || !grow || !partials || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
-      !v_scalars || step < 1)
+  if (!occ_ptr || !entity_params || !bias_params || !inv_occ || !scalars || !W || !partials || !m_entity ||
+      !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1 ||
+      (p->B > 0 && (!occ_rows || !sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: bad argument");
   if (p->flags & VFM_FLAG_NO_PRIOR_TERMS)
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: single-rank only (gradients never leave the kernel)");
@@ -1333,7 +1355,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr};
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss};
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;

@@ -297,17 +297,17 @@ class VFM(nn.Module):
                               train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
         mark("fwd")
-        ops.elbo_finalize(st, scal, out=loss3)
-        mark("finalize")
         if fused is None:
             fused = self.fuse_adam
         if fused and adam and process_group is None:
-            # backward + dense Adam in ONE kernel: the gradient rows never reach HBM
+            # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
             self._adam_t += 1
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                   self._views(self._adam_v), lr, self._adam_t)
+                                   self._views(self._adam_v), lr, self._adam_t, loss_out=loss3)
             mark("bwd_adam")
             return loss3, st.pred
+        ops.elbo_finalize(st, scal, out=loss3)
+        mark("finalize")
         ops.elbo_backward(plan, st, ent, bia, scal, self.inv_occ, self._gout, g_ent, g_bias, g_scal)
         mark("bwd")
         if process_group is not None:
@@ -322,11 +322,15 @@ class VFM(nn.Module):
 
     def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,
             y_test=None, display_every: int = 1, lr: Optional[float] = None, verbose: bool = True,
-            process_group=None):
+            process_group=None, sort_within_batch: bool = True):
         """The training loop of vfm-torch.py:337-422: sequential batches without shuffling
         (:121-122), lr = 1/(1 + nb_train // batch_size) (:92), dense Adam, per-epoch train metrics,
         `save_weights()` each epoch for 'reg' (:380), test metrics every `display_every` epochs.
         With a process group, every batch is split in contiguous row blocks over the ranks.
+        `sort_within_batch`: reorder the rows INSIDE each batch by the id of the last column (items)
+        once, before training -- the batch composition, the loss and the gradients are unchanged
+        (they are sums over the batch's rows), but rows sharing an item become neighbours, so the
+        forward gather re-reads item rows from L2 instead of HBM.
         Returns a history dict (lists per evaluated epoch)."""
         X_train = torch.as_tensor(X_train)
         y_train = torch.as_tensor(y_train, dtype=torch.float32)
@@ -337,6 +341,8 @@ class VFM(nn.Module):
         rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
         Xd = X_train.to(self.device)
         yd = y_train.to(self.device)
+        if sort_within_batch:
+            Xd, yd = sort_rows_within_batches(Xd, yd, batch_size)
         plans, spans = [], []
         for lo in range(0, nb_train, batch_size):
             hi = min(lo + batch_size, nb_train)
@@ -412,6 +418,14 @@ class VFM(nn.Module):
                     "rmse_of_last": rm(out["y_pred_of_last"]), "rmse_of_mean": rm(out["y_pred_of_mean"])}
         auc, ap = _auc_map(y, out["y_pred"])
         return {"auc": auc, "map": ap}
+
+
+def sort_rows_within_batches(X, y, batch_size):
+    """Stable sort of the rows of every batch window [lo, lo+batch_size) by the last id column."""
+    n = X.shape[0]
+    key = X[:, -1].to(torch.int64) + (torch.arange(n, device=X.device) // batch_size) * (int(X.max()) + 1)
+    order = torch.argsort(key, stable=True)
+    return X[order].contiguous(), y[order].contiguous()
 
 
 def _auc_map(y, p):

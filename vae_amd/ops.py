@@ -1,5 +1,8 @@
 """Host-side operators over the C ABI (include/vfm_hip.h).  Device memory, streams and
 autograd come from PyTorch-ROCm; all arithmetic of the hot path runs in the HIP kernels.
+The per-step entry points are called through `torch.ops.vfm_hip.*` (the TORCH_LIBRARY shim
+`csrc/vfm_torch_ops.cpp`, which forwards raw pointers + the current HIP stream to the C ABI); the
+once-per-dataset helpers and the tests of the raw ABI use ctypes on the same library.
 
 `BatchPlan`  -- everything about one batch that does not depend on the parameters: the ids,
                targets, the batch normalisers W (vfm-torch.py:305-306) and the inverted index
@@ -23,6 +26,7 @@ from ._lib import Problem, check, ptr, current_stream_ptr
 
 FLAG_NO_PRIOR_TERMS = 1
 FLAG_EPS_ZERO = 2
+_I63 = (1 << 63) - 1
 
 
 @dataclass
@@ -156,21 +160,18 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
         grow = out_grow if out_grow is not None else torch.empty(B, dtype=torch.float32, device=dev)
     p = _problem(spec, B, plan.B_global, plan.id_bits, seed, step, flags)
     e = eps if eps is not None else (None, None, None)
-    lib = _lib.load()
-    check(lib.vfm_elbo_fwd_f32(C.byref(p), ptr(plan.x), ptr(plan.y), ptr(entity_params), ptr(bias_params),
-                               ptr(inv_occ) if have_y else None, ptr(scalars),
-                               ptr(plan.W) if have_y else None, ptr(e[0]), ptr(e[1]), ptr(e[2]),
-                               ptr(pred), ptr(partials), ptr(sumz), ptr(grow), current_stream_ptr(dev)),
-          "vfm_elbo_fwd_f32")
+    _lib.ops().elbo_fwd(plan.x, plan.y, entity_params, bias_params, inv_occ if have_y else None, scalars,
+                        plan.W if have_y else None, e[0], e[1], e[2], pred, partials, sumz, grow,
+                        list(spec.group_hi), list(spec.group_n), spec.nb_train, plan.B_global,
+                        spec.likelihood, flags, p.seed & _I63, p.step)
     return FwdState(pred, partials, sumz, grow, p, eps)
 
 
 def elbo_finalize(st: FwdState, scalars, out=None) -> torch.Tensor:
     """loss[3] = (loss, likelihood term, KL term) from (rank-summed) partials."""
     loss = out if out is not None else torch.empty(3, dtype=torch.float32, device=scalars.device)
-    lib = _lib.load()
-    check(lib.vfm_elbo_finalize_f32(C.byref(st.problem), ptr(st.partials), ptr(scalars), ptr(loss),
-                                    current_stream_ptr(scalars.device)), "vfm_elbo_finalize_f32")
+    p = st.problem
+    _lib.ops().elbo_finalize(st.partials, scalars, loss, p.nb_train, p.B_global, p.flags)
     return loss
 
 
@@ -187,38 +188,35 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
     if g_scalars is None:
         g_scalars = torch.empty(3, dtype=torch.float32, device=dev)
     e = st.eps if st.eps is not None else (None, None, None)
-    lib = _lib.load()
-    check(lib.vfm_elbo_bwd_f32(C.byref(st.problem), ptr(plan.occ_ptr), ptr(plan.occ_rows),
-                               ptr(entity_params), ptr(bias_params), ptr(inv_occ), ptr(scalars),
-                               ptr(plan.W), ptr(e[0]), ptr(e[1]), ptr(e[2]), ptr(st.sumz), ptr(st.grow),
-                               ptr(st.partials), ptr(grad_out), ptr(g_entity), ptr(g_bias),
-                               ptr(g_scalars), current_stream_ptr(dev)), "vfm_elbo_bwd_f32")
+    p, spec = st.problem, plan.spec
+    _lib.ops().elbo_bwd(plan.occ_ptr, plan.occ_rows, entity_params, bias_params, inv_occ, scalars, plan.W,
+                        e[0], e[1], e[2], st.sumz, st.grow, st.partials, grad_out, g_entity, g_bias, g_scalars,
+                        spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
+                        p.flags, p.seed & _I63, p.step)
     return g_entity, g_bias, g_scalars
 
 
 def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
-                       m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8):
+                       m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None):
     """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
-    m_views / v_views = (entity, bias, scalars) moment tensors."""
+    m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
+    work of elbo_finalize in the same launch."""
     if plan.occ_ptr is None:
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
-    lib = _lib.load()
-    check(lib.vfm_elbo_bwd_adam_f32(
-        C.byref(st.problem), ptr(plan.occ_ptr), ptr(plan.occ_rows), ptr(entity_params), ptr(bias_params),
-        ptr(scalars), ptr(inv_occ), ptr(plan.W), ptr(e[0]), ptr(e[1]), ptr(e[2]), ptr(st.sumz),
-        ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
-        ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step),
-        current_stream_ptr(plan.x.device)), "vfm_elbo_bwd_adam_f32")
+    p, spec = st.problem, plan.spec
+    _lib.ops().elbo_bwd_adam(plan.occ_ptr, plan.occ_rows, entity_params, bias_params, scalars, inv_occ, plan.W,
+                             e[0], e[1], e[2], st.sumz, st.grow, st.partials, m_views[0], v_views[0],
+                             m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
+                             list(spec.group_n), p.nb_train, p.B_global, p.likelihood, p.flags,
+                             p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out)
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     """In-place dense Adam (torch.optim.Adam defaults, vfm-torch.py:339,370) on one flat tensor."""
     for t in (p, g, m, v):
         _need_cuda(t, "adam tensor")
-    lib = _lib.load()
-    check(lib.vfm_adam_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, int(step),
-                           current_stream_ptr(p.device)), "vfm_adam_f32")
+    _lib.ops().adam(p, g, m, v, lr, beta1, beta2, eps, int(step))
 
 
 def philox_eps(spec: Spec, seed: int, step: int, device):
