@@ -64,12 +64,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("VFM_BENCH_BACKEND", "nccl")    # nccl = RCCL; "gloo" only to rehearse on one GPU
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     from vae_amd.model import VFM

@@ -47,6 +47,9 @@ extern "C" {
                                      rows -- KL(q(w0)||N(0,1)) in the loss and its gradient wrt
                                      global_bias_mean/scale -- so that SUMMING loss and scalar
                                      gradients over ranks counts them exactly once                */
+#define VFM_FLAG_SPARSE_ADAM 4    /* vfm_elbo_bwd_adam_f32 only, OPT-IN, changes results: rows that are not
+                                     in the batch are skipped (no momentum drift), unlike the reference's
+                                     dense Adam (vfm-torch.py:339); bias corrections use the global step   */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 

@@ -210,3 +210,39 @@ def test_sort_within_batch_keeps_batches_and_results():
         res.append((h["elbo"], m._flat.clone()))
     assert abs(res[0][0][-1] - res[1][0][-1]) / abs(res[0][0][-1]) < 1e-4
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-3)
+
+
+def test_sparse_adam_opt_in_touches_only_batch_rows():
+    dev = torch.device("cuda:0")
+    c = Case("ml100k_reg_d20")
+    dense, sparse = _model_from_case(c, dev), _model_from_case(c, dev)
+    sparse.sparse_adam = True
+    plan_d = dense.plan(torch.tensor(c.x), torch.tensor(c.y))
+    plan_s = sparse.plan(torch.tensor(c.x), torch.tensor(c.y))
+    before = dense.entity_params.weight.detach().clone()
+    for _ in range(2):
+        dense.train_step(plan_d, lr=0.1, eps=_eps(c, dev))
+        sparse.train_step(plan_s, lr=0.1, eps=_eps(c, dev))
+    touched = torch.zeros(c.T, dtype=torch.bool, device=dev)
+    touched[torch.tensor(c.uniq, device=dev)] = True
+    # rows of the batch: identical updates in both modes; other rows: frozen in sparse mode
+    assert torch.allclose(dense.entity_params.weight[touched], sparse.entity_params.weight[touched], rtol=1e-4, atol=1e-5)
+    assert torch.equal(sparse.entity_params.weight[~touched], before[~touched])
+    assert torch.equal(dense.entity_params.weight[~touched], before[~touched])   # zero grads, zero moments: no drift yet
+
+
+def test_predict_samples_mean_and_variance():
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    torch.manual_seed(0)
+    X, y = synthetic_triples([100, 150], 3000, seed=8)
+    m = VFM(100, 150, 8, device="cuda", rng_seed=3)
+    with torch.no_grad():
+        m.entity_params.weight[:, 8:] *= 0.1         # small posterior scales -> small predictive variance
+        m.bias_params.weight[:, 1] *= 0.1
+        m.global_bias_scale.fill_(0.05)
+    out = m.predict_samples(X[:500], n_samples=64)
+    det = m(X[:500], sample=False)[0].mean.reshape(-1)
+    assert out["logits_var"].min() >= 0 and out["logits_var"].mean() < 1.0
+    # the sample mean approaches the deterministic prediction from the posterior means
+    assert (out["logits_mean"] - det).abs().mean() < 4 * (out["logits_var"].mean() / 64).sqrt() + 0.05

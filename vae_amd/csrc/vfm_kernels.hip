@@ -859,6 +859,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
     float* grow_e = ADAM ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
     const bool touched = beg != end;
+    if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
 
     // loads that do not depend on the index chain
     Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
@@ -1202,6 +1203,8 @@ int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& 
   if (eps == EPS_TABLE && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 0>(a, b, ad, st);
   if (eps == EPS_PHILOX && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 2>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 2>(a, b, ad, st);
   return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
 }
 
@@ -1360,7 +1363,8 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(s, eps, 1, a, b, ad, (hipStream_t)stream)) return rc;
+  if (int rc = dispatch_bwd(s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
+    return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");
 }
 

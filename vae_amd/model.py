@@ -61,7 +61,7 @@ class VFM(nn.Module):
 
     def __init__(self, N: Optional[int] = None, M: Optional[int] = None, embedding_size: int = 20,
                  output: str = "reg", field_sizes: Optional[Sequence[int]] = None,
-                 quirk_le_N: bool = True, device="cuda", rng_seed: int = 0):
+                 quirk_le_N: bool = True, device="cuda", rng_seed: int = 0, sparse_adam: bool = False):
         super().__init__()
         if field_sizes is None:
             if N is None or M is None:
@@ -83,6 +83,9 @@ class VFM(nn.Module):
         self.rng_seed = int(rng_seed)
         self.global_step = 0
         self.fuse_adam = True      # single-rank train_step uses the fused backward+Adam kernel
+        # OPT-IN, changes results: Adam only on the rows of the batch (no momentum drift of the
+        # other rows); the reference's dense Adam (vfm-torch.py:339) moves every row every step
+        self.sparse_adam = bool(sparse_adam)
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
         alpha = torch.rand(1)                                   # nn.init.uniform_ (:145)
@@ -303,7 +306,8 @@ class VFM(nn.Module):
             # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
             self._adam_t += 1
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                   self._views(self._adam_v), lr, self._adam_t, loss_out=loss3)
+                                   self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
+                                   sparse=self.sparse_adam)
             mark("bwd_adam")
             return loss3, st.pred
         ops.elbo_finalize(st, scal, out=loss3)
@@ -406,6 +410,31 @@ class VFM(nn.Module):
         self._all_preds_n += 1
         return {"y_pred": y_pred, "mean_pred": self._all_preds_sum / self._all_preds_n,
                 "y_pred_of_last": last, "y_pred_of_mean": mean}
+
+    @torch.no_grad()
+    def predict_samples(self, X, n_samples: int = 10):
+        """Posterior-predictive mean and variance of the prediction over `n_samples` fresh posterior
+        samples (the quantity the paper's preference-elicitation use case consumes: mean + logit
+        variance, cf. vfm.py:1024-1057).  Each sample is one forward launch with its own Philox step.
+        Returns dict(mean, var, logits_mean, logits_var); 'reg': mean == logits_mean."""
+        plan = self.plan(X, None)
+        ent, bia, scal = self._views(self._flat)
+        n = 0
+        mean = torch.zeros(plan.B, dtype=torch.float32, device=self.device)
+        m2 = torch.zeros_like(mean)
+        pmean = torch.zeros_like(mean)
+        for _ in range(int(n_samples)):
+            step = self.global_step
+            self.global_step += 1
+            logit = ops.elbo_forward(plan, ent, bia, scal, None, seed=self.rng_seed, step=step, train=False).pred
+            n += 1
+            delta = logit - mean
+            mean += delta / n
+            m2 += delta * (logit - mean)
+            pmean += (logit if self.output == "reg" else torch.sigmoid(logit) - pmean * 0) / 1
+        var = m2 / max(n - 1, 1)
+        pm = pmean / n
+        return {"mean": pm, "var": var if self.output == "reg" else None, "logits_mean": mean, "logits_var": var}
 
     @torch.no_grad()
     def evaluate(self, X_test, y_test):

@@ -26,6 +26,7 @@ from ._lib import Problem, check, ptr, current_stream_ptr
 
 FLAG_NO_PRIOR_TERMS = 1
 FLAG_EPS_ZERO = 2
+FLAG_SPARSE_ADAM = 4
 _I63 = (1 << 63) - 1
 
 
@@ -197,7 +198,8 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
 
 
 def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
-                       m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None):
+                       m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None,
+                       sparse=False):
     """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
     m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
     work of elbo_finalize in the same launch."""
@@ -208,7 +210,8 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
     _lib.ops().elbo_bwd_adam(plan.occ_ptr, plan.occ_rows, entity_params, bias_params, scalars, inv_occ, plan.W,
                              e[0], e[1], e[2], st.sumz, st.grow, st.partials, m_views[0], v_views[0],
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
-                             list(spec.group_n), p.nb_train, p.B_global, p.likelihood, p.flags,
+                             list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
+                             p.flags | (FLAG_SPARSE_ADAM if sparse else 0),
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out)
 
 
