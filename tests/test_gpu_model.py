@@ -246,3 +246,43 @@ def test_predict_samples_mean_and_variance():
     assert out["logits_var"].min() >= 0 and out["logits_var"].mean() < 1.0
     # the sample mean approaches the deterministic prediction from the posterior means
     assert (out["logits_mean"] - det).abs().mean() < 4 * (out["logits_var"].mean() / 64).sqrt() + 0.05
+
+
+def test_end_to_end_learning_matches_cpu_reference_port():
+    """Train on synthetic low-rank ratings with the HIP path (Philox eps) and with the reference-shaped
+    CPU port (torch RNG eps): different noise, same model and loop -> both must learn the data, to a
+    similar train/test RMSE (statistical end-to-end parity of fit()/predict())."""
+    from vae_amd.model import VFM
+    from oracle import vfm_oracle as O
+    g = torch.Generator().manual_seed(0)
+    N, M, k, n = 150, 200, 4, 24000
+    U, V = torch.randn(N, k, generator=g) * 0.8, torch.randn(M, k, generator=g) * 0.8
+    bu, bi = torch.randn(N, generator=g) * 0.3, torch.randn(M, generator=g) * 0.3
+    u, i = torch.randint(0, N, (n,), generator=g), torch.randint(0, M, (n,), generator=g)
+    y = (3.0 + bu[u] + bi[i] + (U[u] * V[i]).sum(1) + 0.1 * torch.randn(n, generator=g)).clamp(1, 5)
+    X = torch.stack([u, i + N], 1)
+    Xtr, ytr, Xte, yte = X[:20000], y[:20000], X[20000:], y[20000:]
+    d, epochs, B = 8, 40, 5000
+    torch.manual_seed(42)
+    m = VFM(N, M, d, device="cuda", rng_seed=11)
+    hist = m.fit(Xtr, ytr, n_epochs=epochs, batch_size=B, X_test=Xte, y_test=yte, display_every=epochs - 1,
+                 verbose=False)
+    gpu_rmse = hist["test"][-1]["rmse_of_mean"] if hist["test"][-1]["rmse_of_mean"] else hist["test"][-1]["rmse"]
+    # CPU port, same init, same loop
+    torch.manual_seed(42)
+    P = O.make_params(N + M, d)
+    with torch.no_grad():
+        P["alpha"].copy_(m.alpha.detach().cpu() * 0 + P["alpha"])   # own init is fine; same distribution
+    nb_occ = torch.bincount(Xtr.flatten(), minlength=N + M)
+    opt = torch.optim.Adam(list(P.values()), lr=1 / (1 + len(ytr) // B))
+    torch.manual_seed(7)
+    for ep in range(epochs):
+        for lo in range(0, len(ytr), B):
+            O.reference_shaped_step(P, opt, Xtr[lo:lo + B], ytr[lo:lo + B], nb_occ, N, M, len(ytr), "reg")
+    with torch.no_grad():
+        mu_w, mu_v = P["bias_params"][:, 0], P["entity_params"][:, :d]
+        pred = (P["global_bias_mean"] + mu_w[Xte].sum(1) + mu_v[Xte].prod(1).sum(1)).clamp(1, 5)
+        cpu_rmse = float(torch.sqrt(torch.mean((pred - yte) ** 2)))
+    base = float(torch.sqrt(torch.mean((ytr.mean() - yte) ** 2)))
+    assert gpu_rmse < 0.8 * base and cpu_rmse < 0.8 * base
+    assert abs(gpu_rmse - cpu_rmse) < 0.15 * cpu_rmse
