@@ -172,10 +172,16 @@ def main():
         alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
                "allreduce": 4.0 * n_params,
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
-               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params}
+               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params,
+               # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
+               "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
+               "apply_adam": 4.0 * model.T * (d + 2) + 24.0 * n_params}
+        alg["allreduce"] = 4.0 * model.T * (d + 2) if "bwd_acc" in acc else 4.0 * n_params
         names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
-                 "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat gradient"}
+                 "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
+                 "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
+                 "apply_adam": "k_bwd<APPLY,ADAM> (epilogue + dense Adam from global statistics)"}
         for k, ms in acc.items():
             us = ms / len(events) * 1e3
             gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0
@@ -220,7 +226,7 @@ def main():
                        "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
-                       "step": ("fwd+loss+bwd+" + ("allreduce+" if world > 1 else "") + "dense-adam") if
+                       "step": ("fwd+loss+bwd_acc+allreduce(stats)+apply_adam" if world > 1 else "fwd+loss+bwd+dense-adam") if
                                (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
                        "parallelism": f"row-sharded dp{world}"},
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,

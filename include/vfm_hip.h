@@ -168,6 +168,26 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
                           float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
                           void* stream);
 
+/* Multi-rank form of the backward (row-sharded batch): instead of the [T,2d] gradient, the ranks
+ * exchange its SUFFICIENT STATISTICS, which are sums over batch rows and half the size:
+ *   acc_a [T,d] : A_e = sum_{r in shard, r contains e} grow_r * sumz_r
+ *   acc_g [T,2] : (sum of grow_r over those rows, number of occurrences of e)
+ *   sums  [2]   : (sum_r grow_r, alpha term) of the shard -- from the finalised `partials`
+ * vfm_elbo_bwd_acc_f32 writes them (dense, zeros for entities not in the shard).  The caller sums
+ * acc_a, acc_g, sums over ranks (ONE all-reduce of a flat buffer holding all three), then every rank
+ * calls vfm_elbo_apply_adam_f32: gradient epilogue (eps regeneration, KL part, |.| link) + dense Adam
+ * from the global statistics -- the replicas stay identical.  No VFM_FLAG_NO_PRIOR_TERMS here: the
+ * row-independent terms are added once from the global sums. */
+int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+                         const float* sumz, const float* grow, const double* partials, float* acc_a,
+                         float* acc_g, float* sums, void* stream);
+int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc_a, const float* acc_g, const float* sums,
+                            float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
+                            const double* W, const float* eps_entity, const float* eps_bias,
+                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
+                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
+                            float beta2, float eps_adam, int64_t step, void* stream);
+
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of
  * this update (bias corrections are formed on the host in fp64).  In place on p, m, v; all four

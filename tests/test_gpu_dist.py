@@ -30,7 +30,7 @@ def _make_model(c, dev):
     return m
 
 
-def _worker(rank, world, port, name, out_dir):
+def _worker(rank, world, port, name, out_dir, exchange="stats"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,6 +38,7 @@ def _worker(rank, world, port, name, out_dir):
     dev = torch.device("cuda:0")
     c = Case(name)
     m = _make_model(c, dev)
+    m.exchange = exchange
     B = len(c.y)
     losses = []
     for step in range(3):
@@ -51,10 +52,11 @@ def _worker(rank, world, port, name, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["stats", "grads"])
 @pytest.mark.parametrize("name", ["ml100k_reg_d20"])
-def test_two_ranks_match_one_rank(name, tmp_path):
+def test_two_ranks_match_one_rank(name, exchange, tmp_path):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), exchange), nprocs=world, join=True)
     c = Case(name)
     dev = torch.device("cuda:0")
     m = _make_model(c, dev)

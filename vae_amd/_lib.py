@@ -27,7 +27,7 @@ LIK_NORMAL, LIK_BERNOULLI = 0, 1
 EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
-    "vfm_adam_f32", "vfm_elbo_bwd_adam_f32",
+    "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
 )
 
 
@@ -75,6 +75,9 @@ def load():
                                           [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                  i64, vp]
+    lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 9
+    lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 17 +
+                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":

@@ -155,6 +155,10 @@ struct BwdArgs {
   float* g_bias;
   float* g_scalars;
   float* loss;   // non-NULL: this launch also reduces the forward's partial slots and forms the loss
+  // staged (multi-rank) form: sufficient statistics of the gradient, exchanged instead of the gradient
+  float* accA;   // [T,d]  A_e = sum_r grow_r * sumz_r        (STAGE_ACC writes, STAGE_APPLY reads)
+  float* accG;   // [T,2]  (sum_r grow_r, number of occurrences of e)
+  float* sums;   // [2]    (sum_r grow_r over all rows, alpha term)
 };
 
 template <int VEC>
@@ -833,7 +837,9 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
   return p + (-ad.step_size * m) / denom;
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int ADAM>
+enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE>
 __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
@@ -843,21 +849,26 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   const int lig = tid % LPE;
   const int d = a.d;
   const int C = (d + VEC - 1) / VEC;
-  if (tid < a.G) {
+  if (STAGE != STAGE_ACC && tid < a.G) {
     sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   __syncthreads();
-  const float gout = ADAM ? 1.0f : b.grad_out[0];
+  const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
 
   double fin[5] = {0, 0, 0, 0, 0};
-  const bool fold = b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 into this launch
+  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
-  if (blockIdx.x == 0 && tid == 0) {
+  if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0) {
+    b.sums[0] = (float)b.partials[VFM_P_G];       // this rank's row sums, to be summed over ranks
+    b.sums[1] = (float)b.partials[VFM_P_ALPHA];
+  }
+  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0) {
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
-    const float sum_g = (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
-    const float sum_a = (float)(fold ? fin[VFM_P_ALPHA] : b.partials[VFM_P_ALPHA]);
+    const float sum_g = (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
+    const float sum_a = (STAGE == STAGE_APPLY) ? b.sums[1]
+                                               : (float)(fold ? fin[VFM_P_ALPHA] : b.partials[VFM_P_ALPHA]);
     float e0 = 0.f;
     if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
     if constexpr (EPS == EPS_PHILOX) {
@@ -889,21 +900,28 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   const int64_t stride = (int64_t)gridDim.x * GPB;
   int64_t e = (int64_t)blockIdx.x * GPB + tid / LPE;
   int2 pq = make_int2(0, 0);
-  if (e < a.T) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
+  if (STAGE != STAGE_APPLY && e < a.T) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
   for (; e < a.T; e += stride) {
-    const int beg = pq.x, end = pq.y;
+    int beg = pq.x, end = pq.y;
     const int64_t en = e + stride;
-    if (en < a.T) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+    float2 gc = make_float2(0.f, 0.f);
+    if constexpr (STAGE == STAGE_APPLY) {
+      gc = *reinterpret_cast<const float2*>(b.accG + 2 * (size_t)e);   // (sum of grow, occurrences) over ALL ranks
+      beg = 0; end = 0;
+    } else {
+      if (en < a.T) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+    }
     float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
-    float* grow_e = ADAM ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
-    const bool touched = beg != end;
+    float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
+    const bool touched = (STAGE == STAGE_APPLY) ? gc.y > 0.f : beg != end;
+    const float cntf = (STAGE == STAGE_APPLY) ? gc.y : (float)(end - beg);
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
 
     // loads that do not depend on the index chain
     Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
     float2 th = make_float2(0.f, 1.f), mb = make_float2(0.f, 0.f), vb = make_float2(0.f, 0.f);
     float io = 0.f, epw = 0.f;
-    if (ADAM || touched) {
+    if (STAGE != STAGE_ACC && (ADAM || touched)) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
         const int j = lig + i * LPE;
@@ -970,6 +988,26 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       }
     }
 
+    if constexpr (STAGE == STAGE_ACC) {   // store the statistics (dense: zeros for rows not in this shard)
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) st_chunk<VEC>(b.accA + (size_t)e * d + (size_t)j * VEC, A[i]);
+      }
+      if (lig == 0) *reinterpret_cast<float2*>(b.accG + 2 * (size_t)e) = make_float2(gs, cntf);
+      continue;
+    }
+    if constexpr (STAGE == STAGE_APPLY) {
+      gs = gc.x;
+      if (touched) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) A[i] = ld_chunk<VEC>(b.accA + (size_t)e * d + (size_t)j * VEC);
+        }
+      }
+    }
+
     if (!touched && !ADAM) {   // entity not in the batch: dense zero row
       Chunk<VEC> zc;
 #pragma unroll
@@ -990,7 +1028,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     if (touched) {
       const int64_t lo = 0;
       (void)lo;
-      c = sh_cs[group_index(sh_hi, a.G, e)] * io * (float)(end - beg);
+      c = sh_cs[group_index(sh_hi, a.G, e)] * io * cntf;
     }
     float nb_eps = 0.f;
 #pragma unroll
@@ -1224,14 +1262,14 @@ int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream
   return fail(VFM_E_UNSUPPORTED, "forward: unsupported eps source / mode combination");
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int ADAM>
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
 int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
   const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
   int64_t nb = (a.T + GPB - 1) / GPB;
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
-  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
   return 0;
 }
 
@@ -1243,6 +1281,9 @@ int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& 
   if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
   if (eps == EPS_PHILOX && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 2>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 2>(a, b, ad, st);
+  if (adam == 10) return launch_bwd_t<LPE, CPL, VEC, EPS_ZERO, 0, STAGE_ACC>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1, STAGE_APPLY>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1, STAGE_APPLY>(a, b, ad, st);
   return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
 }
 
@@ -1366,7 +1407,8 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias, g_scalars, nullptr};
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias, g_scalars, nullptr,
+            nullptr, nullptr, nullptr};
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
   Shape s;
@@ -1396,7 +1438,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss};
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr, nullptr, nullptr};
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
@@ -1404,6 +1446,48 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
   if (int rc = dispatch_bwd(s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
     return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");
+}
+
+int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+                         const float* sumz, const float* grow, const double* partials, float* acc_a,
+                         float* acc_g, float* sums, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (!occ_ptr || !partials || !acc_a || !acc_g || !sums || (p->B > 0 && (!occ_rows || !sumz || !grow)))
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
+  KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr, nullptr, nullptr,
+            acc_a, acc_g, sums};
+  AdamArgs ad;
+  memset(&ad, 0, sizeof(ad));
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = dispatch_bwd(s, EPS_ZERO, 10, a, b, ad, (hipStream_t)stream)) return rc;
+  return after_launch("vfm_elbo_bwd_acc_f32");
+}
+
+int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc_a, const float* acc_g, const float* sums,
+                            float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
+                            const double* W, const float* eps_entity, const float* eps_bias,
+                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
+                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
+                            float beta2, float eps_adam, int64_t step, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (!acc_a || !acc_g || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
+      !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
+    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: bad argument");
+  int eps;
+  if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
+  if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_apply_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
+                      eps_global);
+  BwdArgs b{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+            const_cast<float*>(acc_a), const_cast<float*>(acc_g), const_cast<float*>(sums)};
+  AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
+  adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = dispatch_bwd(s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
+  return after_launch("vfm_elbo_apply_adam_f32");
 }
 
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -86,6 +86,10 @@ class VFM(nn.Module):
         # OPT-IN, changes results: Adam only on the rows of the batch (no momentum drift of the
         # other rows); the reference's dense Adam (vfm-torch.py:339) moves every row every step
         self.sparse_adam = bool(sparse_adam)
+        # what the ranks exchange per step when a process group is given: "stats" = sufficient
+        # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
+        self.exchange = "stats"
+        self._xflat = None
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
         alpha = torch.rand(1)                                   # nn.init.uniform_ (:145)
@@ -264,6 +268,16 @@ class VFM(nn.Module):
             self._partials = torch.zeros(_lib.PARTIALS_LEN, dtype=torch.float64, device=self.device)
             self._state_bufs = {}
 
+    def _xviews(self):
+        """Flat exchange buffer [A: T*d | (sum grow, count): 2T | row sums: 2 | loss: 3 | pad]."""
+        n_a = _round4(self.T * self.d)
+        n_g = _round4(2 * self.T)
+        if self._xflat is None:
+            self._xflat = torch.zeros(n_a + n_g + 8, dtype=torch.float32, device=self.device)
+        f = self._xflat
+        return (f[: self.T * self.d].view(self.T, self.d), f[n_a: n_a + 2 * self.T].view(self.T, 2),
+                f[n_a + n_g: n_a + n_g + 2], f[n_a + n_g + 4: n_a + n_g + 7])
+
     def _step_buffers(self, B):
         """Persistent per-step training state (sumz [B,d], grow [B], pred [B]) -- no allocator
         traffic inside the step."""
@@ -309,6 +323,22 @@ class VFM(nn.Module):
                                    self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
                                    sparse=self.sparse_adam)
             mark("bwd_adam")
+            return loss3, st.pred
+        if process_group is not None and adam and self.exchange == "stats":
+            # multi-rank: exchange the gradient's sufficient statistics (A_e, sum grow, count) -- half
+            # the bytes of the gradient -- in ONE all-reduce, then epilogue + Adam on every rank
+            xa, xg, xs, xl = self._xviews()
+            ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
+            mark("finalize")
+            ops.elbo_backward_acc(plan, st, xa, xg, xs)
+            mark("bwd_acc")
+            allreduce_flat(self._xflat, process_group)
+            mark("allreduce")
+            self._adam_t += 1
+            ops.elbo_apply_adam(plan, st, xa, xg, xs, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                self._views(self._adam_v), lr, self._adam_t)
+            mark("apply_adam")
+            loss3.copy_(xl)
             return loss3, st.pred
         ops.elbo_finalize(st, scal, out=loss3)
         mark("finalize")
