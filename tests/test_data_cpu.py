@@ -1,0 +1,90 @@
+"""CPU: the data loaders keep the reference's conventions (prepare.py:10-64) and the product package
+never touches the oracle."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from vae_amd import data as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_dataset(root, name="toy", shifted=True):
+    path = root / name
+    path.mkdir(parents=True)
+    g = np.random.default_rng(0)
+    n, N, M = 60, 7, 5
+    df = pd.DataFrame({"user": g.integers(0, N, n), "item": g.integers(0, M, n), "rating": g.integers(1, 6, n)})
+    df.loc[:N - 1, "user"] = np.arange(N)          # every user / item present
+    df.loc[:M - 1, "item"] = np.arange(M)
+    if shifted:
+        df["shifted_item"] = df["item"] + N
+    df["outcome"] = (df["rating"] >= 4).astype(int)
+    df.to_csv(path / "data.csv", index=False)
+    idx = g.permutation(n)
+    pd.DataFrame({"index": idx[:45]}).to_csv(path / "trainval.csv", index=False)
+    pd.DataFrame({"index": idx[45:]}).to_csv(path / "test.csv", index=False)
+    return df, idx, N, M
+
+
+def test_load_data_contract(tmp_path):
+    df, idx, N, M = _write_dataset(tmp_path)
+    n, m, Xtr, Xte, ytr, yte, i = D.load_data("toy", "reg", root=tmp_path)
+    assert (n, m) == (N, M) and Xtr.shape == (45, 2) and Xte.shape == (15, 2)
+    assert i["trainval"] == idx[:45].tolist() and i["test"] == idx[45:].tolist()
+    assert np.array_equal(Xtr[:, 0], df.loc[idx[:45], "user"]) and np.array_equal(Xtr[:, 1], df.loc[idx[:45], "item"] + N)
+    assert np.array_equal(ytr, df.loc[idx[:45], "rating"])
+    _, _, _, _, yc, _, _ = D.load_data("toy", "class", root=tmp_path)
+    assert set(np.unique(yc)) <= {0, 1}
+
+
+def test_load_data_falls_back_to_unshifted_item(tmp_path):
+    """prepare.py:20-21: without a `shifted_item` column the unshifted item id is used."""
+    df, idx, N, M = _write_dataset(tmp_path, shifted=False)
+    _, _, Xtr, _, _, _, _ = D.load_data("toy", "reg", root=tmp_path)
+    assert np.array_equal(Xtr[:, 1], df.loc[idx[:45], "item"])
+
+
+def test_prepare_data_reindexes_and_exports_libfm(tmp_path):
+    df, idx, N, M = _write_dataset(tmp_path, shifted=False)
+    raw = pd.read_csv(tmp_path / "toy" / "data.csv")
+    raw["user"] = raw["user"] * 10 + 3                  # non-contiguous raw ids
+    raw.drop(columns=["outcome"]).to_csv(tmp_path / "toy" / "data.csv", index=False)
+    out = D.prepare_data("toy", False, root=tmp_path)
+    assert out["user"].max() == N - 1 and (out["shifted_item"] == out["item"] + N).all()
+    assert (out["outcome"] == (out["rating"] >= 4).astype(int)).all()
+    lines = open(tmp_path / "toy" / "toy.trainval_libfm").read().splitlines()
+    assert len(lines) == 45 and re.fullmatch(r"\d+ \d+:1 \d+:1", lines[0])
+    r0 = out.loc[idx[0]]
+    assert lines[0] == f"{int(r0.rating)} {int(r0.user)}:1 {int(r0.shifted_item)}:1"
+
+
+def test_load_fraction_fixture():
+    N, M, Xtr, Xte, ytr, yte = D.load_fraction(os.path.join(ROOT, "tests", "golden", "fraction"))
+    assert (N, M) == (536, 20) and len(ytr) + len(yte) <= 10720 and len(ytr) == 8576
+    assert Xtr[:, 0].max() < N and Xtr[:, 1].min() >= N and Xtr[:, 1].max() < N + M
+    assert set(np.unique(ytr)) == {0.0, 1.0}
+
+
+def test_synthetic_triples_ranges_and_determinism():
+    X, y = D.synthetic_triples([10, 20, 5], 1000, seed=3)
+    X2, y2 = D.synthetic_triples([10, 20, 5], 1000, seed=3)
+    assert (X == X2).all() and (y == y2).all()
+    assert X[:, 0].max() < 10 and X[:, 1].min() >= 10 and X[:, 1].max() < 30 and X[:, 2].min() >= 30 and X[:, 2].max() < 35
+    assert y.min() >= 1 and y.max() <= 5
+    Xz, _ = D.synthetic_triples([10, 2000], 5000, seed=1, zipf=1.1)
+    counts = np.bincount(Xz[:, 1].numpy() - 10, minlength=2000)
+    assert counts[:10].sum() > 5 * counts[-10:].sum()           # popular head
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vae_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+                assert "vfm_oracle" not in txt, f
