@@ -89,6 +89,10 @@ typedef struct vfm_problem {
    * step, shared by every row that contains it (vfm-torch.py:207-208,238-245).          */
   uint64_t seed;
   uint64_t step;
+  /* entity range [e_lo, e_hi) handled by a backward-family call (e_hi == 0: up to T).  Lets a
+   * multi-rank step cut the table in chunks and overlap the exchange of one chunk with the kernels
+   * of its neighbours.  The forward ignores it. */
+  int64_t e_lo, e_hi;
 } vfm_problem_t;
 
 int vfm_abi_version(void);
@@ -170,18 +174,20 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
 
 /* Multi-rank form of the backward (row-sharded batch): instead of the [T,2d] gradient, the ranks
  * exchange its SUFFICIENT STATISTICS, which are sums over batch rows and half the size:
- *   acc_a [T,d] : A_e = sum_{r in shard, r contains e} grow_r * sumz_r
- *   acc_g [T,2] : (sum of grow_r over those rows, number of occurrences of e)
- *   sums  [2]   : (sum_r grow_r, alpha term) of the shard -- from the finalised `partials`
+ *   acc [T, 4 + round4(d)] : one record per entity e
+ *         (sum of grow_r over the shard's rows containing e, number of occurrences of e, 0, 0,
+ *          A_e[0..d-1] = sum of grow_r * sumz_r over those rows)
+ *   sums [2] : (sum_r grow_r, alpha term) of the shard -- from the finalised `partials`
  * vfm_elbo_bwd_acc_f32 writes them (dense, zeros for entities not in the shard).  The caller sums
- * acc_a, acc_g, sums over ranks (ONE all-reduce of a flat buffer holding all three), then every rank
+ * acc and sums over ranks (one all-reduce of a flat buffer holding both, or one per entity chunk
+ * [e_lo, e_hi) to overlap communication with the neighbouring chunks' kernels), then every rank
  * calls vfm_elbo_apply_adam_f32: gradient epilogue (eps regeneration, KL part, |.| link) + dense Adam
  * from the global statistics -- the replicas stay identical.  No VFM_FLAG_NO_PRIOR_TERMS here: the
  * row-independent terms are added once from the global sums. */
 int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
-                         const float* sumz, const float* grow, const double* partials, float* acc_a,
-                         float* acc_g, float* sums, void* stream);
-int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc_a, const float* acc_g, const float* sums,
+                         const float* sumz, const float* grow, const double* partials, float* acc,
+                         float* sums, void* stream);
+int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const float* sums,
                             float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,

@@ -26,10 +26,20 @@ def test_header_symbols_are_exported():
     assert lib.vfm_abi_version() == _lib.ABI_VERSION
 
 
-def test_problem_struct_layout_matches_header():
+def test_problem_struct_layout_matches_header(tmp_path):
+    """sizeof / field offsets of the ctypes mirror == what a C compiler makes of include/vfm_hip.h."""
+    import subprocess
     from vae_amd._lib import Problem
-    # 4*8 + 6*4 + 64*8 + 64*8 + 2*8
-    assert C.sizeof(Problem) == 32 + 24 + 512 + 512 + 16
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_problem_t), offsetof(vfm_problem_t, F),'
+                   'offsetof(vfm_problem_t, group_hi), offsetof(vfm_problem_t, group_n), offsetof(vfm_problem_t, seed),'
+                   'offsetof(vfm_problem_t, e_lo));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(Problem), Problem.F.offset, Problem.group_hi.offset, Problem.group_n.offset,
+                   Problem.seed.offset, Problem.e_lo.offset]
 
 
 def test_bad_arguments_return_errors_not_crashes():

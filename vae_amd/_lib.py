@@ -38,7 +38,7 @@ class Problem(C.Structure):
         ("F", C.c_int32), ("d", C.c_int32), ("likelihood", C.c_int32), ("id_bits", C.c_int32),
         ("n_samples", C.c_int32), ("reserved", C.c_int32),
         ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
-        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
     ]
 
 
@@ -75,8 +75,8 @@ def load():
                                           [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                  i64, vp]
-    lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 9
-    lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 17 +
+    lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 8
+    lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
                                             [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     for name in EXPORTS:
         fn = getattr(lib, name)

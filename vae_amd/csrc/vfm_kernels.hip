@@ -119,6 +119,7 @@ __device__ __forceinline__ void eps_of_chunk(const RngKey& k, uint32_t e, int j,
 // ---------------------------------------------------------------------------------------
 struct KArgs {
   int64_t B, T;
+  int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
   int32_t F, d, lik, id64, G, TR, flags;
   float ll_scale;  // nb_train / B_global
   double ll_scale_d;
@@ -156,8 +157,8 @@ struct BwdArgs {
   float* g_scalars;
   float* loss;   // non-NULL: this launch also reduces the forward's partial slots and forms the loss
   // staged (multi-rank) form: sufficient statistics of the gradient, exchanged instead of the gradient
-  float* accA;   // [T,d]  A_e = sum_r grow_r * sumz_r        (STAGE_ACC writes, STAGE_APPLY reads)
-  float* accG;   // [T,2]  (sum_r grow_r, number of occurrences of e)
+  float* acc;    // [T, 4 + round4(d)] record per entity: (sum_r grow_r, occurrences, 0, 0 | A_e[0..d-1]),
+                 //   A_e = sum_r grow_r * sumz_r      (STAGE_ACC writes, STAGE_APPLY reads)
   float* sums;   // [2]    (sum_r grow_r over all rows, alpha term)
 };
 
@@ -860,11 +861,11 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   const bool fold = STAGE == STAGE_FULL && b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
-  if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0) {
+  if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_lo == 0) {
     b.sums[0] = (float)b.partials[VFM_P_G];       // this rank's row sums, to be summed over ranks
     b.sums[1] = (float)b.partials[VFM_P_ALPHA];
   }
-  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0) {
+  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T) {   // (last chunk of a chunked run)
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
     const float sum_g = (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
     const float sum_a = (STAGE == STAGE_APPLY) ? b.sums[1]
@@ -898,18 +899,19 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   }
 
   const int64_t stride = (int64_t)gridDim.x * GPB;
-  int64_t e = (int64_t)blockIdx.x * GPB + tid / LPE;
+  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);          // floats per exchange record
+  int64_t e = a.e_lo + (int64_t)blockIdx.x * GPB + tid / LPE;
   int2 pq = make_int2(0, 0);
-  if (STAGE != STAGE_APPLY && e < a.T) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
-  for (; e < a.T; e += stride) {
+  if (STAGE != STAGE_APPLY && e < a.e_hi) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
+  for (; e < a.e_hi; e += stride) {
     int beg = pq.x, end = pq.y;
     const int64_t en = e + stride;
     float2 gc = make_float2(0.f, 0.f);
     if constexpr (STAGE == STAGE_APPLY) {
-      gc = *reinterpret_cast<const float2*>(b.accG + 2 * (size_t)e);   // (sum of grow, occurrences) over ALL ranks
+      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)e * xs);   // (sum of grow, occurrences) over ALL ranks
       beg = 0; end = 0;
     } else {
-      if (en < a.T) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+      if (en < a.e_hi) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
     }
     float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
     float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
@@ -992,9 +994,9 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
         const int j = lig + i * LPE;
-        if (j < C) st_chunk<VEC>(b.accA + (size_t)e * d + (size_t)j * VEC, A[i]);
+        if (j < C) st_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC, A[i]);
       }
-      if (lig == 0) *reinterpret_cast<float2*>(b.accG + 2 * (size_t)e) = make_float2(gs, cntf);
+      if (lig == 0) *reinterpret_cast<float4*>(b.acc + (size_t)e * xs) = make_float4(gs, cntf, 0.f, 0.f);
       continue;
     }
     if constexpr (STAGE == STAGE_APPLY) {
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int j = lig + i * LPE;
-          if (j < C) A[i] = ld_chunk<VEC>(b.accA + (size_t)e * d + (size_t)j * VEC);
+          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC);
         }
       }
     }
@@ -1193,6 +1195,7 @@ int check_problem(const vfm_problem_t* p) {
   if (p->n_samples != 1) return fail(VFM_E_UNSUPPORTED, "only n_samples == 1 is supported");
   if (p->B_global < p->B) return fail(VFM_E_INVALID, "B_global < B");
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
+  if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
   Shape s;
   if (!pick_shape(p->d, &s)) return fail(VFM_E_UNSUPPORTED, "embedding size d not supported (d%4==0: d<=1024, else d<=256)");
   return 0;
@@ -1217,6 +1220,7 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   KArgs a;
   memset(&a, 0, sizeof(a));
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.lik = p->likelihood;
+  a.e_lo = p->e_lo; a.e_hi = (p->e_hi > 0 && p->e_hi < p->T) ? p->e_hi : p->T;
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
   a.ll_scale_d = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
   a.ll_scale = (float)a.ll_scale_d;
@@ -1266,9 +1270,10 @@ template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
 int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
   const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
-  int64_t nb = (a.T + GPB - 1) / GPB;
+  int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
   hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
   return 0;
 }
@@ -1408,7 +1413,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias, g_scalars, nullptr,
-            nullptr, nullptr, nullptr};
+            nullptr, nullptr};
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
   Shape s;
@@ -1438,7 +1443,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr, nullptr, nullptr};
+  BwdArgs b{occ_ptr, occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr, nullptr};
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
@@ -1449,14 +1454,14 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
 }
 
 int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
-                         const float* sumz, const float* grow, const double* partials, float* acc_a,
-                         float* acc_g, float* sums, void* stream) {
+                         const float* sumz, const float* grow, const double* partials, float* acc,
+                         float* sums, void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!occ_ptr || !partials || !acc_a || !acc_g || !sums || (p->B > 0 && (!occ_rows || !sumz || !grow)))
+  if (!occ_ptr || !partials || !acc || !sums || (p->B > 0 && (!occ_rows || !sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{occ_ptr, occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr, nullptr, nullptr,
-            acc_a, acc_g, sums};
+            acc, sums};
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
   Shape s;
@@ -1465,14 +1470,14 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const i
   return after_launch("vfm_elbo_bwd_acc_f32");
 }
 
-int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc_a, const float* acc_g, const float* sums,
+int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const float* sums,
                             float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
                             float beta2, float eps_adam, int64_t step, void* stream) {
   if (int rc = check_problem(p)) return rc;
-  if (!acc_a || !acc_g || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
+  if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: bad argument");
   int eps;
@@ -1481,7 +1486,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc_a, const fl
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
   BwdArgs b{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc_a), const_cast<float*>(acc_g), const_cast<float*>(sums)};
+            const_cast<float*>(acc), const_cast<float*>(sums)};
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;

@@ -172,44 +172,46 @@ void elbo_bwd_adam(const Tensor& occ_ptr, const Tensor& occ_rows, Tensor entity,
         "vfm_elbo_bwd_adam_f32");
 }
 
+int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
+
 void elbo_bwd_acc(const Tensor& occ_ptr, const Tensor& occ_rows, const Tensor& sumz, const Tensor& grow,
-                  const Tensor& partials, Tensor acc_a, Tensor acc_g, Tensor sums, int64_t T, int64_t F, int64_t d) {
+                  const Tensor& partials, Tensor acc, Tensor sums, int64_t T, int64_t F, int64_t d, int64_t e_lo,
+                  int64_t e_hi) {
   dev_tensor(occ_ptr, at::kInt, "occ_ptr"); dev_tensor(occ_rows, at::kInt, "occ_rows");
-  dev_tensor(acc_a, at::kFloat, "acc_a"); dev_tensor(acc_g, at::kFloat, "acc_g"); dev_tensor(sums, at::kFloat, "sums");
+  dev_tensor(acc, at::kFloat, "acc"); dev_tensor(sums, at::kFloat, "sums");
   const int64_t B = grow.numel();
-  TORCH_CHECK(occ_ptr.numel() == T + 1 && occ_rows.numel() == B * F && acc_a.numel() >= T * d &&
-              acc_g.numel() >= 2 * T && sums.numel() >= 2, "bwd_acc sizes");
-  c10::hip::HIPGuard guard(acc_a.get_device());
+  TORCH_CHECK(occ_ptr.numel() == T + 1 && occ_rows.numel() == B * F && acc.numel() >= T * rec_len(d) &&
+              sums.numel() >= 2, "bwd_acc sizes");
+  c10::hip::HIPGuard guard(acc.get_device());
   vfm_problem_t p{};
   p.B = B; p.B_global = B; p.T = T; p.nb_train = 1; p.F = (int32_t)F; p.d = (int32_t)d; p.id_bits = 64;
-  p.n_samples = 1;
+  p.n_samples = 1; p.e_lo = e_lo; p.e_hi = e_hi;
   for (int64_t g = 0; g < F; ++g) { p.group_hi[g] = T; p.group_n[g] = 1; }
   check(vfm_elbo_bwd_acc_f32(&p, occ_ptr.data_ptr<int32_t>(), occ_rows.data_ptr<int32_t>(),
                              dev_tensor(sumz, at::kFloat, "sumz").data_ptr<float>(),
                              dev_tensor(grow, at::kFloat, "grow").data_ptr<float>(),
                              dev_tensor(partials, at::kDouble, "partials").data_ptr<double>(),
-                             acc_a.data_ptr<float>(), acc_g.data_ptr<float>(), sums.data_ptr<float>(),
-                             stream_of(acc_a)),
+                             acc.data_ptr<float>(), sums.data_ptr<float>(), stream_of(acc)),
         "vfm_elbo_bwd_acc_f32");
 }
 
-void elbo_apply_adam(const Tensor& acc_a, const Tensor& acc_g, const Tensor& sums, Tensor entity, Tensor bias,
+void elbo_apply_adam(const Tensor& acc, const Tensor& sums, Tensor entity, Tensor bias,
                      Tensor scalars, const Tensor& inv_occ, const Tensor& W, const optional<Tensor>& eps_entity,
                      const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global, Tensor m_entity,
                      Tensor v_entity, Tensor m_bias, Tensor v_bias, Tensor m_scalars, Tensor v_scalars, int64_t F,
                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global,
                      int64_t likelihood, int64_t flags, int64_t seed, int64_t step, double lr, double beta1,
-                     double beta2, double eps_adam, int64_t adam_step) {
+                     double beta2, double eps_adam, int64_t adam_step, int64_t e_lo, int64_t e_hi) {
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
-  TORCH_CHECK(acc_a.numel() >= T * d && acc_g.numel() >= 2 * T && sums.numel() >= 2, "apply_adam sizes");
+  TORCH_CHECK(acc.numel() >= T * rec_len(d) && sums.numel() >= 2, "apply_adam sizes");
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel(), "Adam moment shapes");
   c10::hip::HIPGuard guard(entity.get_device());
   vfm_problem_t p = problem(entity, 0, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step);
+  p.e_lo = e_lo; p.e_hi = e_hi;
   check(vfm_elbo_apply_adam_f32(
-            &p, dev_tensor(acc_a, at::kFloat, "acc_a").data_ptr<float>(),
-            dev_tensor(acc_g, at::kFloat, "acc_g").data_ptr<float>(), dev_tensor(sums, at::kFloat, "sums").data_ptr<float>(),
+            &p, dev_tensor(acc, at::kFloat, "acc").data_ptr<float>(), dev_tensor(sums, at::kFloat, "sums").data_ptr<float>(),
             entity.data_ptr<float>(), bias.data_ptr<float>(), dev_tensor(scalars, at::kFloat, "scalars").data_ptr<float>(),
             dev_tensor(inv_occ, at::kFloat, "inv_occ").data_ptr<float>(), dev_tensor(W, at::kDouble, "W").data_ptr<double>(),
             fptr(eps_entity, "eps_entity"), fptr(eps_bias, "eps_bias"), fptr(eps_global, "eps_global"),
@@ -256,14 +258,14 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor(g!) v_bias, Tensor(h!) m_scalars, Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, "
         "int nb_train, int B_global, int likelihood, int flags, int seed, int step, float lr, float beta1, "
         "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss) -> ()", &elbo_bwd_adam);
-  m.def("elbo_bwd_acc(Tensor occ_ptr, Tensor occ_rows, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc_a, "
-        "Tensor(b!) acc_g, Tensor(c!) sums, int T, int F, int d) -> ()", &elbo_bwd_acc);
-  m.def("elbo_apply_adam(Tensor acc_a, Tensor acc_g, Tensor sums, Tensor(a!) entity_params, Tensor(b!) bias_params, "
+  m.def("elbo_bwd_acc(Tensor occ_ptr, Tensor occ_rows, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
+        "Tensor(c!) sums, int T, int F, int d, int e_lo, int e_hi) -> ()", &elbo_bwd_acc);
+  m.def("elbo_apply_adam(Tensor acc, Tensor sums, Tensor(a!) entity_params, Tensor(b!) bias_params, "
         "Tensor(c!) scalars, Tensor inv_occ, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, "
         "Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, Tensor(g!) v_bias, Tensor(h!) m_scalars, "
         "Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, "
-        "int flags, int seed, int step, float lr, float beta1, float beta2, float eps_adam, int adam_step) -> ()",
-        &elbo_apply_adam);
+        "int flags, int seed, int step, float lr, float beta1, float beta2, float eps_adam, int adam_step, "
+        "int e_lo, int e_hi) -> ()", &elbo_apply_adam);
   m.def("adam(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
         "int step) -> ()", &adam);
 }

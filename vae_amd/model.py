@@ -89,6 +89,7 @@ class VFM(nn.Module):
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         self.exchange = "stats"
+        self.exchange_chunks = 4
         self._xflat = None
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
@@ -269,14 +270,16 @@ class VFM(nn.Module):
             self._state_bufs = {}
 
     def _xviews(self):
-        """Flat exchange buffer [A: T*d | (sum grow, count): 2T | row sums: 2 | loss: 3 | pad]."""
-        n_a = _round4(self.T * self.d)
-        n_g = _round4(2 * self.T)
+        """Flat exchange buffer: T records [sum grow, count, 0, 0 | A_e (d)] then [row sums: 2 | pad: 2 |
+        loss: 3 | pad]; plus the entity boundaries of the exchange chunks."""
+        rl = ops.exchange_record_len(self.d)
+        n = self.T * rl
         if self._xflat is None:
-            self._xflat = torch.zeros(n_a + n_g + 8, dtype=torch.float32, device=self.device)
+            self._xflat = torch.zeros(n + 8, dtype=torch.float32, device=self.device)
         f = self._xflat
-        return (f[: self.T * self.d].view(self.T, self.d), f[n_a: n_a + 2 * self.T].view(self.T, 2),
-                f[n_a + n_g: n_a + n_g + 2], f[n_a + n_g + 4: n_a + n_g + 7])
+        k = max(1, min(int(self.exchange_chunks), self.T))
+        bounds = [self.T * i // k for i in range(k + 1)]
+        return f[:n], f[n: n + 2], f[n + 4: n + 7], bounds
 
     def _step_buffers(self, B):
         """Persistent per-step training state (sumz [B,d], grow [B], pred [B]) -- no allocator
@@ -325,19 +328,28 @@ class VFM(nn.Module):
             mark("bwd_adam")
             return loss3, st.pred
         if process_group is not None and adam and self.exchange == "stats":
-            # multi-rank: exchange the gradient's sufficient statistics (A_e, sum grow, count) -- half
-            # the bytes of the gradient -- in ONE all-reduce, then epilogue + Adam on every rank
-            xa, xg, xs, xl = self._xviews()
+            # multi-rank: exchange the gradient's sufficient statistics (sum grow, count, A_e) -- half
+            # the bytes of the gradient -- then epilogue + Adam on every rank.  The table is cut in
+            # `exchange_chunks` entity ranges: the all-reduce of chunk k overlaps the statistics kernel
+            # of chunk k+1 and the epilogue+Adam kernel of chunk k-1.
+            xacc, xs, xl, bounds = self._xviews()
             ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
             mark("finalize")
-            ops.elbo_backward_acc(plan, st, xa, xg, xs)
+            works = []
+            rl = ops.exchange_record_len(self.d)
+            for k in range(len(bounds) - 1):
+                lo, hi = bounds[k], bounds[k + 1]
+                ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
+                end = self._xflat.numel() if hi == self.T else hi * rl      # the last chunk carries sums + loss
+                works.append(torch.distributed.all_reduce(self._xflat[lo * rl: end], group=process_group,
+                                                          async_op=True))
             mark("bwd_acc")
-            allreduce_flat(self._xflat, process_group)
-            mark("allreduce")
             self._adam_t += 1
-            ops.elbo_apply_adam(plan, st, xa, xg, xs, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                self._views(self._adam_v), lr, self._adam_t)
-            mark("apply_adam")
+            for k in range(len(bounds) - 1):
+                works[k].wait()
+                ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                    self._views(self._adam_v), lr, self._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1])
+            mark("exchange_apply_adam")
             loss3.copy_(xl)
             return loss3, st.pred
         ops.elbo_finalize(st, scal, out=loss3)

@@ -215,27 +215,33 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out)
 
 
-def elbo_backward_acc(plan: BatchPlan, st: FwdState, acc_a, acc_g, sums):
-    """Multi-rank backward, stage 1: this shard's sufficient statistics of the gradient
-    (A_e = sum grow_r*sumz_r [T,d], (sum grow_r, count) [T,2], row sums [2]) -- half the bytes of the
-    gradient; the caller sums them over ranks."""
+def exchange_record_len(d: int) -> int:
+    """Floats per entity in the multi-rank exchange buffer: (sum grow, count, 0, 0 | A_e[0..d-1])."""
+    return 4 + (d + 3) // 4 * 4
+
+
+def elbo_backward_acc(plan: BatchPlan, st: FwdState, acc, sums, e_lo=0, e_hi=0):
+    """Multi-rank backward, stage 1: this shard's sufficient statistics of the gradient for the
+    entities [e_lo, e_hi) -- per entity (sum grow_r, count, A_e = sum grow_r*sumz_r), about half the
+    bytes of the gradient; the caller sums them over ranks."""
     if plan.occ_ptr is None:
         plan.build_index()
     spec = plan.spec
-    _lib.ops().elbo_bwd_acc(plan.occ_ptr, plan.occ_rows, st.sumz, st.grow, st.partials, acc_a, acc_g, sums,
-                            spec.T, spec.F, spec.d)
+    _lib.ops().elbo_bwd_acc(plan.occ_ptr, plan.occ_rows, st.sumz, st.grow, st.partials, acc, sums,
+                            spec.T, spec.F, spec.d, e_lo, e_hi)
 
 
-def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc_a, acc_g, sums, entity_params, bias_params, scalars,
-                    inv_occ, m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8):
-    """Multi-rank backward, stage 2: gradient epilogue + dense Adam from the rank-summed statistics."""
+def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bias_params, scalars,
+                    inv_occ, m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, e_lo=0, e_hi=0):
+    """Multi-rank backward, stage 2: gradient epilogue + dense Adam from the rank-summed statistics of
+    the entities [e_lo, e_hi) (the chunk that ends at T also updates the three scalars)."""
     e = st.eps if st.eps is not None else (None, None, None)
     p, spec = st.problem, plan.spec
-    _lib.ops().elbo_apply_adam(acc_a, acc_g, sums, entity_params, bias_params, scalars, inv_occ, plan.W,
+    _lib.ops().elbo_apply_adam(acc, sums, entity_params, bias_params, scalars, inv_occ, plan.W,
                                e[0], e[1], e[2], m_views[0], v_views[0], m_views[1], v_views[1], m_views[2],
                                v_views[2], spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train,
                                p.B_global, p.likelihood, p.flags & ~FLAG_NO_PRIOR_TERMS, p.seed & _I63, p.step,
-                               lr, beta1, beta2, eps_adam, int(step))
+                               lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi)
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
