@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
@@ -90,7 +91,8 @@ def main():
     torch.manual_seed(42)
     model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
     # synthetic data resident on the device: this rank's rows of nbt global batches
-    X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev)
+    X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
+                             zipf=args.zipf if args.zipf > 0 else None)
     if args.id32:
         X = X.to(torch.int32)
     # occurrence counts of the (virtual) training set: expected counts of nb_train uniform triples,
@@ -209,6 +211,23 @@ def main():
                 "elbo_fwd_kernel": {"achieved": kern["fwd"]["achieved_GBs"], "frac": kern["fwd"]["frac_hbm_peak"],
                                     "avg_us": kern["fwd"]["avg_us"], "alg_bytes": kern["fwd"]["alg_bytes"]}}
 
+    # ---- this box's streaming rate (device-to-device copy of 1 GiB), an honest denominator next to the
+    # 8 TB/s spec peak
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    if roof is not None:
+        roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
+        roof["frac_of_box_stream_copy"] = round(roof["achieved"] / copy_gbs, 4)
+
     # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -226,6 +245,7 @@ def main():
             "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
                        "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
                        "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
+                       "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "step": ("fwd+loss+bwd_acc+allreduce(stats)+apply_adam" if world > 1 else "fwd+loss+bwd+dense-adam") if

@@ -95,6 +95,24 @@ typedef struct vfm_problem {
   int64_t e_lo, e_hi;
 } vfm_problem_t;
 
+/* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
+ *   occ_ptr [T+1] offsets into occ_rows [B*F] (row numbers sorted by entity id, stable).
+ * Long lists (skewed data: a popular item can own 10% of the rows) would serialise on one lane group,
+ * so entities with more than VFM_HEAVY_LIST occurrences are also listed in `heavy_ids` (sorted) and
+ * their lists cut in work items `heavy_items` [n_items,4] = (slot in heavy_ids, begin, end, 0) of at
+ * most VFM_HEAVY_LIST occurrences; every backward call first reduces them into the scratch table
+ * `heavy_acc` [n_heavy, 4 + round4(d)] (overwritten per call).  n_heavy == 0: all three may be NULL. */
+#define VFM_HEAVY_LIST 32
+typedef struct vfm_index {
+  const int32_t* occ_ptr;
+  const int32_t* occ_rows;
+  const int32_t* heavy_ids;
+  const int32_t* heavy_items;
+  float* heavy_acc;
+  int32_t n_heavy;
+  int32_t n_items;
+} vfm_index_t;
+
 int vfm_abi_version(void);
 const char* vfm_last_error(void);
 
@@ -141,12 +159,12 @@ int vfm_elbo_finalize_f32(const vfm_problem_t* p, double* partials, const float*
 
 /* Backward (replaces autograd through vfm-torch.py:189-324,359; :368-369).  Entity-centric:
  * one lane group per table row e sums grow[r] * sumz[r,:] over the rows that contain e
- * (inverted index: occ_ptr [T+1] int32 offsets into occ_rows [B*F] int32 row numbers, sorted
- * by entity id), then writes the DENSE gradient row (zeros for rows not in the batch, like
- * the reference's dense nn.Embedding gradients).  No atomics; bitwise reproducible for a
- * fixed index.  grad_out [1] = dL/dloss (device).  g_scalars [3] = grads of alpha,
+ * (inverted index `idx`), then writes the DENSE gradient row (zeros for rows not in the batch, like
+ * the reference's dense nn.Embedding gradients).  No atomics and bitwise reproducible for a
+ * fixed index, except for the few entities on the index's heavy list (float atomics in their
+ * pre-reduction).  grad_out [1] = dL/dloss (device).  g_scalars [3] = grads of alpha,
  * global_bias_mean, global_bias_scale from the (rank-summed) partials. */
-int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                      const float* entity_params, const float* bias_params,
                      const float* inv_occ, const float* scalars, const double* W,
                      const float* eps_entity, const float* eps_bias, const float* eps_global,
@@ -162,7 +180,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32
  * still move through their momentum, exactly like the reference's dense Adam.
  * `loss` (3 floats) may be NULL; when given, the launch also does the work of
  * vfm_elbo_finalize_f32 (slot reduction + loss triple), saving that launch. */
-int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                           float* entity_params, float* bias_params, float* scalars,
                           const float* inv_occ, const double* W,
                           const float* eps_entity, const float* eps_bias, const float* eps_global,
@@ -184,7 +202,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const 
  * calls vfm_elbo_apply_adam_f32: gradient epilogue (eps regeneration, KL part, |.| link) + dense Adam
  * from the global statistics -- the replicas stay identical.  No VFM_FLAG_NO_PRIOR_TERMS here: the
  * row-independent terms are added once from the global sums. */
-int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const int32_t* occ_ptr, const int32_t* occ_rows,
+int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                          const float* sumz, const float* grow, const double* partials, float* acc,
                          float* sums, void* stream);
 int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const float* sums,

@@ -169,3 +169,47 @@ def test_large_batch_properties():
     p2 = ops.elbo_forward(plan2, ent, bia, scal2, None, seed=3, step=11, train=False).pred
     assert torch.allclose(p2 - p1, torch.full_like(p1, 2.5), atol=1e-3)
     assert torch.allclose(p1, st.pred, rtol=1e-5, atol=1e-4)                    # predict mode == train mode pred
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_skewed_batch_heavy_lists(d):
+    """A few entities own most of the rows (lists far longer than VFM_HEAVY_LIST): the pre-reduced
+    heavy path must give the oracle's gradients, through all three backward entry points."""
+    from vae_amd import ops
+    spec, P, x, y, nb_occ, eps, group_hi = _random_problem([300, 200], d, 6000, "reg", seed=77)
+    g = np.random.default_rng(5)
+    hot = g.random(6000) < 0.7
+    x[hot, 1] = 300 + g.integers(0, 3, hot.sum())          # 3 items own 70 % of the rows
+    x[g.random(6000) < 0.3, 0] = 7                         # one user owns 30 %
+    plan, st, loss3, (g_ent, g_bias, g_sc) = _run_gpu(spec, P, x, y, nb_occ, eps)
+    assert plan.heavy is not None and plan.heavy[0].numel() >= 4
+    r = O.rowwise_elbo(P, x, y.astype(np.float64), nb_occ, group_hi, spec.group_n, spec.nb_train,
+                       eps[0], eps[1], eps[2], "reg")
+    assert abs(loss3[0].item() - r["loss"]) / abs(r["loss"]) < 1e-5
+    assert rel_err(g_ent.cpu().numpy(), r["g_entity_params"]) < 5e-5
+    assert rel_err(g_bias.cpu().numpy(), r["g_bias_params"]) < 5e-5
+    # staged (multi-rank) form on one rank: statistics -> apply == fused backward + Adam
+    dev = torch.device("cuda:0")
+    ent = torch.tensor(P["entity_params"], device=dev); bia = torch.tensor(P["bias_params"], device=dev)
+    scal = torch.tensor(np.concatenate([P["alpha"], P["global_bias_mean"], P["global_bias_scale"]]), device=dev)
+    inv_occ = ops.inv_occ_from_counts(torch.tensor(nb_occ, device=dev))
+    e = (torch.tensor(eps[2], device=dev), torch.tensor(eps[1], device=dev), torch.tensor(eps[0], device=dev))
+    outs = []
+    for staged in (False, True):
+        pe, pb, ps = ent.clone(), bia.clone(), scal.clone()
+        mv = [(torch.zeros_like(pe), torch.zeros_like(pb), torch.zeros(3, device=dev)) for _ in range(2)]
+        st2 = ops.elbo_forward(plan, pe, pb, ps, inv_occ, eps=e)
+        l3 = ops.elbo_finalize(st2, ps)
+        if staged:
+            rl = ops.exchange_record_len(d)
+            acc = torch.zeros(spec.T * rl, device=dev); sums = torch.zeros(2, device=dev)
+            mid = spec.T // 2
+            ops.elbo_backward_acc(plan, st2, acc, sums, 0, mid)
+            ops.elbo_backward_acc(plan, st2, acc, sums, mid, spec.T)
+            ops.elbo_apply_adam(plan, st2, acc, sums, pe, pb, ps, inv_occ, mv[0], mv[1], 0.05, 1, e_lo=0, e_hi=mid)
+            ops.elbo_apply_adam(plan, st2, acc, sums, pe, pb, ps, inv_occ, mv[0], mv[1], 0.05, 1, e_lo=mid, e_hi=spec.T)
+        else:
+            ops.elbo_backward_adam(plan, st2, pe, pb, ps, inv_occ, mv[0], mv[1], 0.05, 1)
+        outs.append((pe, pb, ps))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)

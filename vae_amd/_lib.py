@@ -42,6 +42,16 @@ class Problem(C.Structure):
     ]
 
 
+class Index(C.Structure):
+    """Mirror of `vfm_index_t`."""
+    _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
+                ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
+                ("n_items", C.c_int32)]
+
+
+HEAVY_LIST = 32
+
+
 class VfmLibraryError(RuntimeError):
     pass
 
@@ -69,13 +79,13 @@ def load():
     lib.vfm_batch_norms.argtypes = [PP, vp, vp, vp, vp]
     lib.vfm_elbo_fwd_f32.argtypes = [PP] + [vp] * 15
     lib.vfm_elbo_finalize_f32.argtypes = [PP, vp, vp, vp, vp]
-    lib.vfm_elbo_bwd_f32.argtypes = [PP] + [vp] * 18
+    lib.vfm_elbo_bwd_f32.argtypes = [PP] + [vp] * 17
     lib.vfm_philox_eps_f32.argtypes = [PP, vp, vp, vp, vp]
-    lib.vfm_elbo_bwd_adam_f32.argtypes = ([PP] + [vp] * 19 +
+    lib.vfm_elbo_bwd_adam_f32.argtypes = ([PP] + [vp] * 18 +
                                           [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float,
                                  i64, vp]
-    lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 8
+    lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 7
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
                                             [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     for name in EXPORTS:

@@ -97,34 +97,52 @@ void elbo_finalize(Tensor partials, const Tensor& scalars, Tensor loss, int64_t 
         "vfm_elbo_finalize_f32");
 }
 
-struct BwdCommon {
-  vfm_problem_t p; const int32_t* occ_ptr; const int32_t* occ_rows;
-};
+int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
 
-BwdCommon bwd_common(const Tensor& occ_ptr, const Tensor& occ_rows, const Tensor& entity, const Tensor& bias,
-                     int64_t B, int64_t F, int64_t B_global, int64_t nb_train, int64_t likelihood, int64_t flags,
-                     at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step) {
-  dev_tensor(occ_ptr, at::kInt, "occ_ptr"); dev_tensor(occ_rows, at::kInt, "occ_rows");
-  dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
-  const int64_t T = entity.size(0), d = entity.size(1) / 2;
-  TORCH_CHECK(occ_ptr.numel() == T + 1 && occ_rows.numel() == B * F, "inverted index sizes");
-  return {problem(entity, B, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step),
-          occ_ptr.data_ptr<int32_t>(), occ_rows.data_ptr<int32_t>()};
+// index = [occ_ptr, occ_rows] or [occ_ptr, occ_rows, heavy_ids, heavy_items, heavy_acc]
+vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int64_t d) {
+  TORCH_CHECK(index.size() == 2 || index.size() == 5, "index = [occ_ptr, occ_rows] (+ [heavy_ids, heavy_items, heavy_acc])");
+  dev_tensor(index[0], at::kInt, "occ_ptr"); dev_tensor(index[1], at::kInt, "occ_rows");
+  TORCH_CHECK(index[0].numel() == T + 1 && index[1].numel() == B * F, "inverted index sizes");
+  vfm_index_t ix{};
+  ix.occ_ptr = index[0].data_ptr<int32_t>(); ix.occ_rows = index[1].data_ptr<int32_t>();
+  if (index.size() == 5 && index[2].numel() > 0) {
+    dev_tensor(index[2], at::kInt, "heavy_ids"); dev_tensor(index[3], at::kInt, "heavy_items");
+    dev_tensor(index[4], at::kFloat, "heavy_acc");
+    TORCH_CHECK(index[3].numel() % 4 == 0 && index[4].numel() >= index[2].numel() * rec_len(d), "heavy index sizes");
+    ix.heavy_ids = index[2].data_ptr<int32_t>(); ix.heavy_items = index[3].data_ptr<int32_t>();
+    ix.heavy_acc = index[4].data_ptr<float>();
+    ix.n_heavy = (int32_t)index[2].numel(); ix.n_items = (int32_t)(index[3].numel() / 4);
+  }
+  return ix;
 }
 
-void elbo_bwd(const Tensor& occ_ptr, const Tensor& occ_rows, const Tensor& entity, const Tensor& bias,
+struct BwdCommon {
+  vfm_problem_t p; vfm_index_t ix;
+};
+
+BwdCommon bwd_common(at::TensorList index, const Tensor& entity, const Tensor& bias,
+                     int64_t B, int64_t F, int64_t B_global, int64_t nb_train, int64_t likelihood, int64_t flags,
+                     at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step) {
+  dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
+  const int64_t T = entity.size(0), d = entity.size(1) / 2;
+  return {problem(entity, B, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step),
+          index_of(index, T, B, F, d)};
+}
+
+void elbo_bwd(at::TensorList index, const Tensor& entity, const Tensor& bias,
               const Tensor& inv_occ, const Tensor& scalars, const Tensor& W, const optional<Tensor>& eps_entity,
               const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global, const Tensor& sumz,
               const Tensor& grow, const Tensor& partials, const Tensor& grad_out, Tensor g_entity, Tensor g_bias,
               Tensor g_scalars, int64_t F, at::IntArrayRef group_hi, at::ArrayRef<double> group_n,
               int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed, int64_t step) {
   const int64_t B = grow.numel();
-  BwdCommon c = bwd_common(occ_ptr, occ_rows, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
+  BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
                            group_n, seed, step);
   TORCH_CHECK(g_entity.sizes() == entity.sizes() && g_bias.sizes() == bias.sizes() && g_scalars.numel() >= 3,
               "gradient shapes");
   c10::hip::HIPGuard guard(entity.get_device());
-  check(vfm_elbo_bwd_f32(&c.p, c.occ_ptr, c.occ_rows, entity.data_ptr<float>(), bias.data_ptr<float>(),
+  check(vfm_elbo_bwd_f32(&c.p, &c.ix, entity.data_ptr<float>(), bias.data_ptr<float>(),
                          dev_tensor(inv_occ, at::kFloat, "inv_occ").data_ptr<float>(),
                          dev_tensor(scalars, at::kFloat, "scalars").data_ptr<float>(),
                          dev_tensor(W, at::kDouble, "W").data_ptr<double>(), fptr(eps_entity, "eps_entity"),
@@ -139,7 +157,7 @@ void elbo_bwd(const Tensor& occ_ptr, const Tensor& occ_rows, const Tensor& entit
         "vfm_elbo_bwd_f32");
 }
 
-void elbo_bwd_adam(const Tensor& occ_ptr, const Tensor& occ_rows, Tensor entity, Tensor bias, Tensor scalars,
+void elbo_bwd_adam(at::TensorList index, Tensor entity, Tensor bias, Tensor scalars,
                    const Tensor& inv_occ, const Tensor& W, const optional<Tensor>& eps_entity,
                    const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global, const Tensor& sumz,
                    const Tensor& grow, const Tensor& partials, Tensor m_entity, Tensor v_entity, Tensor m_bias,
@@ -148,14 +166,14 @@ void elbo_bwd_adam(const Tensor& occ_ptr, const Tensor& occ_rows, Tensor entity,
                    int64_t flags, int64_t seed, int64_t step, double lr, double beta1, double beta2,
                    double eps_adam, int64_t adam_step, const optional<Tensor>& loss) {
   const int64_t B = grow.numel();
-  BwdCommon c = bwd_common(occ_ptr, occ_rows, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
+  BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
                            group_n, seed, step);
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel() && m_scalars.numel() >= 3 &&
               v_scalars.numel() >= 3, "Adam moment shapes");
   c10::hip::HIPGuard guard(entity.get_device());
   check(vfm_elbo_bwd_adam_f32(
-            &c.p, c.occ_ptr, c.occ_rows, entity.data_ptr<float>(), bias.data_ptr<float>(),
+            &c.p, &c.ix, entity.data_ptr<float>(), bias.data_ptr<float>(),
             dev_tensor(scalars, at::kFloat, "scalars").data_ptr<float>(),
             dev_tensor(inv_occ, at::kFloat, "inv_occ").data_ptr<float>(),
             dev_tensor(W, at::kDouble, "W").data_ptr<double>(), fptr(eps_entity, "eps_entity"),
@@ -172,22 +190,19 @@ void elbo_bwd_adam(const Tensor& occ_ptr, const Tensor& occ_rows, Tensor entity,
         "vfm_elbo_bwd_adam_f32");
 }
 
-int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
-
-void elbo_bwd_acc(const Tensor& occ_ptr, const Tensor& occ_rows, const Tensor& sumz, const Tensor& grow,
+void elbo_bwd_acc(at::TensorList index, const Tensor& sumz, const Tensor& grow,
                   const Tensor& partials, Tensor acc, Tensor sums, int64_t T, int64_t F, int64_t d, int64_t e_lo,
                   int64_t e_hi) {
-  dev_tensor(occ_ptr, at::kInt, "occ_ptr"); dev_tensor(occ_rows, at::kInt, "occ_rows");
   dev_tensor(acc, at::kFloat, "acc"); dev_tensor(sums, at::kFloat, "sums");
   const int64_t B = grow.numel();
-  TORCH_CHECK(occ_ptr.numel() == T + 1 && occ_rows.numel() == B * F && acc.numel() >= T * rec_len(d) &&
-              sums.numel() >= 2, "bwd_acc sizes");
+  TORCH_CHECK(acc.numel() >= T * rec_len(d) && sums.numel() >= 2, "bwd_acc sizes");
+  vfm_index_t ix = index_of(index, T, B, F, d);
   c10::hip::HIPGuard guard(acc.get_device());
   vfm_problem_t p{};
   p.B = B; p.B_global = B; p.T = T; p.nb_train = 1; p.F = (int32_t)F; p.d = (int32_t)d; p.id_bits = 64;
   p.n_samples = 1; p.e_lo = e_lo; p.e_hi = e_hi;
   for (int64_t g = 0; g < F; ++g) { p.group_hi[g] = T; p.group_n[g] = 1; }
-  check(vfm_elbo_bwd_acc_f32(&p, occ_ptr.data_ptr<int32_t>(), occ_rows.data_ptr<int32_t>(),
+  check(vfm_elbo_bwd_acc_f32(&p, &ix,
                              dev_tensor(sumz, at::kFloat, "sumz").data_ptr<float>(),
                              dev_tensor(grow, at::kFloat, "grow").data_ptr<float>(),
                              dev_tensor(partials, at::kDouble, "partials").data_ptr<double>(),
@@ -247,18 +262,18 @@ TORCH_LIBRARY(vfm_hip, m) {
         "int likelihood, int flags, int seed, int step) -> ()", &elbo_fwd);
   m.def("elbo_finalize(Tensor(a!) partials, Tensor scalars, Tensor(b!) loss, int nb_train, int B_global, int flags) -> ()",
         &elbo_finalize);
-  m.def("elbo_bwd(Tensor occ_ptr, Tensor occ_rows, Tensor entity_params, Tensor bias_params, Tensor inv_occ, "
+  m.def("elbo_bwd(Tensor[] index, Tensor entity_params, Tensor bias_params, Tensor inv_occ, "
         "Tensor scalars, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor sumz, Tensor grow, "
         "Tensor partials, Tensor grad_out, Tensor(a!) g_entity, Tensor(b!) g_bias, Tensor(c!) g_scalars, int F, "
         "int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, int flags, int seed, int step) -> ()",
         &elbo_bwd);
-  m.def("elbo_bwd_adam(Tensor occ_ptr, Tensor occ_rows, Tensor(a!) entity_params, Tensor(b!) bias_params, "
+  m.def("elbo_bwd_adam(Tensor[] index, Tensor(a!) entity_params, Tensor(b!) bias_params, "
         "Tensor(c!) scalars, Tensor inv_occ, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, "
         "Tensor sumz, Tensor grow, Tensor partials, Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, "
         "Tensor(g!) v_bias, Tensor(h!) m_scalars, Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, "
         "int nb_train, int B_global, int likelihood, int flags, int seed, int step, float lr, float beta1, "
         "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss) -> ()", &elbo_bwd_adam);
-  m.def("elbo_bwd_acc(Tensor occ_ptr, Tensor occ_rows, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
+  m.def("elbo_bwd_acc(Tensor[] index, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
         "Tensor(c!) sums, int T, int F, int d, int e_lo, int e_hi) -> ()", &elbo_bwd_acc);
   m.def("elbo_apply_adam(Tensor acc, Tensor sums, Tensor(a!) entity_params, Tensor(b!) bias_params, "
         "Tensor(c!) scalars, Tensor inv_occ, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, "

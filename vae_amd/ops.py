@@ -103,6 +103,7 @@ class BatchPlan:
                 raise IndexError(f"entity id out of range [0,{spec.T}): min {lo}, max {hi}")
         self.W = None
         self.occ_ptr = self.occ_rows = None
+        self.heavy = None
         dev = x.device
         lib = _lib.load()
         if inv_occ is not None and y is not None:
@@ -126,6 +127,31 @@ class BatchPlan:
         occ_ptr = torch.zeros(self.spec.T + 1, dtype=torch.int64, device=self.x.device)
         torch.cumsum(counts, 0, out=occ_ptr[1:])
         self.occ_ptr = occ_ptr.to(torch.int32).contiguous()
+        # long lists (skewed data): cut in work items of at most HEAVY_LIST occurrences, pre-reduced by
+        # their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
+        L = _lib.HEAVY_LIST
+        heavy = torch.nonzero(counts > L).reshape(-1)
+        self.heavy = None
+        if heavy.numel() > 0:
+            cnt = counts[heavy]
+            beg = occ_ptr[heavy]
+            nchunk = (cnt + L - 1) // L
+            slot = torch.repeat_interleave(torch.arange(heavy.numel(), device=flat.device), nchunk)
+            first = torch.cumsum(nchunk, 0) - nchunk
+            k = torch.arange(slot.numel(), device=flat.device) - first[slot]
+            ib = beg[slot] + k * L
+            ie = torch.minimum(ib + L, (beg + cnt)[slot])
+            items = torch.stack([slot, ib, ie, torch.zeros_like(slot)], 1).to(torch.int32).contiguous()
+            rec = 4 + (self.spec.d + 3) // 4 * 4
+            self.heavy = (heavy.to(torch.int32).contiguous(), items,
+                          torch.zeros(heavy.numel() * rec, dtype=torch.float32, device=flat.device))
+
+    def index_tensors(self):
+        """What the backward-family ops take as `index`."""
+        if self.occ_ptr is None:
+            self.build_index()
+        base = [self.occ_ptr, self.occ_rows]
+        return base + list(self.heavy) if self.heavy is not None else base
 
 
 @dataclass
@@ -190,7 +216,7 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
         g_scalars = torch.empty(3, dtype=torch.float32, device=dev)
     e = st.eps if st.eps is not None else (None, None, None)
     p, spec = st.problem, plan.spec
-    _lib.ops().elbo_bwd(plan.occ_ptr, plan.occ_rows, entity_params, bias_params, inv_occ, scalars, plan.W,
+    _lib.ops().elbo_bwd(plan.index_tensors(), entity_params, bias_params, inv_occ, scalars, plan.W,
                         e[0], e[1], e[2], st.sumz, st.grow, st.partials, grad_out, g_entity, g_bias, g_scalars,
                         spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
                         p.flags, p.seed & _I63, p.step)
@@ -207,7 +233,7 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
     p, spec = st.problem, plan.spec
-    _lib.ops().elbo_bwd_adam(plan.occ_ptr, plan.occ_rows, entity_params, bias_params, scalars, inv_occ, plan.W,
+    _lib.ops().elbo_bwd_adam(plan.index_tensors(), entity_params, bias_params, scalars, inv_occ, plan.W,
                              e[0], e[1], e[2], st.sumz, st.grow, st.partials, m_views[0], v_views[0],
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
@@ -227,7 +253,7 @@ def elbo_backward_acc(plan: BatchPlan, st: FwdState, acc, sums, e_lo=0, e_hi=0):
     if plan.occ_ptr is None:
         plan.build_index()
     spec = plan.spec
-    _lib.ops().elbo_bwd_acc(plan.occ_ptr, plan.occ_rows, st.sumz, st.grow, st.partials, acc, sums,
+    _lib.ops().elbo_bwd_acc(plan.index_tensors(), st.sumz, st.grow, st.partials, acc, sums,
                             spec.T, spec.F, spec.d, e_lo, e_hi)
 
 
