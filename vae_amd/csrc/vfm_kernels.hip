@@ -5,16 +5,19 @@
 // Replaces the per-batch body of the reference: vfm-torch.py:189-324 (CF.forward), the loss
 // line :359 and autograd through them (:368-369).  Math: SURVEY.md Appendix A.
 //
-// Work decomposition
-//   forward : a *lane group* of LPE lanes owns one batch row; each lane owns CPL chunks of
-//             VEC consecutive embedding coordinates.  A 256-thread workgroup stages a tile of
-//             rows in LDS first (one thread per (row, field) occurrence: id, bias sample,
-//             KL weight), then the lane groups gather the 8d-byte table rows with 16-byte
-//             loads, form z = mu + |s| eps in registers, and reduce the FM term across the
-//             group with wave shuffles.
-//   backward: entity-centric.  A lane group owns one TABLE row e and sums grow[r]*sumz[r,:]
-//             over the batch rows containing e (inverted index), then writes the dense
-//             gradient row once.  No atomics.
+// Kernels (details at each definition)
+//   k_fwd     : a *lane group* of LPE lanes owns one batch row, each lane CPL chunks of VEC
+//               coordinates; rows of a workgroup are contiguous; ids -> table rows -> arithmetic are
+//               software-pipelined in registers; FM reduction with DPP / permlane swaps; per-block
+//               partial sums to private slots (no atomics).
+//   k_finalize: adds the slots, forms the loss (also foldable into the fused backward).
+//   k_bwd     : entity-centric.  A lane group owns one TABLE row e, sums grow[r]*sumz[r,:] over the
+//               batch rows containing e (inverted index) and either stores the dense gradient row,
+//               applies dense Adam in place (ADAM), or -- multi-rank -- stores / consumes the
+//               gradient's sufficient statistics (STAGE_ACC / STAGE_APPLY).
+//   k_heavy   : parallel pre-reduction of occurrence lists longer than VFM_HEAVY_LIST (skewed data).
+//   k_adam    : dense Adam on a flat buffer (unfused path).  k_norms, k_inv_occ: per-batch / per-dataset
+//               normalisers.  k_philox_dump: the eps stream, for tests.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -38,7 +41,6 @@ int fail_hip(hipError_t e, const char* where) {
 }
 
 constexpr int BLOCK = 256;
-constexpr int OCC_CAP = 1024;  // (row, field) occurrences staged per LDS tile
 constexpr float LOG_SQRT_2PI = 0.918938533204672742f;
 constexpr float LN2 = 0.693147180559945309f;
 
@@ -120,7 +122,7 @@ __device__ __forceinline__ void eps_of_chunk(const RngKey& k, uint32_t e, int j,
 struct KArgs {
   int64_t B, T;
   int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
-  int32_t F, d, lik, id64, G, TR, flags;
+  int32_t F, d, lik, id64, G, flags;
   float ll_scale;  // nb_train / B_global
   double ll_scale_d;
   RngKey key;
@@ -1112,8 +1114,6 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 
     float c = 0.f;
     if (touched) {
-      const int64_t lo = 0;
-      (void)lo;
       c = sh_cs[group_index(sh_hi, a.G, e)] * io * cntf;
     }
     float nb_eps = 0.f;
