@@ -85,7 +85,7 @@ typedef struct vfm_problem {
   int64_t group_hi[VFM_MAX_FIELDS];
   double group_n[VFM_MAX_FIELDS];
   /* counter-based RNG key, used when the eps tables are NULL: eps(e,k) =
-   * BoxMuller(Philox4x32-10(key = seed, ctr = (k/4, e, step, tag))).  One draw per ENTITY per
+   * BoxMuller(Philox4x32-10(key = seed, ctr = (k/8, e, step))).  One draw per ENTITY per
    * step, shared by every row that contains it (vfm-torch.py:207-208,238-245).          */
   uint64_t seed;
   uint64_t step;
@@ -141,7 +141,7 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
  *       sumz [B,d] and grow [B]: training state for the backward call:
  *       sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.
  *  eps: Philox mode draws, per entity and step, d embedding normals + 1 first-order-weight
- *       normal from Philox4x32-10(ctr = (k/4, e, step), key = seed) (see vfm_philox_eps_f32).  */
+ *       normal from Philox4x32-10(ctr = (k/8, e, step), key = seed) (see vfm_philox_eps_f32).  */
 int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      const float* entity_params, const float* bias_params,
                      const float* inv_occ, const float* scalars, const double* W,

@@ -286,3 +286,29 @@ def test_end_to_end_learning_matches_cpu_reference_port():
     base = float(torch.sqrt(torch.mean((ytr.mean() - yte) ** 2)))
     assert gpu_rmse < 0.8 * base and cpu_rmse < 0.8 * base
     assert abs(gpu_rmse - cpu_rmse) < 0.2 * cpu_rmse
+
+
+def test_philox_stream_statistics():
+    """The in-kernel eps stream (Philox4x32-10 + Box-Muller, 16-bit radius / 10-bit angle): moments,
+    Kolmogorov distance to N(0,1), no point mass at 0, no correlation between the two normals of a pair,
+    between neighbouring entities, or between the embedding and first-order streams."""
+    from vae_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    spec = ops.Spec(T=20000, F=2, d=64, group_hi=(10001, 20000), group_n=(10000.0, 10000.0),
+                    likelihood=_lib.LIK_NORMAL, nb_train=1)
+    ee, eb, eg = ops.philox_eps(spec, seed=2024, step=3, device=dev)
+    x = ee.reshape(-1)
+    n = x.numel()
+    assert abs(x.mean().item()) < 4 / n ** 0.5 and abs(x.var().item() - 1) < 6 * (2 / n) ** 0.5
+    assert abs((x ** 4).mean().item() - 3) < 0.05 and abs((x ** 3).mean().item()) < 0.02
+    assert (x == 0).sum().item() == 0
+    xs, _ = torch.sort(x.double())
+    ks = (torch.special.ndtr(xs) - (torch.arange(n, device=dev, dtype=torch.float64) + 0.5) / n).abs().max().item()
+    assert ks < 2.5 / n ** 0.5, ks                       # ~ the 0.1 % critical value of the KS statistic
+    assert x.abs().max().item() < 4.9                     # 16-bit radius: sqrt(2 ln 2^17) = 4.85
+    assert abs((ee[:, 0::2] * ee[:, 1::2]).mean().item()) < 4 / (n / 2) ** 0.5      # cos / sin partners
+    assert abs((ee[:-1] * ee[1:]).mean().item()) < 4 / n ** 0.5                    # neighbouring entities
+    assert abs((ee[:, 0] * eb).mean().item()) < 4 / 20000 ** 0.5                   # embedding vs bias stream
+    assert abs(eb.mean().item()) < 0.03 and abs(eb.var().item() - 1) < 0.04
+    ee2, eb2, _ = ops.philox_eps(spec, seed=2025, step=3, device=dev)              # another seed
+    assert abs((ee * ee2).mean().item()) < 4 / n ** 0.5
