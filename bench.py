@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the global batch stays at --batch rows and is split over the ranks "
+                         "(SURVEY cfg4); default is weak scaling, --batch rows per rank")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -85,6 +88,8 @@ def main():
     sizes, d, B, nb_train, output = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    if args.strong:
+        B = (B + world - 1) // world          # rows per rank of a fixed global batch
     F = len(sizes)
     nbt = max(1, min(args.n_batches, args.steps + args.warmup))
 
@@ -240,7 +245,7 @@ def main():
             "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
                        "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,

@@ -473,7 +473,7 @@ class VFM(nn.Module):
             delta = logit - mean
             mean += delta / n
             m2 += delta * (logit - mean)
-            pmean += (logit if self.output == "reg" else torch.sigmoid(logit) - pmean * 0) / 1
+            pmean += logit if self.output == "reg" else torch.sigmoid(logit)
         var = m2 / max(n - 1, 1)
         pm = pmean / n
         return {"mean": pm, "var": var if self.output == "reg" else None, "logits_mean": mean, "logits_var": var}
