@@ -213,3 +213,47 @@ def test_skewed_batch_heavy_lists(d):
         outs.append((pe, pb, ps))
     for a, b in zip(*outs):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_randomised_configurations_against_oracle():
+    """Seeded random sweep over (F, d, B, likelihood, id width, skew): forward, loss, all gradients and
+    the fused backward+Adam step vs the fp64 oracle."""
+    from vae_amd import ops
+    rng = np.random.default_rng(2024)
+    dev = torch.device("cuda:0")
+    ds = [4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 160, 256, 3, 6, 10, 50]
+    for trial in range(24):
+        F = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 9]))
+        d = int(rng.choice(ds))
+        B = int(rng.integers(1, 700))
+        output = "reg" if rng.random() < 0.5 else "class"
+        id_dtype = torch.int32 if rng.random() < 0.5 else torch.int64
+        sizes = [int(rng.integers(2, 40)) for _ in range(F)]
+        spec, P, x, y, nb_occ, eps, group_hi = _random_problem(sizes, d, B, output, seed=1000 + trial)
+        if rng.random() < 0.4 and B > 64:                   # skew: one entity per column owns most rows
+            for f in range(F):
+                x[rng.random(B) < 0.6, f] = x[0, f]
+        tag = (trial, F, d, B, output, str(id_dtype))
+        plan, st, loss3, (g_ent, g_bias, g_sc) = _run_gpu(spec, P, x, y, nb_occ, eps, id_dtype)
+        r = O.rowwise_elbo(P, x, y.astype(np.float64), nb_occ, group_hi, spec.group_n, spec.nb_train,
+                           eps[0], eps[1], eps[2], output)
+        assert abs(loss3[0].item() - r["loss"]) / abs(r["loss"]) < 2e-5, tag
+        assert rel_err(st.pred.cpu().numpy(), r["pred"]) < 5e-5, tag
+        # F == 1 is degenerate (no interactions: the true FM gradient is 0 and the kernel's
+        # sum_r g_r*sumz_r - z_e*sum_r g_r cancels two equal fp32 numbers): looser bound there
+        gtol = 1e-4 if F > 1 else 1e-3
+        assert rel_err(g_ent.cpu().numpy(), r["g_entity_params"]) < gtol, tag
+        assert rel_err(g_bias.cpu().numpy(), r["g_bias_params"]) < 1e-4, tag
+        # fused backward + Adam == oracle gradients through the numpy Adam
+        ent = torch.tensor(P["entity_params"], device=dev); bia = torch.tensor(P["bias_params"], device=dev)
+        scal = torch.tensor(np.concatenate([P["alpha"], P["global_bias_mean"], P["global_bias_scale"]]), device=dev)
+        inv_occ = ops.inv_occ_from_counts(torch.tensor(nb_occ, device=dev))
+        e = (torch.tensor(eps[2], device=dev), torch.tensor(eps[1], device=dev), torch.tensor(eps[0], device=dev))
+        mv = [(torch.zeros_like(ent), torch.zeros_like(bia), torch.zeros(3, device=dev)) for _ in range(2)]
+        st2 = ops.elbo_forward(plan, ent, bia, scal, inv_occ, eps=e)
+        l3 = torch.empty(3, device=dev)
+        ops.elbo_backward_adam(plan, st2, ent, bia, scal, inv_occ, mv[0], mv[1], 0.01, 1, loss_out=l3)
+        pe = P["entity_params"].astype(np.float64).copy()
+        O.adam_step(pe, r["g_entity_params"], np.zeros_like(pe), np.zeros_like(pe), 1, 0.01)
+        assert rel_err(ent.cpu().numpy(), pe) < (1e-5 if F > 1 else 1e-2), tag   # (Adam normalises: sign noise at F == 1)
+        assert abs(l3[0].item() - r["loss"]) / abs(r["loss"]) < 2e-5, tag
