@@ -88,3 +88,24 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
                 assert "vfm_oracle" not in txt, f
+
+
+def test_libfm_round_trip(tmp_path):
+    """prepare_data's libFM export (prepare.py:58-62) read back by the movie100-branch loader."""
+    df, idx, N, M = _write_dataset(tmp_path, shifted=False)
+    out = D.prepare_data("toy", True, root=tmp_path)
+    n, m, Xtr, Xte, ytr, yte = D.load_libfm(tmp_path / "toy" / "toy.trainval_libfm", tmp_path / "toy" / "toy.test_libfm")
+    assert (n, m) == (N, M) and Xtr.shape == (45, 2) and Xte.shape == (15, 2)
+    assert np.array_equal(Xtr[:, 0], out.loc[idx[:45], "user"]) and np.array_equal(Xtr[:, 1], out.loc[idx[:45], "shifted_item"])
+    assert np.array_equal(ytr, out.loc[idx[:45], "outcome"])
+
+
+def test_load_ratings_frame_reindexes_and_splits():
+    g = np.random.default_rng(1)
+    df = pd.DataFrame({"userId": g.choice([3, 17, 99, 1000], 200), "movieId": g.choice([5, 6, 70, 800, 9000], 200),
+                       "rating": g.integers(1, 11, 200) / 2})
+    N, M, Xtr, Xte, ytr, yte = D.load_ratings_frame(df, seed=0)
+    assert (N, M) == (4, 5) and len(ytr) == 160 and len(yte) == 40
+    X = np.concatenate([Xtr, Xte])
+    assert X[:, 0].min() == 0 and X[:, 0].max() == 3 and X[:, 1].min() == 4 and X[:, 1].max() == 8
+    assert sorted(np.concatenate([ytr, yte]).tolist()) == sorted(df["rating"].astype(np.float32).tolist())

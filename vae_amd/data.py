@@ -60,6 +60,43 @@ def prepare_data(DATA, is_classification, root="data"):
     return df
 
 
+def load_libfm(train_path, test_path):
+    """The `movie100` branch of the reference (vfm-torch.py:31-57): libFM text files with lines
+    `<outcome> <user>:1 <item>:1` (as written by `prepare_data`).  Returns
+    (N, M, X_train, X_test, y_train, y_test) with N / M counted over train + test like the reference
+    (:48-50); ids are used as they appear in the files (already shifted when exported by prepare_data)."""
+    import pandas as pd
+
+    def read(path):
+        df = pd.read_csv(path, names=("outcome", "user", "item"), sep=" ")
+        df["user"] = df["user"].map(lambda t: t[:-2])          # strip the ":1" (vfm-torch.py:38-39)
+        df["item"] = df["item"].map(lambda t: t[:-2])
+        return df.astype(int)
+
+    tr, te = read(train_path), read(test_path)
+    both = pd.concat((tr, te), axis=0)
+    N, M = int(both["user"].nunique()), int(both["item"].nunique())
+    return (N, M, tr[["user", "item"]].to_numpy(), te[["user", "item"]].to_numpy(),
+            tr["outcome"].to_numpy(), te["outcome"].to_numpy())
+
+
+def load_ratings_frame(df, user_col="userId", item_col="movieId", rating_col="rating", test_size=0.2,
+                       seed=None):
+    """The `movielens` / parquet branches of the reference (vfm-torch.py:60-73,96-117): re-index users
+    and items with np.unique, shift item ids by N, shuffle-split 80/20 (the reference's
+    train_test_split(shuffle=True) is unseeded; pass `seed` for reproducibility).
+    Returns (N, M, X_train, X_test, y_train, y_test)."""
+    user = np.unique(df[user_col], return_inverse=True)[1]
+    item = np.unique(df[item_col], return_inverse=True)[1]
+    N, M = int(user.max()) + 1, int(item.max()) + 1
+    X = np.stack([user, item + N], 1).astype(np.int64)
+    y = np.asarray(df[rating_col], dtype=np.float32)
+    perm = np.random.default_rng(seed).permutation(len(y))
+    n_te = int(round(test_size * len(y)))
+    te, tr = perm[:n_te], perm[n_te:]
+    return N, M, X[tr], X[te], y[tr], y[te]
+
+
 def load_fraction(path, test_size=0.2, seed=0):
     """The shipped toy set `data/fraction/data.csv` (536 users x 20 items, binary `outcome`).
     It has no split files and no `shifted_item` column, so: item ids are shifted by N here and the
