@@ -484,7 +484,8 @@ __device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC
       if constexpr (MODE == MODE_TRAIN) {
         kq = g2 * g2 + kq;
         kq = m2 * m2 + kq;
-        lg += __builtin_amdgcn_logf(fmaxf(g2.x, SIGMA_MIN)) + __builtin_amdgcn_logf(fmaxf(g2.y, SIGMA_MIN));
+        // log s0 + log s1 = log(s0 * s1): one v_log_f32 per pair (the clamped product stays >= 1e-24)
+        lg += __builtin_amdgcn_logf(fmaxf(g2.x, SIGMA_MIN) * fmaxf(g2.y, SIGMA_MIN));
       }
     }
     zz += valid ? zq.x + zq.y : 0.f;
