@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 SINGLE_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20", "ml100k_class_d20",
-                "ml20m_reg_d128"]
-F64_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20"]
+                "ml20m_reg_d128", "dup_reg_d12", "dup_class_d12"]
+F64_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20", "dup_reg_d12"]
 
 PARAM_KEYS = ("alpha", "global_bias_mean", "global_bias_scale", "bias_params", "entity_params")
 

@@ -259,6 +259,16 @@ def main():
     single_case(ns, CF, "ml20m_reg_d128", N, M, d, x, y, nb_train, nb_occ, "reg",
                 also_f64=False, sparse_rows=True)
 
+    # (4b) few entities, many duplicates (every entity in hundreds of rows): long inverted-index lists
+    g = np.random.default_rng(4)
+    N, M, d, B, nb_train = 5, 4, 12, 2000, 2000
+    x = np.stack([g.integers(0, N, B), N + g.integers(0, M, B)], 1)
+    nb_occ = np.bincount(x.reshape(-1), minlength=N + M)
+    y = g.integers(1, 6, B).astype(np.float32)
+    single_case(ns, CF, "dup_reg_d12", N, M, d, x, y, nb_train, nb_occ, "reg")
+    single_case(ns, CF, "dup_class_d12", N, M, d, x, (y >= 3).astype(np.float32), nb_train, nb_occ, "class",
+                also_f64=False)
+
     # (5) 3 batches/epoch (1000,1000,500) x 2 epochs Adam trajectory, short last batch
     g = np.random.default_rng(3)
     N, M, d = 120, 200, 16
