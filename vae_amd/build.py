@@ -22,8 +22,10 @@ def build_hip_library(force=False, verbose=False):
     """libvfm_hip.so: kernels + C ABI (include/vfm_hip.h), gfx950 only."""
     src = os.path.join(HERE, "csrc", "vfm_kernels.hip")
     hdr = os.path.join(ROOT, "include", "vfm_hip.h")
+    parts = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))
+             if f.endswith(".hpp")]             # the kernels, included by vfm_kernels.hip (one TU)
     out = os.path.join(HERE, "libvfm_hip.so")
-    if not force and not _stale(out, [src, hdr]):
+    if not force and not _stale(out, [src, hdr] + parts):
         return out
     cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-o", out, src]

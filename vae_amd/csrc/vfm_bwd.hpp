@@ -1,0 +1,368 @@
+// vfm_bwd.hpp -- k_heavy, k_bwd: entity-centric gradients / fused Adam / multi-rank stages.
+// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+#pragma once
+
+// ---------------------------------------------------------------------------------------
+// backward (entity-centric, dense gradient rows, no atomics) -- optionally with the dense Adam
+// update fused in (ADAM = 1): the gradient row never leaves registers.
+//
+// A lane group owns one TABLE row e: it sums grow[r] * sumz[r,:] over the batch rows that contain
+// e (inverted index occ_ptr / occ_rows), adds the KL part, and either stores the dense gradient
+// row (zeros when e is not in the batch: the reference's nn.Embedding gradients are dense) or
+// applies torch.optim.Adam's update to (p, m, v) of that row in place.  Only e's own parameters
+// are read, so the in-place update is race free.  All loads that do not depend on the index
+// chain (own row, Adam moments, next entity's offsets) are issued before walking it.
+// ---------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* m_entity; float* v_entity; float* m_bias; float* v_bias; float* m_scal; float* v_scal;
+  float b1, b2, eps, step_size, bc2_sqrt;
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamArgs& ad) {
+  m = m + (g - m) * (1.0f - ad.b1);
+  v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
+  const float denom = __fsqrt_rn(v) / ad.bc2_sqrt + ad.eps;
+  return p + (-ad.step_size * m) / denom;
+}
+
+// Skewed batches (a popular item can own 10^4 of the 10^5 rows): an occurrence list longer than
+// VFM_HEAVY_LIST is cut in chunks of that length (work items built with the index), each walked by
+// its own lane group here and added -- a few float atomics per chunk -- into the entity's record of a
+// small scratch table; the main kernel then reads that record instead of walking the list.  Without
+// it one lane group serialises the whole list (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
+template <int LPE, int CPL, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ items, int n_items,
+                                                 const int32_t* __restrict__ occ_rows,
+                                                 const float* __restrict__ sumz, const float* __restrict__ grow,
+                                                 float* __restrict__ heavy_acc, int d) {
+  constexpr int GPB = BLOCK / LPE;
+  const int lig = threadIdx.x % LPE;
+  const int C = (d + VEC - 1) / VEC;
+  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
+  for (int it = blockIdx.x * GPB + threadIdx.x / LPE; it < n_items; it += gridDim.x * GPB) {
+    const int slot = items[4 * it], beg = items[4 * it + 1], end = items[4 * it + 2];
+    Chunk<VEC> A[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
+    float gs = 0.f;
+    for (int o = beg; o < end; o += 4) {      // four occurrences in flight
+      int r[4]; float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = o + u < end;
+        r[u] = occ_rows[ok ? o + u : beg];
+        g[u] = ok ? grow[r[u]] : 0.f;
+        gs += g[u];
+      }
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          Chunk<VEC> sv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sv[u] = ld_chunk<VEC>(sumz + (size_t)r[u] * d + (size_t)j * VEC);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g[u], sv[u].v[t], A[i].v[t]);
+        }
+      }
+    }
+    float* rec = heavy_acc + (size_t)slot * xs;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int j = lig + i * LPE;
+      if (j < C) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) atomicAdd(rec + 4 + (size_t)j * VEC + t, A[i].v[t]);
+      }
+    }
+    if (lig == 0) { atomicAdd(rec, gs); atomicAdd(rec + 1, (float)(end - beg)); }
+  }
+}
+
+__device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ids[mid] < e) lo = mid + 1; else hi = mid;
+  }
+  return (n > 0 && ids[lo] == e) ? lo : -1;
+}
+
+enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE>
+__global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
+  constexpr int GPB = BLOCK / LPE;
+  __shared__ float sh_cs[VFM_MAX_FIELDS];
+  __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
+  __shared__ double sh_fin[5][BLOCK / 64];
+  const int tid = threadIdx.x;
+  const int lig = tid % LPE;
+  const int d = a.d;
+  const int C = (d + VEC - 1) / VEC;
+  if (STAGE != STAGE_ACC && tid < a.G) {
+    sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
+    sh_hi[tid] = a.group_hi[tid];
+  }
+  __syncthreads();
+  const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
+
+  double fin[5] = {0, 0, 0, 0, 0};
+  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 in
+  if (blockIdx.x == 0 && fold)
+    reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
+  if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_lo == 0) {
+    b.sums[0] = (float)b.partials[VFM_P_G];       // this rank's row sums, to be summed over ranks
+    b.sums[1] = (float)b.partials[VFM_P_ALPHA];
+  }
+  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T) {   // (last chunk of a chunked run)
+    const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
+    const float sum_g = (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
+    const float sum_a = (STAGE == STAGE_APPLY) ? b.sums[1]
+                                               : (float)(fold ? fin[VFM_P_ALPHA] : b.partials[VFM_P_ALPHA]);
+    float e0 = 0.f;
+    if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
+    if constexpr (EPS == EPS_PHILOX) {
+      float n[8], nb;
+      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      e0 = n[0];
+    }
+    const float as0 = fabsf(s0);
+    const float prior = (a.flags & VFM_FLAG_NO_PRIOR_TERMS) ? 0.f : 1.f;
+    const float ga = (a.lik == VFM_LIK_NORMAL)
+                         ? gout * signf(alpha) * a.ll_scale * sum_a : 0.f;
+    const float gm = gout * (sum_g + prior * m0);
+    const float gs = gout * signf(s0) * (e0 * sum_g + prior * (as0 - inv_sigma(as0)));
+    if constexpr (ADAM) {
+      float* sc = const_cast<float*>(a.scalars);
+      const float gg[3] = {ga, gm, gs};
+      for (int i = 0; i < 3; ++i) {
+        float m = ad.m_scal[i], v = ad.v_scal[i];
+        // alpha has no gradient under the Bernoulli likelihood (reference: grad None, Adam skips it)
+        if (i == 0 && a.lik != VFM_LIK_NORMAL) continue;
+        sc[i] = adam_update(sc[i], gg[i], m, v, ad);
+        ad.m_scal[i] = m; ad.v_scal[i] = v;
+      }
+    } else {
+      b.g_scalars[0] = ga; b.g_scalars[1] = gm; b.g_scalars[2] = gs;
+    }
+  }
+
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);          // floats per exchange record
+  int64_t e = a.e_lo + (int64_t)blockIdx.x * GPB + tid / LPE;
+  int2 pq = make_int2(0, 0);
+  if (STAGE != STAGE_APPLY && e < a.e_hi) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
+  for (; e < a.e_hi; e += stride) {
+    int beg = pq.x, end = pq.y;
+    const int64_t en = e + stride;
+    float2 gc = make_float2(0.f, 0.f);
+    if constexpr (STAGE == STAGE_APPLY) {
+      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)e * xs);   // (sum of grow, occurrences) over ALL ranks
+      beg = 0; end = 0;
+    } else {
+      if (en < a.e_hi) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+    }
+    float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
+    float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
+    const bool touched = (STAGE == STAGE_APPLY) ? gc.y > 0.f : beg != end;
+    const float cntf = (STAGE == STAGE_APPLY) ? gc.y : (float)(end - beg);
+    if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
+
+    // loads that do not depend on the index chain
+    Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
+    float2 th = make_float2(0.f, 1.f), mb = make_float2(0.f, 0.f), vb = make_float2(0.f, 0.f);
+    float io = 0.f, epw = 0.f;
+    if (STAGE != STAGE_ACC && (ADAM || touched)) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          mu[i] = ld_chunk<VEC>(prow + (size_t)j * VEC);
+          s[i] = ld_chunk<VEC>(prow + d + (size_t)j * VEC);
+          if constexpr (ADAM) {
+            const size_t o = (size_t)e * (2 * (size_t)d) + (size_t)j * VEC;
+            mm[i] = ld_chunk_nt<VEC>(ad.m_entity + o); ms[i] = ld_chunk_nt<VEC>(ad.m_entity + o + d);
+            vm[i] = ld_chunk_nt<VEC>(ad.v_entity + o); vs[i] = ld_chunk_nt<VEC>(ad.v_entity + o + d);
+          }
+          if constexpr (EPS == EPS_TABLE)
+            if (touched) ep[i] = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
+        }
+      }
+      if (lig == 0) {
+        th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
+        if constexpr (ADAM) {
+          mb = *reinterpret_cast<const float2*>(ad.m_bias + 2 * (size_t)e);
+          vb = *reinterpret_cast<const float2*>(ad.v_bias + 2 * (size_t)e);
+        }
+      }
+      if (touched) {
+        io = a.inv_occ[e];
+        if constexpr (EPS == EPS_TABLE) epw = a.eps_bias[e];
+      }
+    }
+
+    // walk the inverted index: A = sum_r g_r * sumz_r, gs = sum_r g_r
+    Chunk<VEC> A[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
+    float gs = 0.f;
+    int o = beg;
+    if (STAGE != STAGE_APPLY && end - beg > VFM_HEAVY_LIST && b.n_heavy > 0) {
+      const int slot = heavy_slot_of(b.heavy_ids, b.n_heavy, (int)e);
+      if (slot >= 0) {      // pre-reduced by k_heavy: read the record, skip the walk
+        const float* rec = b.heavy_acc + (size_t)slot * xs;
+        gs = rec[0];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) A[i] = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);
+        }
+        o = end;
+      }
+    }
+    for (; o + 1 < end; o += 2) {       // two occurrences in flight
+      const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
+      const float g0 = b.grow[r0], g1 = b.grow[r1];
+      gs += g0 + g1;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
+          const Chunk<VEC> s1v = ld_chunk<VEC>(b.sumz + (size_t)r1 * d + (size_t)j * VEC);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g1, s1v.v[t], fmaf(g0, s0v.v[t], A[i].v[t]));
+        }
+      }
+    }
+    if (o < end) {
+      const int r0 = b.occ_rows[o];
+      const float g0 = b.grow[r0];
+      gs += g0;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g0, s0v.v[t], A[i].v[t]);
+        }
+      }
+    }
+
+    if constexpr (STAGE == STAGE_ACC) {   // store the statistics (dense: zeros for rows not in this shard)
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) st_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC, A[i]);
+      }
+      if (lig == 0) *reinterpret_cast<float4*>(b.acc + (size_t)e * xs) = make_float4(gs, cntf, 0.f, 0.f);
+      continue;
+    }
+    if constexpr (STAGE == STAGE_APPLY) {
+      gs = gc.x;
+      if (touched) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC);
+        }
+      }
+    }
+
+    if (!touched && !ADAM) {   // entity not in the batch: dense zero row
+      Chunk<VEC> zc;
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) zc.v[t] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          st_chunk_nt<VEC>(grow_e + (size_t)j * VEC, zc);
+          st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, zc);
+        }
+      }
+      if (lig == 0) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
+      continue;
+    }
+
+    float c = 0.f;
+    if (touched) {
+      c = sh_cs[group_index(sh_hi, a.G, e)] * io * cntf;
+    }
+    float nb_eps = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int j = lig + i * LPE;
+      if (j < C) {
+        Chunk<VEC> gm, gv;
+        if (touched) {
+          Chunk<VEC> epc;
+          if constexpr (EPS == EPS_TABLE) {
+            epc = ep[i];
+          } else if constexpr (EPS == EPS_ZERO) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) epc.v[t] = 0.f;
+          } else {
+            float nb;
+            eps_of_chunk<VEC>(a.key, (uint32_t)e, j, epc.v, nb);
+            if (i == 0) nb_eps = nb;
+          }
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            const float sg = fabsf(s[i].v[t]);
+            const float z = fmaf(sg, epc.v[t], mu[i].v[t]);
+            const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
+            gm.v[t] = gout * (gz + c * mu[i].v[t]);
+            gv.v[t] = gout * signf(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) { gm.v[t] = 0.f; gv.v[t] = 0.f; }
+        }
+        if constexpr (ADAM) {
+          Chunk<VEC> pm, ps;
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            pm.v[t] = adam_update(mu[i].v[t], gm.v[t], mm[i].v[t], vm[i].v[t], ad);
+            ps.v[t] = adam_update(s[i].v[t], gv.v[t], ms[i].v[t], vs[i].v[t], ad);
+          }
+          const size_t o2 = (size_t)e * (2 * (size_t)d) + (size_t)j * VEC;
+          st_chunk<VEC>(prow + (size_t)j * VEC, pm);
+          st_chunk<VEC>(prow + d + (size_t)j * VEC, ps);
+          st_chunk_nt<VEC>(ad.m_entity + o2, mm[i]); st_chunk_nt<VEC>(ad.m_entity + o2 + d, ms[i]);
+          st_chunk_nt<VEC>(ad.v_entity + o2, vm[i]); st_chunk_nt<VEC>(ad.v_entity + o2 + d, vs[i]);
+        } else {
+          st_chunk_nt<VEC>(grow_e + (size_t)j * VEC, gm);
+          st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, gv);
+        }
+      }
+    }
+    if (lig == 0) {
+      float g0 = 0.f, g1 = 0.f;
+      if (touched) {
+        if constexpr (EPS == EPS_TABLE) nb_eps = epw;
+        const float sg = fabsf(th.y);
+        g0 = gout * (gs + c * th.x);
+        g1 = gout * signf(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
+      }
+      if constexpr (ADAM) {
+        float2 pn;
+        pn.x = adam_update(th.x, g0, mb.x, vb.x, ad);
+        pn.y = adam_update(th.y, g1, mb.y, vb.y, ad);
+        *reinterpret_cast<float2*>(const_cast<float*>(a.bias) + 2 * (size_t)e) = pn;
+        *reinterpret_cast<float2*>(ad.m_bias + 2 * (size_t)e) = mb;
+        *reinterpret_cast<float2*>(ad.v_bias + 2 * (size_t)e) = vb;
+      } else {
+        *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(g0, g1);
+      }
+    }
+  }
+}
