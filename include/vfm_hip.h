@@ -50,6 +50,12 @@ extern "C" {
 #define VFM_FLAG_SPARSE_ADAM 4    /* vfm_elbo_bwd_adam_f32 only, OPT-IN, changes results: rows that are not
                                      in the batch are skipped (no momentum drift), unlike the reference's
                                      dense Adam (vfm-torch.py:339); bias corrections use the global step   */
+#define VFM_FLAG_ZPRE 8           /* vfm_elbo_fwd_f32: `entity_params` holds PRECOMPUTED samples, one record
+                                     (w, 0, 0, 0 | z[0..d-1]) of 4 + round4(d) floats per slot, and x holds
+                                     slot numbers (entity-sharded mode: the owner of an entity samples it
+                                     once -- vfm_shard_sample_f32 -- and ships z instead of mu and s); no
+                                     KL term is formed (the owner adds it), bias_params / inv_occ / W may be
+                                     NULL, eps_global alone may be given                                    */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 
@@ -93,6 +99,10 @@ typedef struct vfm_problem {
    * multi-rank step cut the table in chunks and overlap the exchange of one chunk with the kernels
    * of its neighbours.  The forward ignores it. */
   int64_t e_lo, e_hi;
+  /* entity-sharded mode (tables partitioned over N ranks by e mod N): vfm_elbo_apply_adam_f32 then
+   * handles the owned entities e = own_rank + li * own_mod, li in [e_lo, e_hi) (LOCAL indices; the
+   * statistics records are indexed by li).  own_mod <= 1: not sharded. */
+  int32_t own_mod, own_rank;
 } vfm_problem_t;
 
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
@@ -210,7 +220,20 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, void* stream);
+                            float beta2, float eps_adam, int64_t step, double* kl_ws, void* stream);
+
+/* Entity-sharded multi-rank mode (tables partitioned by e mod N; every rank keeps rows of the batch).
+ * Per step: (1) every owner samples the entities other ranks asked for -- vfm_shard_sample_f32 writes one
+ * record (w, 0, 0, 0 | z) per requested id -- and the records travel in an all-to-all; (2) the forward
+ * runs on slot numbers with VFM_FLAG_ZPRE; (3) vfm_elbo_bwd_acc_f32 over the slots gives the statistics
+ * records, which travel back in a second all-to-all; (4) the owner adds the records of each source rank
+ * into its dense table of local records with vfm_records_add_f32 and (5) calls
+ * vfm_elbo_apply_adam_f32 with own_mod / own_rank set (kl_ws, 1 + 4096 doubles, receives in [0] the
+ * owner's share of the KL term: sum of c_e * KL_e over its entities in the batch). */
+int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
+                         const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
+                         void* stream);
+int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, void* stream);
 
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of

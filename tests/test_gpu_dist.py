@@ -103,3 +103,60 @@ def test_fit_two_ranks_matches_single_rank(tmp_path):
     assert np.array_equal(p0, p1)
     assert rel_err(p0, m._flat.cpu().numpy()) < 1e-4
     assert rel_err(np.load(tmp_path / "elbo_0.npy"), np.array(h["elbo"])) < 1e-4
+
+
+def _sharded_worker(rank, world, port, name, out_dir, use_tables):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import shard_rows
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    m = _make_model(c, dev)
+    m.exchange = "sharded"
+    eps = None
+    if use_tables:
+        e0, ew, ev = c.eps("f32")
+        eps = (torch.tensor(ev, device=dev), torch.tensor(ew, device=dev), torch.tensor(e0, device=dev))
+    B = len(c.y)
+    losses = []
+    a, b = shard_rows(0, B, rank, world)
+    plan = m.plan(torch.tensor(c.x[a:b]), torch.tensor(c.y[a:b]), B_global=B, process_group=dist.group.WORLD)
+    for step in range(3):
+        loss3, _ = m.train_step(plan, lr=0.05, eps=eps, process_group=dist.group.WORLD)
+        losses.append(loss3.cpu().numpy().copy())
+    m.sync_params(dist.group.WORLD)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"sh_params_{rank}.npy"), m._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"sh_loss_{rank}.npy"), np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,use_tables", [("ml100k_reg_d20", True), ("ml100k_reg_d20", False),
+                                             ("dup_class_d12", True)])
+def test_entity_sharded_step_matches_one_rank(name, use_tables, world, tmp_path):
+    """Entity-sharded mode (tables partitioned by e mod N, two all-to-alls per step) == the 1-rank step:
+    losses, and after sync_params every parameter."""
+    mp.spawn(_sharded_worker, args=(world, _free_port(), name, str(tmp_path), use_tables), nprocs=world, join=True)
+    c = Case(name)
+    dev = torch.device("cuda:0")
+    m = _make_model(c, dev)
+    eps = None
+    if use_tables:
+        e0, ew, ev = c.eps("f32")
+        eps = (torch.tensor(ev, device=dev), torch.tensor(ew, device=dev), torch.tensor(e0, device=dev))
+    plan = m.plan(torch.tensor(c.x), torch.tensor(c.y))
+    ref_losses = []
+    for step in range(3):
+        loss3, _ = m.train_step(plan, lr=0.05, eps=eps, fused=False)
+        ref_losses.append(loss3.cpu().numpy().copy())
+    want = m._flat.cpu().numpy()
+    ps = [np.load(tmp_path / f"sh_params_{r}.npy") for r in range(world)]
+    n_tab = m._off_scal                                    # tables (entity + bias): identical after sync_params
+    for p in ps[1:]:
+        assert np.array_equal(ps[0][:n_tab], p[:n_tab])
+        assert np.allclose(ps[0][n_tab:], p[n_tab:], rtol=1e-6)    # replicated scalars
+    assert rel_err(ps[0], want) < 2e-5
+    l0 = np.load(tmp_path / "sh_loss_0.npy")
+    assert rel_err(l0[:, 0], np.array(ref_losses)[:, 0]) < 1e-5

@@ -28,6 +28,7 @@ EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
+    "vfm_shard_sample_f32", "vfm_records_add_f32",
 )
 
 
@@ -39,6 +40,7 @@ class Problem(C.Structure):
         ("n_samples", C.c_int32), ("reserved", C.c_int32),
         ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
         ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
+        ("own_mod", C.c_int32), ("own_rank", C.c_int32),
     ]
 
 
@@ -87,7 +89,9 @@ def load():
                                  i64, vp]
     lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 7
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
-                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
+                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
+    lib.vfm_shard_sample_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":

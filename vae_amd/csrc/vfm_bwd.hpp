@@ -154,15 +154,20 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 
   const int64_t stride = (int64_t)gridDim.x * GPB;
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);          // floats per exchange record
-  int64_t e = a.e_lo + (int64_t)blockIdx.x * GPB + tid / LPE;
+  // entity-sharded apply (own_mod > 1): this rank owns the entities e = own_rank + li * own_mod; the
+  // loop runs over the local index li and the statistics records are indexed by li
+  const bool sharded = STAGE == STAGE_APPLY && a.own_mod > 1;
+  float klacc = 0.f;                                   // sum of c_e * KL_e over this thread's entities
+  int64_t li = a.e_lo + (int64_t)blockIdx.x * GPB + tid / LPE;
   int2 pq = make_int2(0, 0);
-  if (STAGE != STAGE_APPLY && e < a.e_hi) pq = make_int2(b.occ_ptr[e], b.occ_ptr[e + 1]);
-  for (; e < a.e_hi; e += stride) {
+  if (STAGE != STAGE_APPLY && li < a.e_hi) pq = make_int2(b.occ_ptr[li], b.occ_ptr[li + 1]);
+  for (; li < a.e_hi; li += stride) {
+    const int64_t e = sharded ? (int64_t)a.own_rank + li * a.own_mod : li;
     int beg = pq.x, end = pq.y;
-    const int64_t en = e + stride;
+    const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
     if constexpr (STAGE == STAGE_APPLY) {
-      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)e * xs);   // (sum of grow, occurrences) over ALL ranks
+      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)li * xs);   // (sum of grow, occurrences) over ALL ranks
       beg = 0; end = 0;
     } else {
       if (en < a.e_hi) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int j = lig + i * LPE;
-          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC);
+          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)li * xs + 4 + (size_t)j * VEC);
         }
       }
     }
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
             const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
             gm.v[t] = gout * (gz + c * mu[i].v[t]);
             gv.v[t] = gout * signf(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
+            if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(mu[i].v[t], sg), klacc);
           }
         } else {
 #pragma unroll
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         const float sg = fabsf(th.y);
         g0 = gout * (gs + c * th.x);
         g1 = gout * signf(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
+        if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(th.x, sg), klacc);
       }
       if constexpr (ADAM) {
         float2 pn;
@@ -363,6 +370,15 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       } else {
         *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(g0, g1);
       }
+    }
+  }
+  if (STAGE == STAGE_APPLY && b.kl_slots) {       // uniform; per-block KL partial for the owner's loss term
+    __shared__ float sh_kl[4];
+    float v1[1] = {klacc};
+    block_sum<1>(v1, sh_kl);
+    if (tid == 0) {
+      b.kl_slots[1 + blockIdx.x] = (double)v1[0];
+      if (blockIdx.x == 0) b.kl_slots[0] = (double)gridDim.x;
     }
   }
 }

@@ -8,6 +8,7 @@
 struct KArgs {
   int64_t B, T;
   int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
+  int32_t own_mod, own_rank;   // entity-sharded apply: this rank owns e = own_rank (mod own_mod)
   int32_t F, d, lik, id64, G, flags;
   float ll_scale;  // nb_train / B_global
   double ll_scale_d;
@@ -52,6 +53,7 @@ struct BwdArgs {
   const int32_t* heavy_ids;   // [n_heavy] sorted
   const float* heavy_acc;     // [n_heavy, 4 + round4(d)] records (sum grow, count, 0, 0 | A_e)
   int32_t n_heavy;
+  double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
 };
 
 template <int VEC>

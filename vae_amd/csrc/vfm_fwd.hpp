@@ -14,7 +14,9 @@
 // KL arithmetic of the previous row runs.  FF = 2 keeps both fields of a row in registers
 // (the reference's user/item case); FF = 0 streams a runtime number of fields.
 // ---------------------------------------------------------------------------------------
-enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2 };
+// EPS_ZPRE: the "table" holds precomputed samples, one record (w, 0, 0, 0 | z[0..d-1]) per slot
+// (entity-sharded multi-rank mode: the owner of an entity samples it once and ships z, not mu / s)
+enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3 };
 enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
 
 template <int CPL, int VEC, int EPS>
@@ -31,6 +33,20 @@ __device__ __forceinline__ void load_field(const KArgs& a, uint32_t e, int lig, 
                                            FieldRegs<CPL, VEC, EPS>& R) {
   const int d = a.d;
   R.e = e;
+  if constexpr (EPS == EPS_ZPRE) {
+    const float* rec = a.entity + (size_t)e * (4 + (((size_t)d + 3) & ~(size_t)3));
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      int j = lig + i * LPE;
+      j = j < C ? j : C - 1;
+      R.mu[i] = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);     // z itself
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) R.s[i].v[t] = 0.f;
+    }
+    R.th = make_float2(rec[0], 0.f);                           // the sampled first-order weight
+    R.io = 0.f;                                                // KL is the owner's business
+    return;
+  }
   const float* row = a.entity + (size_t)e * (2 * (size_t)d);
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -147,7 +163,7 @@ __device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CP
     if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
       for (int t = 0; t < VEC; ++t) ep[t] = R.ep[i].v[t];
-    } else if constexpr (EPS == EPS_ZERO) {
+    } else if constexpr (EPS == EPS_ZERO || EPS == EPS_ZPRE) {
 #pragma unroll
       for (int t = 0; t < VEC; ++t) ep[t] = 0.f;
     } else {
@@ -183,7 +199,7 @@ __device__ __forceinline__ void consume_row2(const KArgs& a, const FieldRegs<CPL
     if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) { ep0[t] = R0.ep[i].v[t]; ep1[t] = R1.ep[i].v[t]; }
-    } else if constexpr (EPS == EPS_ZERO) {
+    } else if constexpr (EPS == EPS_ZERO || EPS == EPS_ZPRE) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) { ep0[t] = 0.f; ep1[t] = 0.f; }
     } else {
@@ -270,17 +286,21 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   const int C = (a.d + VEC - 1) / VEC;
 
   if (MODE == MODE_TRAIN && tid < a.G) {
-    sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
+    sh_cs[tid] = (EPS == EPS_ZPRE) ? 0.f : (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = fabsf(alpha);
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
-  if constexpr (EPS == EPS_PHILOX) {
-    float n[8], nb;
-    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
-    e0 = n[0];
+  if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZPRE) {     // (ZPRE: the scalars are replicated, w0 is local)
+    if (EPS == EPS_ZPRE && a.eps_global) {
+      e0 = a.eps_global[0];
+    } else {
+      float n[8], nb;
+      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      e0 = n[0];
+    }
   }
   const float w0 = fmaf(fabsf(s0), e0, m0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);

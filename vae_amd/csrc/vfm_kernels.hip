@@ -49,6 +49,7 @@ constexpr float LN2 = 0.693147180559945309f;
 #include "vfm_small_kernels.hpp"
 #include "vfm_fwd.hpp"
 #include "vfm_bwd.hpp"
+#include "vfm_shard.hpp"
 #include "vfm_adam.hpp"
 
 // ---------------------------------------------------------------------------------------
@@ -87,6 +88,7 @@ int check_problem(const vfm_problem_t* p) {
   if (p->B_global < p->B) return fail(VFM_E_INVALID, "B_global < B");
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
   if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
+  if (p->own_mod > 1 && (p->own_rank < 0 || p->own_rank >= p->own_mod)) return fail(VFM_E_INVALID, "bad ownership (own_rank, own_mod)");
   Shape s;
   if (!pick_shape(p->d, &s)) return fail(VFM_E_UNSUPPORTED, "embedding size d not supported (d%4==0: d<=1024, else d<=256)");
   return 0;
@@ -100,6 +102,7 @@ int env_int(const char* name, int dflt) {
 // eps source of a call: VFM_FLAG_EPS_ZERO > tables > Philox
 int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const float* eg, int* mode) {
   const int neps = (ee != nullptr) + (eb != nullptr) + (eg != nullptr);
+  if ((p->flags & VFM_FLAG_ZPRE) && neps <= 1 && (neps == 0 || eg)) { *mode = EPS_ZPRE; return 0; }
   if (neps != 0 && neps != 3) return fail(VFM_E_INVALID, "give all three eps tables or none");
   *mode = (p->flags & VFM_FLAG_EPS_ZERO) ? EPS_ZERO : (neps == 3 ? EPS_TABLE : EPS_PHILOX);
   return 0;
@@ -112,6 +115,7 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   memset(&a, 0, sizeof(a));
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.lik = p->likelihood;
   a.e_lo = p->e_lo; a.e_hi = (p->e_hi > 0 && p->e_hi < p->T) ? p->e_hi : p->T;
+  a.own_mod = p->own_mod > 1 ? p->own_mod : 1; a.own_rank = p->own_mod > 1 ? p->own_rank : 0;
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
   a.ll_scale_d = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
   a.ll_scale = (float)a.ll_scale_d;
@@ -151,7 +155,7 @@ int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream
     }                                                                            \
     return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0, true>(a, o, st);               \
   }
-  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN)
+  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN) FWD(EPS_ZPRE, MODE_TRAIN)
   FWD(EPS_PHILOX, MODE_PREDICT) FWD(EPS_TABLE, MODE_PREDICT) FWD(EPS_ZERO, MODE_PREDICT)
 #undef FWD
   return fail(VFM_E_UNSUPPORTED, "forward: unsupported eps source / mode combination");
@@ -296,15 +300,18 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
     hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st0, partials, (int)VFM_N_PARTIALS);
     return after_launch("vfm_elbo_fwd_f32");
   }
-  if (!x || !entity_params || !bias_params || !scalars || !pred)
+  const bool zpre = (p->flags & VFM_FLAG_ZPRE) != 0;
+  if (!x || !entity_params || (!bias_params && !zpre) || !scalars || !pred)
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: NULL pointer");
   const bool train = y != nullptr;
-  if (train && (!inv_occ || !W || !sumz || !grow))
+  if (train && (((!inv_occ || !W) && !zpre) || !sumz || !grow))
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: y given, so inv_occ, W, sumz and grow are required");
+  if (zpre && !train) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_ZPRE needs y (training forward)");
   if (!train && (sumz || grow)) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: sumz / grow need y");
   int eps;
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
   if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
+  if (zpre) eps = EPS_ZPRE;
   hipStream_t st = (hipStream_t)stream;
   KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
@@ -414,7 +421,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, void* stream) {
+                            float beta2, float eps_adam, int64_t step, double* kl_ws, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
@@ -425,13 +432,55 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
   BwdArgs b{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0};
+            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, kl_ws};
+  if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
+    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
+  if (kl_ws) hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, kl_ws);
   return after_launch("vfm_elbo_apply_adam_f32");
+}
+
+int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
+                         const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
+                         void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (n < 0 || n > 0x7FFFFFFFLL || (n > 0 && (!ids || !entity_params || !bias_params || !out)))
+    return fail(VFM_E_INVALID, "vfm_shard_sample_f32: bad argument");
+  if ((eps_entity == nullptr) != (eps_bias == nullptr))
+    return fail(VFM_E_INVALID, "vfm_shard_sample_f32: give both eps tables or none");
+  if (n == 0) return 0;
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, nullptr, nullptr, nullptr, eps_entity,
+                      eps_bias, nullptr);
+  Shape s;
+  pick_shape(p->d, &s);
+  hipStream_t st = (hipStream_t)stream;
+#define X(L_, C_, V_)                                                                              \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                 \
+    constexpr int GPB = BLOCK / L_;                                                                \
+    int64_t nb = (n + GPB - 1) / GPB;                                                              \
+    if (nb > 4096) nb = 4096;                                                                      \
+    if (eps_entity)                                                                                \
+      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_TABLE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, (int)n, out); \
+    else                                                                                           \
+      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_PHILOX>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, (int)n, out); \
+  }
+  FOR_SHAPES(X)
+#undef X
+  return after_launch("vfm_shard_sample_f32");
+}
+
+int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, void* stream) {
+  if (n < 0 || d < 1 || (n > 0 && (!dst || !idx || !src))) return fail(VFM_E_INVALID, "vfm_records_add_f32: bad argument");
+  if (n == 0) return 0;
+  const int xs4 = 1 + (d + 3) / 4;
+  int64_t nb = (n * xs4 + BLOCK - 1) / BLOCK;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_records_add, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n, xs4);
+  return after_launch("vfm_records_add_f32");
 }
 
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -84,3 +84,20 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partial
   double tot[5];
   reduce_slots_and_loss(partials, scalars, ll_scale, flags, loss, sh, tot);
 }
+
+// ws[0] <- sum of ws[1 .. (int)ws[0]]  (per-block partial sums written by a preceding kernel)
+__global__ __launch_bounds__(BLOCK) void k_sum_slots(double* __restrict__ ws) {
+  __shared__ double sh[BLOCK / 64];
+  const int n = (int)ws[0];
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += BLOCK) acc += ws[1 + i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+    ws[0] = t;
+  }
+}

@@ -216,15 +216,22 @@ void elbo_apply_adam(const Tensor& acc, const Tensor& sums, Tensor entity, Tenso
                      Tensor v_entity, Tensor m_bias, Tensor v_bias, Tensor m_scalars, Tensor v_scalars, int64_t F,
                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global,
                      int64_t likelihood, int64_t flags, int64_t seed, int64_t step, double lr, double beta1,
-                     double beta2, double eps_adam, int64_t adam_step, int64_t e_lo, int64_t e_hi) {
+                     double beta2, double eps_adam, int64_t adam_step, int64_t e_lo, int64_t e_hi,
+                     int64_t own_mod, int64_t own_rank, const optional<Tensor>& kl_ws) {
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
-  TORCH_CHECK(acc.numel() >= T * rec_len(d) && sums.numel() >= 2, "apply_adam sizes");
+  const int64_t n_rec = own_mod > 1 ? (T - own_rank + own_mod - 1) / own_mod : T;
+  TORCH_CHECK(acc.numel() >= n_rec * rec_len(d) && sums.numel() >= 2, "apply_adam sizes");
+  double* klp = nullptr;
+  if (kl_ws.has_value() && kl_ws->defined()) {
+    TORCH_CHECK(kl_ws->numel() >= 4097, "kl_ws needs 4097 doubles");
+    klp = dev_tensor(*kl_ws, at::kDouble, "kl_ws").data_ptr<double>();
+  }
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel(), "Adam moment shapes");
   c10::hip::HIPGuard guard(entity.get_device());
   vfm_problem_t p = problem(entity, 0, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step);
-  p.e_lo = e_lo; p.e_hi = e_hi;
+  p.e_lo = e_lo; p.e_hi = e_hi; p.own_mod = (int32_t)own_mod; p.own_rank = (int32_t)own_rank;
   check(vfm_elbo_apply_adam_f32(
             &p, dev_tensor(acc, at::kFloat, "acc").data_ptr<float>(), dev_tensor(sums, at::kFloat, "sums").data_ptr<float>(),
             entity.data_ptr<float>(), bias.data_ptr<float>(), dev_tensor(scalars, at::kFloat, "scalars").data_ptr<float>(),
@@ -235,8 +242,58 @@ void elbo_apply_adam(const Tensor& acc, const Tensor& sums, Tensor entity, Tenso
             dev_tensor(m_bias, at::kFloat, "m_bias").data_ptr<float>(), dev_tensor(v_bias, at::kFloat, "v_bias").data_ptr<float>(),
             dev_tensor(m_scalars, at::kFloat, "m_scalars").data_ptr<float>(),
             dev_tensor(v_scalars, at::kFloat, "v_scalars").data_ptr<float>(), (float)lr, (float)beta1, (float)beta2,
-            (float)eps_adam, adam_step, stream_of(entity)),
+            (float)eps_adam, adam_step, klp, stream_of(entity)),
         "vfm_elbo_apply_adam_f32");
+}
+
+// ---- entity-sharded mode ----
+void elbo_fwd_zpre(const Tensor& x, const Tensor& y, const Tensor& zbuf, const Tensor& scalars,
+                   const optional<Tensor>& eps_global, Tensor pred, Tensor partials, Tensor sumz, Tensor grow,
+                   int64_t d, int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed,
+                   int64_t step) {
+  const Ids id = ids_of(x);
+  dev_tensor(zbuf, at::kFloat, "zbuf"); dev_tensor(scalars, at::kFloat, "scalars");
+  dev_tensor(pred, at::kFloat, "pred"); dev_tensor(partials, at::kDouble, "partials");
+  TORCH_CHECK(zbuf.numel() % rec_len(d) == 0, "zbuf must hold whole records");
+  const int64_t U = zbuf.numel() / rec_len(d);
+  TORCH_CHECK(pred.numel() >= id.B && partials.numel() >= VFM_PARTIALS_LEN && sumz.numel() >= id.B * d &&
+              grow.numel() >= id.B, "output sizes");
+  c10::hip::HIPGuard guard(x.get_device());
+  std::vector<int64_t> hi((size_t)id.F, U > 0 ? U : 1);
+  std::vector<double> gn((size_t)id.F, 1.0);
+  vfm_problem_t p = problem(x, id.B, B_global, U > 0 ? U : 1, id.F, d, nb_train, likelihood, id.id_bits,
+                            flags | VFM_FLAG_ZPRE, hi, gn, seed, step);
+  check(vfm_elbo_fwd_f32(&p, id.ptr, dev_tensor(y, at::kFloat, "y").data_ptr<float>(), zbuf.data_ptr<float>(),
+                         nullptr, nullptr, scalars.data_ptr<float>(), nullptr, nullptr, nullptr,
+                         fptr(eps_global, "eps_global"), pred.data_ptr<float>(), partials.data_ptr<double>(),
+                         dev_tensor(sumz, at::kFloat, "sumz").data_ptr<float>(),
+                         dev_tensor(grow, at::kFloat, "grow").data_ptr<float>(), stream_of(x)),
+        "vfm_elbo_fwd_f32 (ZPRE)");
+}
+
+void shard_sample(const Tensor& ids, const Tensor& entity, const Tensor& bias, const optional<Tensor>& eps_entity,
+                  const optional<Tensor>& eps_bias, Tensor out, int64_t seed, int64_t step) {
+  dev_tensor(ids, at::kInt, "ids"); dev_tensor(entity, at::kFloat, "entity_params");
+  dev_tensor(bias, at::kFloat, "bias_params"); dev_tensor(out, at::kFloat, "out");
+  const int64_t T = entity.size(0), d = entity.size(1) / 2, n = ids.numel();
+  TORCH_CHECK(out.numel() >= n * rec_len(d), "out too small");
+  c10::hip::HIPGuard guard(entity.get_device());
+  std::vector<int64_t> hi(1, T);
+  std::vector<double> gn(1, 1.0);
+  vfm_problem_t p = problem(entity, 0, 0, T, 1, d, 1, 0, 64, 0, hi, gn, seed, step);
+  check(vfm_shard_sample_f32(&p, ids.data_ptr<int32_t>(), n, entity.data_ptr<float>(), bias.data_ptr<float>(),
+                             fptr(eps_entity, "eps_entity"), fptr(eps_bias, "eps_bias"), out.data_ptr<float>(),
+                             stream_of(entity)),
+        "vfm_shard_sample_f32");
+}
+
+void records_add(Tensor dst, const Tensor& idx, const Tensor& src, int64_t d) {
+  dev_tensor(dst, at::kFloat, "dst"); dev_tensor(idx, at::kInt, "idx"); dev_tensor(src, at::kFloat, "src");
+  TORCH_CHECK(src.numel() >= idx.numel() * rec_len(d), "src too small");
+  c10::hip::HIPGuard guard(dst.get_device());
+  check(vfm_records_add_f32(dst.data_ptr<float>(), idx.data_ptr<int32_t>(), src.data_ptr<float>(), idx.numel(),
+                            (int32_t)d, stream_of(dst)),
+        "vfm_records_add_f32");
 }
 
 void adam(Tensor p, const Tensor& g, Tensor m, Tensor v, double lr, double beta1, double beta2, double eps,
@@ -280,7 +337,13 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, Tensor(g!) v_bias, Tensor(h!) m_scalars, "
         "Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, "
         "int flags, int seed, int step, float lr, float beta1, float beta2, float eps_adam, int adam_step, "
-        "int e_lo, int e_hi) -> ()", &elbo_apply_adam);
+        "int e_lo, int e_hi, int own_mod, int own_rank, Tensor(j!)? kl_ws) -> ()", &elbo_apply_adam);
+  m.def("elbo_fwd_zpre(Tensor x, Tensor y, Tensor zbuf, Tensor scalars, Tensor? eps_global, Tensor(a!) pred, "
+        "Tensor(b!) partials, Tensor(c!) sumz, Tensor(d!) grow, int d, int nb_train, int B_global, int likelihood, "
+        "int flags, int seed, int step) -> ()", &elbo_fwd_zpre);
+  m.def("shard_sample(Tensor ids, Tensor entity_params, Tensor bias_params, Tensor? eps_entity, Tensor? eps_bias, "
+        "Tensor(a!) out, int seed, int step) -> ()", &shard_sample);
+  m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d) -> ()", &records_add);
   m.def("adam(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
         "int step) -> ()", &adam);
 }

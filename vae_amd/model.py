@@ -202,6 +202,11 @@ class VFM(nn.Module):
             y = torch.as_tensor(y).to(self.device)
             if self.inv_occ is None:
                 raise RuntimeError("call set_training_data() before building training plans")
+        if process_group is not None and self.exchange == "sharded" and y is not None:
+            from .sharded import ShardedPlan
+            return ShardedPlan(self.spec(), x, y, self.inv_occ, B_global if B_global is not None else x.shape[0],
+                               process_group, torch.distributed.get_rank(process_group),
+                               torch.distributed.get_world_size(process_group))
         return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
                              build_index=build_index and y is not None, process_group=process_group)
 
@@ -245,6 +250,12 @@ class VFM(nn.Module):
         st = ops.elbo_forward(plan, ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
         return st.pred
 
+    def sync_params(self, process_group):
+        """Entity-sharded mode: refresh the parameter rows owned by the other ranks (all-gather)."""
+        from .sharded import sync_params
+        sync_params(self, process_group, torch.distributed.get_rank(process_group),
+                    torch.distributed.get_world_size(process_group))
+
     @torch.no_grad()
     def save_weights(self):
         """Snapshot the posterior means and update their running average over epochs
@@ -281,6 +292,16 @@ class VFM(nn.Module):
         bounds = [self.T * i // k for i in range(k + 1)]
         return f[:n], f[n: n + 2], f[n + 4: n + 7], bounds
 
+    def _ensure_shard_state(self, world, rank):
+        """Buffers of the entity-sharded step: dense local statistics records, small exchange vector,
+        KL workspace."""
+        if getattr(self, "_shard_acc", None) is None:
+            from .sharded import owned_rows
+            rl = ops.exchange_record_len(self.d)
+            self._shard_acc = torch.zeros(owned_rows(self.T, rank, world) * rl, dtype=torch.float32, device=self.device)
+            self._shard_small = torch.zeros(16, dtype=torch.float32, device=self.device)
+            self._shard_klws = torch.zeros(4097, dtype=torch.float64, device=self.device)
+
     def _step_buffers(self, B):
         """Persistent per-step training state (sumz [B,d], grow [B], pred [B]) -- no allocator
         traffic inside the step."""
@@ -303,6 +324,11 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
+        if process_group is not None and self.exchange == "sharded":
+            from .sharded import train_step_sharded
+            if not adam:
+                raise ValueError("the entity-sharded step always applies Adam")
+            return train_step_sharded(self, plan, lr, eps=eps, out_pred=out_pred, mark=mark)
         ent, bia, scal = self._views(self._flat)
         g_ent, g_bias, g_scal = self._views(self._gflat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
@@ -404,6 +430,8 @@ class VFM(nn.Module):
                 losses[i] = loss3[0]
             # ---- end of epoch (vfm-torch.py:378-384)
             if self.output == "reg":
+                if world > 1 and self.exchange == "sharded":
+                    self.sync_params(process_group)
                 self.save_weights()
             if epoch % display_every == 0:
                 rec = {"epoch": epoch, "elbo": float(losses.mean())}
@@ -417,6 +445,8 @@ class VFM(nn.Module):
                 else:
                     rec["train_auc"], rec["train_map"] = _auc_map(yd, torch.sigmoid(tp))
                 if X_test is not None:
+                    if world > 1 and self.exchange == "sharded":
+                        self.sync_params(process_group)        # rows owned by other ranks are stale
                     rec["test"] = self.evaluate(X_test, y_test)
                 hist["epoch"].append(epoch)
                 hist["elbo"].append(rec["elbo"])
