@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "stats", "grads", "sharded"],
+                    help="what ranks exchange per step when N>1 (see DESIGN.md section 6)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the global batch stays at --batch rows and is split over the ranks "
                          "(SURVEY cfg4); default is weak scaling, --batch rows per rank")
@@ -95,6 +97,7 @@ def main():
 
     torch.manual_seed(42)
     model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
+    model.exchange = args.exchange
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -118,7 +121,7 @@ def main():
             xb, yb = xb[o].contiguous(), yb[o].contiguous()
         p = model.plan(xb, yb, B_global=B * world, process_group=pg)
         plans.append(p)
-        uniq.append(int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
+        uniq.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
     U = sum(uniq) / len(uniq)
 
     events = []
@@ -160,6 +163,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
         dt = float(t.item())
     loss = float(model._gflat[model._n_flat].item())
+    if world > 1 and model.exchange == "sharded":
+        model.sync_params(pg)
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region
@@ -183,20 +188,26 @@ def main():
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
                "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
                # all-reduce of the statistics overlapped with the epilogue + dense Adam kernels
-               "exchange_apply_adam": 4.0 * model.T * (d + 2) + 24.0 * n_params}
+               "exchange_apply_adam": 4.0 * model.T * (d + 2) + 24.0 * n_params,
+               # entity-sharded form (per rank): records of the touched entities travel twice
+               "sample_a2a": U * (8 * d + 8) + 2 * 4.0 * U * (d + 4), "acc_a2a": B * F * (4 * d + 8) + 2 * 4.0 * U * (d + 4),
+               "apply_adam": 24.0 * n_params / max(world, 1) + 4.0 * U * (d + 4)}
         alg["allreduce"] = 4.0 * n_params
         names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
                  "exchange_apply_adam": "RCCL all-reduce of the statistics, chunk-overlapped with "
-                                        "k_bwd<APPLY,ADAM> (epilogue + dense Adam)"}
+                                        "k_bwd<APPLY,ADAM> (epilogue + dense Adam)",
+                 "sample_a2a": "k_sample (owners) + all-to-all of (w | z) records",
+                 "acc_a2a": "k_bwd<ACC> over slots + all-to-all of statistics records",
+                 "apply_adam": "k_records_add + k_bwd<APPLY,ADAM> on owned rows + scalar all-reduce"}
         for k, ms in acc.items():
             us = ms / len(events) * 1e3
             gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0
             kern[k] = {"kernel": names[k], "avg_us": round(us, 2), "alg_bytes": int(alg[k]),
                        "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        cand = [k for k in kern if k not in ("finalize", "allreduce", "exchange_apply_adam")]
+        cand = [k for k in kern if k in ("fwd", "bwd", "bwd_adam", "bwd_acc", "adam")]
         dom = max(cand, key=lambda k: kern[k]["avg_us"])
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
@@ -253,6 +264,7 @@ def main():
                        "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
+                       "exchange": model.exchange if world > 1 else None,
                        "step": ("fwd+loss+bwd_acc+allreduce(stats)+apply_adam" if world > 1 else "fwd+loss+bwd+dense-adam") if
                                (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
                        "parallelism": f"row-sharded dp{world}"},

@@ -88,7 +88,9 @@ class VFM(nn.Module):
         self.sparse_adam = bool(sparse_adam)
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
-        self.exchange = "stats"
+        # "sharded" = entity-sharded tables (vae_amd/sharded.py); "auto" picks "sharded" when the table is
+        # much larger than what a batch touches (T > 4 * rows * fields), else "stats"
+        self.exchange = "auto"
         self.exchange_chunks = 4
         self._xflat = None
 
@@ -202,6 +204,9 @@ class VFM(nn.Module):
             y = torch.as_tensor(y).to(self.device)
             if self.inv_occ is None:
                 raise RuntimeError("call set_training_data() before building training plans")
+        if process_group is not None and self.exchange == "auto" and y is not None:
+            rows = int(B_global) if B_global is not None else int(x.shape[0])
+            self.exchange = "sharded" if self.T > 4 * rows * self.F else "stats"
         if process_group is not None and self.exchange == "sharded" and y is not None:
             from .sharded import ShardedPlan
             return ShardedPlan(self.spec(), x, y, self.inv_occ, B_global if B_global is not None else x.shape[0],
