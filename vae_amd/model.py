@@ -88,8 +88,9 @@ class VFM(nn.Module):
         self.sparse_adam = bool(sparse_adam)
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
-        # "sharded" = entity-sharded tables (vae_amd/sharded.py); "auto" picks "sharded" when the table is
-        # much larger than what a batch touches (T > 4 * rows * fields), else "stats"
+        # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
+        # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
+        # "auto" picks it unless the whole statistics table is tiny (< 4 MB: one small all-reduce wins).
         self.exchange = "auto"
         self.exchange_chunks = 4
         self._xflat = None
@@ -205,8 +206,8 @@ class VFM(nn.Module):
             if self.inv_occ is None:
                 raise RuntimeError("call set_training_data() before building training plans")
         if process_group is not None and self.exchange == "auto" and y is not None:
-            rows = int(B_global) if B_global is not None else int(x.shape[0])
-            self.exchange = "sharded" if self.T > 4 * rows * self.F else "stats"
+            table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
+            self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
         if process_group is not None and self.exchange == "sharded" and y is not None:
             from .sharded import ShardedPlan
             return ShardedPlan(self.spec(), x, y, self.inv_occ, B_global if B_global is not None else x.shape[0],
