@@ -233,7 +233,14 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
 int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
                          const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
                          void* stream);
-int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, void* stream);
+/* atomic == 0: plain adds, idx must not repeat inside one call (one call per source rank: deterministic);
+ * atomic != 0: float atomics, idx may repeat (all source ranks in one launch). */
+int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, int32_t atomic,
+                        void* stream);
+/* glue of the sharded step, one thread each: small[2..4] <- (loss_local[1], loss_local[2], kl_ws[0]) before
+ * the 8-float all-reduce; loss3 <- (nll + kl, nll, kl) from the summed vector after it. */
+int vfm_shard_pack_f32(float* small, const float* loss_local, const double* kl_ws, void* stream);
+int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
 
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of

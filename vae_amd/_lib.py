@@ -28,7 +28,7 @@ EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
-    "vfm_shard_sample_f32", "vfm_records_add_f32",
+    "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
 )
 
 
@@ -91,7 +91,9 @@ def load():
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
                                             [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_shard_sample_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
-    lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, vp]
+    lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+    lib.vfm_shard_pack_f32.argtypes = [vp, vp, vp, vp]
+    lib.vfm_shard_loss_f32.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":

@@ -473,14 +473,31 @@ int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, 
   return after_launch("vfm_shard_sample_f32");
 }
 
-int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, void* stream) {
+int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, int32_t atomic,
+                        void* stream) {
   if (n < 0 || d < 1 || (n > 0 && (!dst || !idx || !src))) return fail(VFM_E_INVALID, "vfm_records_add_f32: bad argument");
   if (n == 0) return 0;
   const int xs4 = 1 + (d + 3) / 4;
-  int64_t nb = (n * xs4 + BLOCK - 1) / BLOCK;
+  int64_t nb = (n * xs4 * (atomic ? 4 : 1) + BLOCK - 1) / BLOCK;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_records_add, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n, xs4);
+  if (atomic)
+    hipLaunchKernelGGL(k_records_add_atomic, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n,
+                       4 * xs4);
+  else
+    hipLaunchKernelGGL(k_records_add, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n, xs4);
   return after_launch("vfm_records_add_f32");
+}
+
+int vfm_shard_pack_f32(float* small, const float* loss_local, const double* kl_ws, void* stream) {
+  if (!small || !loss_local || !kl_ws) return fail(VFM_E_INVALID, "vfm_shard_pack_f32: NULL pointer");
+  hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, (hipStream_t)stream, small, loss_local, kl_ws);
+  return after_launch("vfm_shard_pack_f32");
+}
+
+int vfm_shard_loss_f32(const float* small, float* loss3, void* stream) {
+  if (!small || !loss3) return fail(VFM_E_INVALID, "vfm_shard_loss_f32: NULL pointer");
+  hipLaunchKernelGGL(k_shard_loss, dim3(1), dim3(64), 0, (hipStream_t)stream, small, loss3);
+  return after_launch("vfm_shard_loss_f32");
 }
 
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -287,12 +287,27 @@ void shard_sample(const Tensor& ids, const Tensor& entity, const Tensor& bias, c
         "vfm_shard_sample_f32");
 }
 
-void records_add(Tensor dst, const Tensor& idx, const Tensor& src, int64_t d) {
+void shard_pack(Tensor small, const Tensor& loss_local, const Tensor& kl_ws) {
+  c10::hip::HIPGuard guard(small.get_device());
+  check(vfm_shard_pack_f32(dev_tensor(small, at::kFloat, "small").data_ptr<float>(),
+                           dev_tensor(loss_local, at::kFloat, "loss_local").data_ptr<float>(),
+                           dev_tensor(kl_ws, at::kDouble, "kl_ws").data_ptr<double>(), stream_of(small)),
+        "vfm_shard_pack_f32");
+}
+
+void shard_loss(const Tensor& small, Tensor loss3) {
+  c10::hip::HIPGuard guard(small.get_device());
+  check(vfm_shard_loss_f32(dev_tensor(small, at::kFloat, "small").data_ptr<float>(),
+                           dev_tensor(loss3, at::kFloat, "loss3").data_ptr<float>(), stream_of(small)),
+        "vfm_shard_loss_f32");
+}
+
+void records_add(Tensor dst, const Tensor& idx, const Tensor& src, int64_t d, bool atomic) {
   dev_tensor(dst, at::kFloat, "dst"); dev_tensor(idx, at::kInt, "idx"); dev_tensor(src, at::kFloat, "src");
   TORCH_CHECK(src.numel() >= idx.numel() * rec_len(d), "src too small");
   c10::hip::HIPGuard guard(dst.get_device());
   check(vfm_records_add_f32(dst.data_ptr<float>(), idx.data_ptr<int32_t>(), src.data_ptr<float>(), idx.numel(),
-                            (int32_t)d, stream_of(dst)),
+                            (int32_t)d, atomic ? 1 : 0, stream_of(dst)),
         "vfm_records_add_f32");
 }
 
@@ -343,7 +358,9 @@ TORCH_LIBRARY(vfm_hip, m) {
         "int flags, int seed, int step) -> ()", &elbo_fwd_zpre);
   m.def("shard_sample(Tensor ids, Tensor entity_params, Tensor bias_params, Tensor? eps_entity, Tensor? eps_bias, "
         "Tensor(a!) out, int seed, int step) -> ()", &shard_sample);
-  m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d) -> ()", &records_add);
+  m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d, bool atomic) -> ()", &records_add);
+  m.def("shard_pack(Tensor(a!) small, Tensor loss_local, Tensor kl_ws) -> ()", &shard_pack);
+  m.def("shard_loss(Tensor small, Tensor(a!) loss3) -> ()", &shard_loss);
   m.def("adam(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
         "int step) -> ()", &adam);
 }

@@ -93,6 +93,7 @@ class VFM(nn.Module):
         # "auto" picks it unless the whole statistics table is tiny (< 4 MB: one small all-reduce wins).
         self.exchange = "auto"
         self.exchange_chunks = 4
+        self.shard_deterministic = False   # True: add the source ranks' statistics one launch per rank
         self._xflat = None
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)

@@ -136,13 +136,16 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     # 5. owner: sum the sources' records, epilogue + Adam on owned rows (+ my share of the KL term)
     acc = model._shard_acc
     acc.zero_()
-    off = 0
-    for s in range(N):
-        c = plan.req_counts[s]
-        if c:
-            _lib.ops().records_add(acc, plan.req_local[off: off + c], plan.rrecv[off * plan.rl: (off + c) * plan.rl],
-                                   spec.d)
-        off += c
+    if model.shard_deterministic:          # one launch per source rank, plain adds: bitwise reproducible
+        off = 0
+        for s in range(N):
+            c = plan.req_counts[s]
+            if c:
+                _lib.ops().records_add(acc, plan.req_local[off: off + c],
+                                       plan.rrecv[off * plan.rl: (off + c) * plan.rl], spec.d, False)
+            off += c
+    elif plan.R:                            # one launch, float atomics
+        _lib.ops().records_add(acc, plan.req_local, plan.rrecv, spec.d, True)
     model._adam_t += 1
     t_own = owned_rows(spec.T, r, N)
     st_own = ops.FwdState(pred, partials, sumz, grow,
@@ -152,8 +155,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
                         model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t,
                         e_lo=0, e_hi=t_own, own_mod=N, own_rank=r, kl_ws=model._shard_klws)
     # 6. one tiny all-reduce: [sum g, alpha term, nll, KL(q(w0)) (rank 0 only), my KL share]
-    small[2:4] = loss_local[1:3]
-    small[4] = model._shard_klws[0].to(torch.float32)
+    _lib.ops().shard_pack(small, loss_local, model._shard_klws)
     dist.all_reduce(small[0:8], group=plan.group)
     # scalar Adam (replicated, identical on every rank): an empty last chunk of the apply kernel
     if N > 1:
@@ -162,9 +164,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
                             e_lo=spec.T, e_hi=spec.T, own_mod=N, own_rank=r)
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
-    loss3[1] = small[2]
-    loss3[2] = small[3] + small[4]
-    loss3[0] = loss3[1] + loss3[2]
+    _lib.ops().shard_loss(small, loss3)
     return loss3, pred
 
 
