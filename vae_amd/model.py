@@ -94,6 +94,7 @@ class VFM(nn.Module):
         self.exchange = "auto"
         self.exchange_chunks = 4
         self.shard_deterministic = False   # True: add the source ranks' statistics one launch per rank
+        self._stale_group = None
         self._xflat = None
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
@@ -239,6 +240,8 @@ class VFM(nn.Module):
         a fresh posterior sample; last/mean logits are the deterministic predictions from the last /
         epoch-averaged posterior means once `save_weights()` has run (None before).  The KL branch
         is not evaluated on inference inputs (kl_term is None)."""
+        if getattr(self, "_stale_group", None) is not None:
+            self.sync_params(self._stale_group)      # entity-sharded training: collective, every rank calls it
         plan = self.plan(x, None) if not isinstance(x, ops.BatchPlan) else x
         ent, bia, scal = self._views(self._flat)
         step = self.global_step
@@ -265,6 +268,12 @@ class VFM(nn.Module):
 
     @torch.no_grad()
     def save_weights(self):
+        if getattr(self, "_stale_group", None) is not None:
+            self.sync_params(self._stale_group)
+        self._save_weights()
+
+    @torch.no_grad()
+    def _save_weights(self):
         """Snapshot the posterior means and update their running average over epochs
         (vfm-torch.py:179-185; the reference keeps every snapshot and re-averages, the running
         mean is the same quantity)."""

@@ -165,6 +165,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     _lib.ops().shard_loss(small, loss3)
+    model._stale_group = plan.group      # rows owned by other ranks are stale until sync_params()
     return loss3, pred
 
 
@@ -190,3 +191,4 @@ def sync_params(model, group, rank: int, world: int):
         for s in range(world):
             n = owned_rows(T, s, world)
             tab[s::world] = out[s][:n]
+    model._stale_group = None
