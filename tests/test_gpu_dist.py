@@ -119,7 +119,8 @@ def _sharded_worker(rank, world, port, name, out_dir, use_tables):
     c = Case(name)
     m = _make_model(c, dev)
     m.exchange = "sharded"
-    m.shard_deterministic = (world == 3)          # cover both ways of adding the sources' statistics
+    m.shard_gather = use_tables                   # cover the gather form and both dense-table forms
+    m.shard_deterministic = (world == 3)
     eps = None
     if use_tables:
         e0, ew, ev = c.eps("f32")

@@ -89,7 +89,7 @@ def load():
                                  i64, vp]
     lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 7
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
-                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
+                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp, vp, vp])
     lib.vfm_shard_sample_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.vfm_shard_pack_f32.argtypes = [vp, vp, vp, vp]

@@ -166,8 +166,17 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     int beg = pq.x, end = pq.y;
     const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
+    int rbeg = 0, rend = 0;
     if constexpr (STAGE == STAGE_APPLY) {
-      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)li * xs);   // (sum of grow, occurrences) over ALL ranks
+      if (b.occ_ptr) {     // gather form: the records of entity li sit at positions occ_rows[rbeg..rend) of b.acc
+        rbeg = b.occ_ptr[li]; rend = b.occ_ptr[li + 1];
+        for (int q = rbeg; q < rend; ++q) {
+          const float2 t2 = *reinterpret_cast<const float2*>(b.acc + (size_t)b.occ_rows[q] * xs);
+          gc.x += t2.x; gc.y += t2.y;
+        }
+      } else {
+        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)li * xs);   // (sum of grow, occurrences) over ALL ranks
+      }
       beg = 0; end = 0;
     } else {
       if (en < a.e_hi) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
@@ -274,10 +283,25 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     if constexpr (STAGE == STAGE_APPLY) {
       gs = gc.x;
       if (touched) {
+        if (b.occ_ptr) {
+          for (int q = rbeg; q < rend; ++q) {
+            const float* rec = b.acc + (size_t)b.occ_rows[q] * xs + 4;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int j = lig + i * LPE;
-          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)li * xs + 4 + (size_t)j * VEC);
+            for (int i = 0; i < CPL; ++i) {
+              const int j = lig + i * LPE;
+              if (j < C) {
+                const Chunk<VEC> t4 = ld_chunk<VEC>(rec + (size_t)j * VEC);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) A[i].v[t] += t4.v[t];
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < CPL; ++i) {
+            const int j = lig + i * LPE;
+            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)li * xs + 4 + (size_t)j * VEC);
+          }
         }
       }
     }

@@ -421,7 +421,8 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, double* kl_ws, void* stream) {
+                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
+                            const int32_t* rec_pos, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
@@ -431,7 +432,9 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_apply_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
-  BwdArgs b{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  if ((rec_ptr == nullptr) != (rec_pos == nullptr))
+    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_ptr and rec_pos go together");
+  BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
             const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, kl_ws};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");

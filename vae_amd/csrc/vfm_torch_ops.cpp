@@ -217,11 +217,22 @@ void elbo_apply_adam(const Tensor& acc, const Tensor& sums, Tensor entity, Tenso
                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global,
                      int64_t likelihood, int64_t flags, int64_t seed, int64_t step, double lr, double beta1,
                      double beta2, double eps_adam, int64_t adam_step, int64_t e_lo, int64_t e_hi,
-                     int64_t own_mod, int64_t own_rank, const optional<Tensor>& kl_ws) {
+                     int64_t own_mod, int64_t own_rank, const optional<Tensor>& kl_ws,
+                     const optional<Tensor>& rec_ptr, const optional<Tensor>& rec_pos) {
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
   const int64_t n_rec = own_mod > 1 ? (T - own_rank + own_mod - 1) / own_mod : T;
-  TORCH_CHECK(acc.numel() >= n_rec * rec_len(d) && sums.numel() >= 2, "apply_adam sizes");
+  const bool gather = rec_ptr.has_value() && rec_ptr->defined();
+  const int32_t* rp = nullptr; const int32_t* rq = nullptr;
+  if (gather) {
+    TORCH_CHECK(rec_pos.has_value() && rec_pos->defined() && rec_ptr->numel() == n_rec + 1 &&
+                acc.numel() >= rec_pos->numel() * rec_len(d), "gather index sizes");
+    rp = dev_tensor(*rec_ptr, at::kInt, "rec_ptr").data_ptr<int32_t>();
+    rq = dev_tensor(*rec_pos, at::kInt, "rec_pos").data_ptr<int32_t>();
+  } else {
+    TORCH_CHECK(acc.numel() >= n_rec * rec_len(d), "apply_adam sizes");
+  }
+  TORCH_CHECK(sums.numel() >= 2, "sums size");
   double* klp = nullptr;
   if (kl_ws.has_value() && kl_ws->defined()) {
     TORCH_CHECK(kl_ws->numel() >= 4097, "kl_ws needs 4097 doubles");
@@ -242,7 +253,7 @@ void elbo_apply_adam(const Tensor& acc, const Tensor& sums, Tensor entity, Tenso
             dev_tensor(m_bias, at::kFloat, "m_bias").data_ptr<float>(), dev_tensor(v_bias, at::kFloat, "v_bias").data_ptr<float>(),
             dev_tensor(m_scalars, at::kFloat, "m_scalars").data_ptr<float>(),
             dev_tensor(v_scalars, at::kFloat, "v_scalars").data_ptr<float>(), (float)lr, (float)beta1, (float)beta2,
-            (float)eps_adam, adam_step, klp, stream_of(entity)),
+            (float)eps_adam, adam_step, klp, rp, rq, stream_of(entity)),
         "vfm_elbo_apply_adam_f32");
 }
 
@@ -352,7 +363,8 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, Tensor(g!) v_bias, Tensor(h!) m_scalars, "
         "Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, "
         "int flags, int seed, int step, float lr, float beta1, float beta2, float eps_adam, int adam_step, "
-        "int e_lo, int e_hi, int own_mod, int own_rank, Tensor(j!)? kl_ws) -> ()", &elbo_apply_adam);
+        "int e_lo, int e_hi, int own_mod, int own_rank, Tensor(j!)? kl_ws, Tensor? rec_ptr, Tensor? rec_pos) -> ()",
+        &elbo_apply_adam);
   m.def("elbo_fwd_zpre(Tensor x, Tensor y, Tensor zbuf, Tensor scalars, Tensor? eps_global, Tensor(a!) pred, "
         "Tensor(b!) partials, Tensor(c!) sumz, Tensor(d!) grow, int d, int nb_train, int B_global, int likelihood, "
         "int flags, int seed, int step) -> ()", &elbo_fwd_zpre);

@@ -93,7 +93,8 @@ class VFM(nn.Module):
         # "auto" picks it unless the whole statistics table is tiny (< 4 MB: one small all-reduce wins).
         self.exchange = "auto"
         self.exchange_chunks = 4
-        self.shard_deterministic = False   # True: add the source ranks' statistics one launch per rank
+        self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
+        self.shard_deterministic = False   # (shard_gather=False) add the sources one launch per rank, no atomics
         self._stale_group = None
         self._xflat = None
 

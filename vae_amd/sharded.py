@@ -70,6 +70,14 @@ class ShardedPlan:
         dist.all_to_all_single(req, self.slot_ids.to(torch.int32), self.req_counts, self.need_counts, group=group)
         self.req_ids = req.contiguous()                               # global ids (all owned by me), by source
         self.req_local = (req // N).to(torch.int32).contiguous()      # local record index at the owner
+        # gather index of the owner: for each owned (local) entity, where its records land in the
+        # receive buffer of the statistics all-to-all (one per rank that has it in its rows)
+        t_own = owned_rows(T, rank, N)
+        rl64 = self.req_local.to(torch.int64)
+        self.rec_pos = torch.argsort(rl64, stable=True).to(torch.int32).contiguous()
+        rp = torch.zeros(t_own + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(rl64, minlength=t_own), 0, out=rp[1:])
+        self.rec_ptr = rp.to(torch.int32).contiguous()
         # --- inverted index over slots (what vfm_elbo_bwd_acc_f32 walks)
         sspec = ops.Spec(T=max(self.U, 1), F=spec.F, d=spec.d, group_hi=tuple([max(self.U, 1)] * spec.F),
                          group_n=tuple([1.0] * spec.F), likelihood=spec.likelihood, nb_train=spec.nb_train)
@@ -134,18 +142,23 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
                            plan.splits(plan.req_counts), plan.splits(plan.need_counts), group=plan.group)
     mark("acc_a2a")
     # 5. owner: sum the sources' records, epilogue + Adam on owned rows (+ my share of the KL term)
-    acc = model._shard_acc
-    acc.zero_()
-    if model.shard_deterministic:          # one launch per source rank, plain adds: bitwise reproducible
-        off = 0
-        for s in range(N):
-            c = plan.req_counts[s]
-            if c:
-                _lib.ops().records_add(acc, plan.req_local[off: off + c],
-                                       plan.rrecv[off * plan.rl: (off + c) * plan.rl], spec.d, False)
-            off += c
-    elif plan.R:                            # one launch, float atomics
-        _lib.ops().records_add(acc, plan.req_local, plan.rrecv, spec.d, True)
+    rec_index = None
+    if model.shard_gather:                 # the apply kernel sums the sources' records itself (default)
+        acc = plan.rrecv
+        rec_index = (plan.rec_ptr, plan.rec_pos)
+    else:                                  # dense local table of records, filled by vfm_records_add_f32
+        acc = model._shard_acc
+        acc.zero_()
+        if model.shard_deterministic:      # one launch per source rank, plain adds
+            off = 0
+            for s in range(N):
+                c = plan.req_counts[s]
+                if c:
+                    _lib.ops().records_add(acc, plan.req_local[off: off + c],
+                                           plan.rrecv[off * plan.rl: (off + c) * plan.rl], spec.d, False)
+                off += c
+        elif plan.R:                       # one launch, float atomics
+            _lib.ops().records_add(acc, plan.req_local, plan.rrecv, spec.d, True)
     model._adam_t += 1
     t_own = owned_rows(spec.T, r, N)
     st_own = ops.FwdState(pred, partials, sumz, grow,
@@ -153,7 +166,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     own_plan = _OwnPlan(spec, plan.W)
     ops.elbo_apply_adam(own_plan, st_own, acc, small[0:2], ent, bia, scal, model.inv_occ,
                         model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t,
-                        e_lo=0, e_hi=t_own, own_mod=N, own_rank=r, kl_ws=model._shard_klws)
+                        e_lo=0, e_hi=t_own, own_mod=N, own_rank=r, kl_ws=model._shard_klws, rec_index=rec_index)
     # 6. one tiny all-reduce: [sum g, alpha term, nll, KL(q(w0)) (rank 0 only), my KL share]
     _lib.ops().shard_pack(small, loss_local, model._shard_klws)
     dist.all_reduce(small[0:8], group=plan.group)
@@ -161,7 +174,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     if N > 1:
         ops.elbo_apply_adam(own_plan, st_own, acc, small[0:2], ent, bia, scal, model.inv_occ,
                             model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t,
-                            e_lo=spec.T, e_hi=spec.T, own_mod=N, own_rank=r)
+                            e_lo=spec.T, e_hi=spec.T, own_mod=N, own_rank=r, rec_index=rec_index)
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     _lib.ops().shard_loss(small, loss3)
