@@ -312,3 +312,29 @@ def test_philox_stream_statistics():
     assert abs(eb.mean().item()) < 0.03 and abs(eb.var().item() - 1) < 0.04
     ee2, eb2, _ = ops.philox_eps(spec, seed=2025, step=3, device=dev)              # another seed
     assert abs((ee * ee2).mean().item()) < 4 / n ** 0.5
+
+
+def test_state_dict_round_trip_and_device_moves():
+    """state_dict has the reference's keys; loading it into a fresh model reproduces the predictions;
+    .to() keeps the parameters tied to the flat buffer; dtype conversions are refused."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([60, 40], 3000, seed=2)
+    torch.manual_seed(1)
+    a = VFM(60, 40, 12, device="cuda", rng_seed=4)
+    a.fit(X, y, n_epochs=2, batch_size=1000, verbose=False)
+    sd = {k: v.detach().cpu().clone() for k, v in a.state_dict().items()}
+    assert {"alpha", "global_bias_mean", "global_bias_scale", "bias_params.weight", "entity_params.weight",
+            "prec_global_bias_prior", "prec_user_entity_prior"} <= set(sd)
+    torch.manual_seed(99)
+    b = VFM(60, 40, 12, device="cuda", rng_seed=4)
+    b.load_state_dict(sd)
+    pa = a(X[:500], sample=False)[0].mean
+    pb = b(X[:500], sample=False)[0].mean
+    assert torch.equal(pa, pb)
+    # parameters stay views of ONE flat buffer after a device round trip
+    b = b.to("cpu").to("cuda")
+    assert b.entity_params.weight.data_ptr() == b._flat.data_ptr()
+    assert torch.equal(b(X[:500], sample=False)[0].mean, pa)
+    with pytest.raises(TypeError):
+        b.double()

@@ -155,7 +155,9 @@ class VFM(nn.Module):
                 flat[self._off_scal: self._off_scal + 3])
 
     def _apply(self, fn, *a, **k):
-        # keep the parameters tied to the flat buffer across .to()/.cuda()
+        # keep the parameters tied to the flat buffer across .to()/.cuda(); the kernels are fp32 only
+        if fn(torch.zeros(1, dtype=torch.float32, device=self._flat.device)).dtype != torch.float32:
+            raise TypeError("VFM computes in fp32 only (like the reference); dtype conversions are not supported")
         with torch.no_grad():
             cur = torch.cat([self.entity_params.weight.reshape(-1),
                              torch.zeros(self._off_bias - self._n_ent, device=self._flat.device),
