@@ -113,15 +113,30 @@ def main():
     model.set_training_data(X, nb_train=nb_train, nb_occ=occ)
     model.lr = 1.0 / (1 + nb_train // (B * world))       # vfm-torch.py:92
 
-    plans, uniq = [], []
-    for i in range(nbt):
-        xb, yb = X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]
-        if not args.no_sort:
-            o = torch.argsort(xb[:, -1], stable=True)
-            xb, yb = xb[o].contiguous(), yb[o].contiguous()
-        p = model.plan(xb, yb, B_global=B * world, process_group=pg)
-        plans.append(p)
-        uniq.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
+    def build_plans():
+        ps, us = [], []
+        for i in range(nbt):
+            xb, yb = X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]
+            if not args.no_sort:
+                o = torch.argsort(xb[:, -1], stable=True)
+                xb, yb = xb[o].contiguous(), yb[o].contiguous()
+            p = model.plan(xb, yb, B_global=B * world, process_group=pg)
+            ps.append(p)
+            us.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
+        return ps, us
+
+    exchange_note = None
+    try:
+        plans, uniq = build_plans()
+    except Exception as exc:          # communication-pattern fallback only (never a compute fallback)
+        if world > 1 and model.exchange == "sharded":
+            exchange_note = "sharded plan failed (%s: %s); using the statistics all-reduce" % (
+                type(exc).__name__, str(exc)[:200])
+            print("[bench] " + exchange_note, file=sys.stderr)
+            model.exchange = "stats"
+            plans, uniq = build_plans()
+        else:
+            raise
     U = sum(uniq) / len(uniq)
 
     events = []
@@ -264,7 +279,7 @@ def main():
                        "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
-                       "exchange": model.exchange if world > 1 else None,
+                       "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
                        "step": ("fwd+loss+bwd_acc+allreduce(stats)+apply_adam" if world > 1 else "fwd+loss+bwd+dense-adam") if
                                (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
                        "parallelism": f"row-sharded dp{world}"},
