@@ -464,8 +464,8 @@ int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, 
 #define X(L_, C_, V_)                                                                              \
   if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                 \
     constexpr int GPB = BLOCK / L_;                                                                \
-    int64_t nb = (n + GPB - 1) / GPB;                                                              \
-    if (nb > 4096) nb = 4096;                                                                      \
+    int64_t nb = (n + GPB - 1) / GPB;   /* one record per lane group: latency is hidden by occupancy */ \
+    if (nb > 65535) nb = 65535;                                                                    \
     if (eps_entity)                                                                                \
       hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_TABLE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, (int)n, out); \
     else                                                                                           \
