@@ -108,11 +108,13 @@ typedef struct vfm_problem {
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
  *   occ_ptr [T+1] offsets into occ_rows [B*F] (row numbers sorted by entity id, stable).
  * Long lists (skewed data: a popular item can own 10% of the rows) would serialise on one lane group,
- * so entities with more than VFM_HEAVY_LIST occurrences are also listed in `heavy_ids` (sorted) and
- * their lists cut in work items `heavy_items` [n_items,4] = (slot in heavy_ids, begin, end, 0) of at
- * most VFM_HEAVY_LIST occurrences; every backward call first reduces them into the scratch table
+ * so entities with more than VFM_HEAVY_LIST occurrences (any threshold >= VFM_HEAVY_MIN works: the
+ * kernels look an entity up in `heavy_ids` whenever its list is longer than VFM_HEAVY_MIN) are also
+ * listed in `heavy_ids` (sorted) and their lists cut in work items `heavy_items` [n_items,4] =
+ * (slot in heavy_ids, begin, end, 0) of about that many occurrences; every backward call first reduces them into the scratch table
  * `heavy_acc` [n_heavy, 4 + round4(d)] (overwritten per call).  n_heavy == 0: all three may be NULL. */
-#define VFM_HEAVY_LIST 32
+#define VFM_HEAVY_LIST 64
+#define VFM_HEAVY_MIN 8
 typedef struct vfm_index {
   const int32_t* occ_ptr;
   const int32_t* occ_rows;

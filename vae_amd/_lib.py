@@ -51,7 +51,7 @@ class Index(C.Structure):
                 ("n_items", C.c_int32)]
 
 
-HEAVY_LIST = 32
+HEAVY_LIST = int(os.environ.get("VFM_HEAVY_LIST", "64"))   # >= 8 (VFM_HEAVY_MIN); tuning knob of the plan builder
 
 
 class VfmLibraryError(RuntimeError):

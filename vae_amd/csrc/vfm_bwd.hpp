@@ -228,7 +228,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
     float gs = 0.f;
     int o = beg;
-    if (STAGE != STAGE_APPLY && end - beg > VFM_HEAVY_LIST && b.n_heavy > 0) {
+    if (STAGE != STAGE_APPLY && b.n_heavy > 0 && end - beg > VFM_HEAVY_MIN) {
       const int slot = heavy_slot_of(b.heavy_ids, b.n_heavy, (int)e);
       if (slot >= 0) {      // pre-reduced by k_heavy: read the record, skip the walk
         const float* rec = b.heavy_acc + (size_t)slot * xs;
