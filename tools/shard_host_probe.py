@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Whole entity-sharded step (Python + launches + collectives on a 1-rank gloo group) at cfg3 on one GPU:
+shows the host-side cost of the step next to the kernel time (tools/shard_probe.py)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from vae_amd.model import VFM
+from vae_amd.data import synthetic_triples
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("gloo", rank=0, world_size=1)
+if os.environ.get("LOCAL_COLLECTIVES", "1") == "1":
+    # a 1-rank group: every collective is the identity -- replace gloo's host-staged copies by
+    # device-side ones so that what remains is the step's own Python + launch + kernel time
+    import vae_amd.sharded as _sh
+    import vae_amd.dist as _vd
+
+    def _a2a(out, inp, *a, **k):
+        out.copy_(inp)
+
+    def _ar(t, *a, **k):
+        class _W:
+            def wait(self):
+                pass
+        return _W()
+
+    dist.all_to_all_single = _a2a
+    dist.all_reduce = _ar
+dev = torch.device("cuda")
+sizes, d, B, nb_train = [138493, 26744], 128, 100000, 16000210
+torch.manual_seed(42)
+m = VFM(field_sizes=sizes, embedding_size=d, device=dev, rng_seed=3)
+m.exchange = os.environ.get("EXCHANGE", "sharded")
+X, y = synthetic_triples(sizes, 4 * B, seed=1, device=dev)
+occ = torch.clamp(torch.bincount(X.reshape(-1), minlength=sum(sizes)) * 40, min=1)
+m.set_training_data(X, nb_train=nb_train, nb_occ=occ)
+m.lr = 0.006
+plans = [m.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B], process_group=dist.group.WORLD) for i in range(4)]
+for s in range(10):
+    m.train_step(plans[s % 4], process_group=dist.group.WORLD)
+torch.cuda.synchronize()
+n = 200
+t0 = time.perf_counter()
+for s in range(n):
+    m.train_step(plans[s % 4], process_group=dist.group.WORLD)
+th = time.perf_counter() - t0
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(m.exchange, "ms/step", round(dt / n * 1e3, 4), "host enqueue ms/step", round(th / n * 1e3, 4))
+dist.destroy_process_group()
