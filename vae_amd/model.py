@@ -179,6 +179,35 @@ class VFM(nn.Module):
         self._tie()
         return out
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def training_state_dict(self):
+        """Everything needed to resume training bit-for-bit: parameters (state_dict), Adam moments and
+        step count, the Philox step counter, the epoch-averaged posterior means of save_weights()."""
+        opt = None
+        if self._adam_m is not None:
+            opt = {"m": self._adam_m.detach().cpu().clone(), "v": self._adam_v.detach().cpu().clone(),
+                   "t": int(self._adam_t)}
+        snap = None
+        if self._n_saved:
+            snap = {"n": int(self._n_saved), "mean": self._mean_flat.detach().cpu().clone(),
+                    "last": self._last_flat.detach().cpu().clone()}
+        return {"model": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+                "adam": opt, "global_step": int(self.global_step), "rng_seed": int(self.rng_seed),
+                "lr": self.lr, "snapshots": snap}
+
+    def load_training_state_dict(self, state):
+        self.load_state_dict(state["model"])
+        self.global_step, self.rng_seed, self.lr = int(state["global_step"]), int(state["rng_seed"]), state["lr"]
+        if state.get("adam") is not None:
+            self._ensure_opt_state()
+            self._adam_m.copy_(state["adam"]["m"].to(self.device))
+            self._adam_v.copy_(state["adam"]["v"].to(self.device))
+            self._adam_t = int(state["adam"]["t"])
+        if state.get("snapshots") is not None:
+            self._n_saved = int(state["snapshots"]["n"])
+            self._mean_flat = state["snapshots"]["mean"].to(self.device).clone()
+            self._last_flat = state["snapshots"]["last"].to(self.device).clone()
+
     @property
     def device(self):
         return self._flat.device
