@@ -22,7 +22,8 @@
  *    bias_params   [T, 2]           : row e = [ mu_w, s_w ]
  *    scalars       [3]              : alpha, global_bias_mean, global_bias_scale
  *    x             [B, F] row-major entity ids, int64 (reference: torch.LongTensor) or int32
- *    link function is |.| (vfm-torch.py:126): sigma = |s|.
+ *    link function of the scale parameters: sigma = |s| (vfm-torch.py:126, the assignment that wins)
+ *    or, with VFM_FLAG_LINK_SOFTPLUS, sigma = softplus(s) (:125) -- the reference's global LINK.
  */
 #ifndef VFM_HIP_H
 #define VFM_HIP_H
@@ -58,6 +59,9 @@ extern "C" {
                                      NULL, eps_global alone may be given                                    */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
+#define VFM_FLAG_LINK_SOFTPLUS 16 /* LINK = softplus instead of |.| (vfm-torch.py:125-126; applies to alpha,
+                                     global_bias_scale and both tables' scale halves); give it to every call
+                                     of a step                                                            */
 
 /* indices into the fp64 `partials` vector written by vfm_elbo_fwd_f32 */
 #define VFM_P_LL 0      /* sum_r log p(y_r | pred_r)                                    */
@@ -65,6 +69,7 @@ extern "C" {
 #define VFM_P_G 2       /* sum_r dloss/dpred_r                                          */
 #define VFM_P_ALPHA 3   /* sum_r [(y-pred)^2/2 - 1/(2|alpha|)]                          */
 #define VFM_P_BADID 4   /* number of ids outside [0,T) met (they are clamped to 0)      */
+#define VFM_P_GE0 5     /* n_samples > 1: sum_s eps0^s * sum_r dloss/dpred[s,r]         */
 #define VFM_N_PARTIALS 8
 /* `partials` is a caller-owned fp64 workspace of VFM_PARTIALS_LEN entries: [0..7] the sums
  * above (valid after vfm_elbo_finalize_f32; [7] = number of forward blocks), followed by one
@@ -82,7 +87,8 @@ typedef struct vfm_problem {
   int32_t d;          /* embedding size                                                  */
   int32_t likelihood; /* VFM_LIK_*                                                       */
   int32_t id_bits;    /* 64 or 32: element type of x                                     */
-  int32_t n_samples;  /* variational samples S; only 1 is supported (vfm-torch.py:19)    */
+  int32_t n_samples;  /* variational samples S in [1,64] (N_VARIATIONAL_SAMPLES, vfm-torch.py:19);
+                         S > 1: forward, finalize, vfm_elbo_bwd_f32 and vfm_elbo_bwd_adam_f32 only   */
   int32_t flags;      /* VFM_FLAG_*                                                      */
   /* id groups for the KL re-weighting (vfm-torch.py:314-317): entity e belongs to the first
    * g with e < group_hi[g]; its KL is scaled by group_n[g] / W[g].  There are F groups and
@@ -112,7 +118,7 @@ typedef struct vfm_problem {
  * kernels look an entity up in `heavy_ids` whenever its list is longer than VFM_HEAVY_MIN) are also
  * listed in `heavy_ids` (sorted) and their lists cut in work items `heavy_items` [n_items,4] =
  * (slot in heavy_ids, begin, end, 0) of about that many occurrences; every backward call first reduces them into the scratch table
- * `heavy_acc` [n_heavy, 4 + round4(d)] (overwritten per call).  n_heavy == 0: all three may be NULL. */
+ * `heavy_acc` [n_samples, n_heavy, 4 + round4(d)] (overwritten per call).  n_heavy == 0: all three may be NULL. */
 #define VFM_HEAVY_LIST 64
 #define VFM_HEAVY_MIN 8
 typedef struct vfm_index {
@@ -147,11 +153,15 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
  *       inv_occ, W, sumz, grow may be NULL too.  With y, all of them are required.)
  *       W [F] batch-global normalisers, eps_* tables indexed BY ENTITY ID
  *       (eps_entity [T,d], eps_bias [T], eps_global [1]) or all three NULL => Philox.
- *  out: pred [B]      unscaled prediction (logit for Bernoulli)
+ *  out: pred [S,B]    unscaled prediction (logit for Bernoulli) of every variational sample
  *       partials [VFM_PARTIALS_LEN] fp64 workspace: per-workgroup partial sums; call
  *       vfm_elbo_finalize_f32 to reduce them into partials[0..7] (see VFM_P_*)
- *       sumz [B,d] and grow [B]: training state for the backward call:
- *       sumz[r,k] = sum_f z[x_rf,k],  grow[r] = dloss/dpred_r.
+ *       sumz [S,B,d] and grow [B]: training state for the backward call:
+ *       sumz[s,r,k] = sum_f z^s[x_rf,k],  grow[r] = sum_s dloss/dpred[s,r].
+ *  S = n_samples > 1 (vfm-torch.py:238-245,265): per sample its own eps (tables: eps_entity [S,T,d],
+ *       eps_bias [S,T], eps_global [S]); the entity terms are averaged over the samples BEFORE the
+ *       likelihood, the global bias is not: pred[s,r] = w0^s + mean_s'(sum_f w^s' + FM(z^s')), and the
+ *       loss averages the log-likelihood over S*B (:359).  One launch per sample.
  *  eps: Philox mode draws, per entity and step, d embedding normals + 1 first-order-weight
  *       normal from Philox4x32-10(ctr = (k/8, e, step), key = seed) (see vfm_philox_eps_f32).  */
 int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
@@ -257,7 +267,7 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta2, float eps, int64_t step, void* stream);
 
 /* Debug / test helper: write the eps the kernels would generate from (seed, step) into
- * tables (eps_entity [T,d], eps_bias [T], eps_global [1]). */
+ * tables (eps_entity [S,T,d], eps_bias [S,T], eps_global [S]; S = n_samples). */
 int vfm_philox_eps_f32(const vfm_problem_t* p, float* eps_entity, float* eps_bias,
                        float* eps_global, void* stream);
 

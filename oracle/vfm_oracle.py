@@ -55,13 +55,18 @@ def make_params(T, d, dtype=torch.float32, seed=42, alpha=None):
     return {k: v.to(dtype).requires_grad_(True) for k, v in P.items()}
 
 
-def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None):
-    """One `CF.forward` (vfm-torch.py:189-324), S = 1 variational sample.
+TORCH_LINKS = {"abs": torch.abs, "softplus": torch.nn.functional.softplus}     # vfm-torch.py:126 / :125
 
-    eps: None -> draw with rsample exactly like the reference (RNG order eps0,
-    eps_w[U], eps_v[U,d] over the SORTED unique ids); or a tuple
-    (eps0[1], eps_w[U], eps_v[U,d]) to replay recorded draws.
-    Returns (likelihood distribution with batch shape [1,B], kl_term[1])."""
+
+def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None, n_samples=1, link="abs"):
+    """One `CF.forward` (vfm-torch.py:189-324) with S = n_samples variational samples
+    (the reference's global N_VARIATIONAL_SAMPLES, :19) and `link` = its global LINK (:125-126).
+
+    eps: None -> draw with rsample exactly like the reference (RNG order eps0[S,1],
+    eps_w[S,U], eps_v[S,U,d] over the SORTED unique ids); or a tuple
+    (eps0[S], eps_w[S,U], eps_v[S,U,d]) (S = 1: the leading axis may be absent) to replay
+    recorded draws.  Returns (likelihood distribution with batch shape [S,B], kl_term[1])."""
+    LINK, S = TORCH_LINKS[link], int(n_samples)
     uniq, pos, cnt = torch.unique(x, return_inverse=True, return_counts=True)
     users, cnt_u = torch.unique(x[:, 0], return_counts=True)
     items, cnt_i = torch.unique(x[:, 1], return_counts=True)
@@ -70,23 +75,23 @@ def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None):
     theta = torch.nn.functional.embedding(uniq, P["bias_params"])
     phi = torch.nn.functional.embedding(uniq, P["entity_params"])
     d = phi.shape[1] // 2
-    q0 = distributions.Normal(P["global_bias_mean"], torch.abs(P["global_bias_scale"]))
-    qw = distributions.Normal(theta[:, 0], torch.abs(theta[:, 1]))
-    qv = distributions.Normal(loc=phi[:, :d], scale=torch.abs(phi[:, d:]))
+    q0 = distributions.Normal(P["global_bias_mean"], LINK(P["global_bias_scale"]))
+    qw = distributions.Normal(theta[:, 0], LINK(theta[:, 1]))
+    qv = distributions.Normal(loc=phi[:, :d], scale=LINK(phi[:, d:]))
 
     if eps is None:
-        w0, w, z = q0.rsample((1,)), qw.rsample((1,)), qv.rsample((1,))
+        w0, w, z = q0.rsample((S,)), qw.rsample((S,)), qv.rsample((S,))
     else:
         e0, ew, ev = (torch.as_tensor(e, dtype=phi.dtype) for e in eps)
-        w0 = (q0.loc + e0.reshape(1, 1) * q0.scale)
-        w = (qw.loc + ew.reshape(1, -1) * qw.scale)
-        z = (qv.loc + ev.reshape(1, -1, d) * qv.scale)
+        w0 = (q0.loc + e0.reshape(S, 1) * q0.scale)
+        w = (qw.loc + ew.reshape(S, -1) * qw.scale)
+        z = (qv.loc + ev.reshape(S, -1, d) * qv.scale)
 
     first = w[:, pos].sum(axis=2).mean(axis=0).squeeze()
     second = z[:, pos].prod(axis=2).sum(axis=2).mean(axis=0)
     logits = w0 + first + second
     if output == "reg":
-        lik = distributions.Normal(logits, torch.sqrt(1 / torch.abs(P["alpha"])))
+        lik = distributions.Normal(logits, torch.sqrt(1 / LINK(P["alpha"])))
     else:
         lik = distributions.Bernoulli(logits=logits)
 
@@ -98,15 +103,16 @@ def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None):
     return lik, distributions.kl_divergence(q0, prior) + kl
 
 
-def reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output="reg", eps=None):
-    lik, kl = reference_shaped_forward(P, x, nb_occ, N, M, output, eps)
+def reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output="reg", eps=None, n_samples=1, link="abs"):
+    lik, kl = reference_shaped_forward(P, x, nb_occ, N, M, output, eps, n_samples, link)
     loss = -lik.log_prob(y.to(kl.dtype)).mean() * nb_train + kl          # vfm-torch.py:359
     return loss, lik, kl
 
 
-def reference_shaped_step(P, opt, x, y, nb_occ, N, M, nb_train, output="reg", eps=None):
+def reference_shaped_step(P, opt, x, y, nb_occ, N, M, nb_train, output="reg", eps=None, n_samples=1,
+                          link="abs"):
     """forward + loss + backward + optimiser step (vfm-torch.py:353-370)."""
-    loss, lik, _ = reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output, eps)
+    loss, lik, _ = reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output, eps, n_samples, link)
     opt.zero_grad()
     loss.backward()
     opt.step()
@@ -128,18 +134,33 @@ def batch_norms(x, nb_occ):
     return (1.0 / nb_occ[x].astype(np.float64)).sum(axis=0)
 
 
+def _np_link(link):
+    """(sigma(s), dsigma/ds) of the link function (vfm-torch.py:125-126), float64."""
+    if link == "abs":
+        return np.abs, np.sign
+    if link == "softplus":
+        return (lambda s: np.logaddexp(0.0, s)), (lambda s: 1.0 / (1.0 + np.exp(-s)))
+    raise ValueError(link)
+
+
 def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_v,
-                 output="reg", W=None, B_global=None, want_grads=True):
+                 output="reg", W=None, B_global=None, want_grads=True, link="abs"):
     """Row-wise ELBO + analytic gradients, float64.
 
     P: dict of numpy arrays (alpha[1], global_bias_mean[1], global_bias_scale[1],
        bias_params[T,2], entity_params[T,2d]).
     x [B,F] int, y [B], nb_occ [T] int; eps_w [T], eps_v [T,d] are indexed BY ENTITY ID
-    (one draw per entity per batch, shared by all rows that contain it).
+    (one draw per entity per batch, shared by all rows that contain it).  With S > 1
+    variational samples (vfm-torch.py:19,238-245): eps0 [S], eps_w [S,T], eps_v [S,T,d]; the
+    entity terms are averaged over the samples before the likelihood, the global bias is not
+    (:244-245,265), and the likelihood is averaged over S*B (:359).
     group_hi [G] exclusive id upper bounds, group_n [G] the n_g multipliers (N, M);
     column f's normaliser W_f divides group f's KL sum (G == F).
-    W / B_global: batch-global normalisers / row count when `x` is only a shard."""
+    W / B_global: batch-global normalisers / row count when `x` is only a shard.
+    link: the scale parameters' link function, "abs" (:126) or "softplus" (:125).
+    Outputs `pred`, `mean`: [B] for S = 1, else [S,B]."""
     f8 = np.float64
+    L, dL = _np_link(link)
     x = np.asarray(x)
     B, F = x.shape
     Bg = B if B_global is None else B_global
@@ -148,9 +169,12 @@ def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_
     d = ent.shape[1] // 2
     alpha, m0, s0 = (float(np.asarray(P[k]).reshape(-1)[0])
                      for k in ("alpha", "global_bias_mean", "global_bias_scale"))
-    eps0 = float(np.asarray(eps0).reshape(-1)[0])
-    eps_w = np.asarray(eps_w, f8)
     eps_v = np.asarray(eps_v, f8)
+    multi = eps_v.ndim == 3
+    eps_v = eps_v if multi else eps_v[None]
+    S = eps_v.shape[0]
+    eps0 = np.asarray(eps0, f8).reshape(-1)[:S]
+    eps_w = np.asarray(eps_w, f8).reshape(S, -1)
     group_n = np.asarray(group_n, f8)
     inv_occ = 1.0 / nb_occ.astype(f8)
     if W is None:
@@ -162,16 +186,17 @@ def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_
     bx, ex = bia[x].astype(f8), ent[x].astype(f8)       # gather first, then widen
     mu_w, s_w = bx[..., 0], bx[..., 1]                  # [B,F]
     mu_v, s_v = ex[..., :d], ex[..., d:]                # [B,F,d]
-    sg_w, sg_v = np.abs(s_w), np.abs(s_v)
-    ew, ev = eps_w[x], eps_v[x]
+    sg_w, sg_v = L(s_w), L(s_v)
+    sg0, a = float(L(np.float64(s0))), float(L(np.float64(alpha)))
+    ew, ev = eps_w[:, x], eps_v[:, x]                    # [S,B,F], [S,B,F,d]
     w = mu_w + sg_w * ew
     z = mu_v + sg_v * ev
-    w0 = m0 + abs(s0) * eps0
-    sz = z.sum(axis=1)                                   # [B,d]
-    q = 0.5 * ((sz * sz).sum(axis=1) - (z * z).sum(axis=(1, 2)))
-    pred = w0 + w.sum(axis=1) + q
+    w0 = m0 + sg0 * eps0                                 # [S]
+    sz = z.sum(axis=2)                                   # [S,B,d]
+    q = 0.5 * ((sz * sz).sum(axis=2) - (z * z).sum(axis=(2, 3)))
+    m = (w.sum(axis=2) + q).mean(axis=0)                 # [B]  (mean over samples BEFORE the likelihood)
+    pred = w0[:, None] + m[None, :]                      # [S,B]
 
-    a = abs(alpha)
     if output == "reg":
         ll = -0.5 * a * (y - pred) ** 2 + 0.5 * math.log(a) - LOG_SQRT_2PI
         dll = a * (y - pred)
@@ -186,34 +211,35 @@ def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_
     kl_e = kl_w + kl_v                                   # [B,F] per occurrence
     grp = group_of(x, group_hi)                          # [B,F]
     io = inv_occ[x]
-    S = np.zeros(G, f8)
-    np.add.at(S, grp.reshape(-1), (kl_e * io).reshape(-1))
-    kl0 = 0.5 * (s0 * s0 + m0 * m0 - 1.0) - math.log(abs(s0))
+    Sg = np.zeros(G, f8)
+    np.add.at(Sg, grp.reshape(-1), (kl_e * io).reshape(-1))
+    kl0 = 0.5 * (sg0 * sg0 + m0 * m0 - 1.0) - math.log(sg0)
     cscale = group_n / W                                 # n_g / W_g
-    kl = kl0 + (cscale * S).sum()
+    kl = kl0 + (cscale * Sg).sum()
     ll_sum = ll.sum()
-    loss = -(nb_train / Bg) * ll_sum + kl
-    out = {"pred": pred, "mean": mean, "ll_sum": ll_sum, "S": S, "W": W, "kl0": kl0,
-           "kl": kl, "loss": loss}
+    scale = nb_train / (Bg * S)
+    loss = -scale * ll_sum + kl
+    out = {"pred": pred if multi else pred[0], "mean": mean if multi else mean[0], "ll_sum": ll_sum,
+           "S": Sg, "W": W, "kl0": kl0, "kl": kl, "loss": loss}
     if not want_grads:
         return out
 
-    g = -(nb_train / Bg) * dll                           # dloss/dpred  [B]
+    gs_ = -scale * dll                                   # dloss/dpred[s,r]  [S,B]
+    g = gs_.sum(axis=0)                                  # dloss/dm_r        [B]
     c = cscale[grp] * io                                 # [B,F]
     g_bias = np.zeros(bia.shape, f8)
     g_ent = np.zeros(ent.shape, f8)
     np.add.at(g_bias[:, 0], x, g[:, None] + c * mu_w)
-    np.add.at(g_bias[:, 1], x, np.sign(s_w) * (g[:, None] * ew + c * (sg_w - 1.0 / sg_w)))
-    other = sz[:, None, :] - z                           # sum over the other fields
-    gz = g[:, None, None] * other
-    gm = gz + c[:, :, None] * mu_v
-    gs = np.sign(s_v) * (gz * ev + c[:, :, None] * (sg_v - 1.0 / sg_v))
-    np.add.at(g_ent, x.reshape(-1), np.concatenate([gm, gs], axis=2).reshape(B * F, 2 * d))
-    gsum = g.sum()
-    out["g_global_bias_mean"] = np.array([gsum + m0])
-    out["g_global_bias_scale"] = np.array([np.sign(s0) * (eps0 * gsum + abs(s0) - 1.0 / abs(s0))])
+    np.add.at(g_bias[:, 1], x, dL(s_w) * (g[:, None] * ew.mean(axis=0) + c * (sg_w - 1.0 / sg_w)))
+    other = sz[:, :, None, :] - z                        # [S,B,F,d] sum over the other fields
+    gm = g[:, None, None] * other.mean(axis=0) + c[:, :, None] * mu_v
+    gsd = dL(s_v) * (g[:, None, None] * (other * ev).mean(axis=0) + c[:, :, None] * (sg_v - 1.0 / sg_v))
+    np.add.at(g_ent, x.reshape(-1), np.concatenate([gm, gsd], axis=2).reshape(B * F, 2 * d))
+    gsum_s = gs_.sum(axis=1)                             # [S]
+    out["g_global_bias_mean"] = np.array([gsum_s.sum() + m0])
+    out["g_global_bias_scale"] = np.array([float(dL(np.float64(s0))) * ((eps0 * gsum_s).sum() + sg0 - 1.0 / sg0)])
     if output == "reg":
-        out["g_alpha"] = np.array([np.sign(alpha) * (nb_train / Bg) *
+        out["g_alpha"] = np.array([float(dL(np.float64(alpha))) * scale *
                                    (0.5 * (y - pred) ** 2 - 0.5 / a).sum()])
     else:
         out["g_alpha"] = np.zeros(1)

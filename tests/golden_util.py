@@ -9,6 +9,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 SINGLE_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20", "ml100k_class_d20",
                 "ml20m_reg_d128", "dup_reg_d12", "dup_class_d12"]
 F64_CASES = ["quirk_reg_d8", "fraction_class_d5", "ml100k_reg_d20", "dup_reg_d12"]
+# the reference's other two globals of the path (vfm-torch.py:19,125-126): S > 1 samples, LINK = softplus
+VARIANT_CASES = ["multi_reg_d8_s3", "softplus_reg_d8", "softplus_multi_class_d8_s2", "dup_multi_reg_d12_s2"]
 
 PARAM_KEYS = ("alpha", "global_bias_mean", "global_bias_scale", "bias_params", "entity_params")
 
@@ -28,6 +30,8 @@ class Case:
         self.x, self.y, self.nb_occ = z["x"], z["y"], z["nb_occ"]
         self.uniq = z["uniq"]
         self.sparse = "sparse_rows" in z.files
+        self.n_samples = int(z["n_samples"]) if "n_samples" in z.files else 1
+        self.link = str(z["link"]) if "link" in z.files else "abs"
         self.group_hi = np.array([self.N + 1, self.T], dtype=np.int64)   # `<= N` quirk
         self.group_n = np.array([self.N, self.M], dtype=np.float64)
 
@@ -42,13 +46,15 @@ class Case:
         return P
 
     def eps(self, tag="f32", dtype=None):
-        """eps0[1], eps_w[T], eps_v[T,d] scattered to entity-id order."""
+        """eps0[1], eps_w[T], eps_v[T,d] scattered to entity-id order ([S], [S,T], [S,T,d] for
+        fixtures with S > 1 variational samples)."""
         z = self.z
         dt = dtype or z[f"{tag}_eps_v"].dtype
-        ew = np.zeros(self.T, dt)
-        ev = np.zeros((self.T, self.d), dt)
-        ew[self.uniq] = z[f"{tag}_eps_w"]
-        ev[self.uniq] = z[f"{tag}_eps_v"]
+        lead = () if self.n_samples == 1 else (self.n_samples,)
+        ew = np.zeros(lead + (self.T,), dt)
+        ev = np.zeros(lead + (self.T, self.d), dt)
+        ew[..., self.uniq] = z[f"{tag}_eps_w"]
+        ev[..., self.uniq, :] = z[f"{tag}_eps_v"]
         return z[f"{tag}_eps0"].astype(dt), ew, ev
 
     def eps_uniq(self, tag="f32"):

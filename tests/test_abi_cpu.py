@@ -50,8 +50,11 @@ def test_bad_arguments_return_errors_not_crashes():
     assert b"bad B or T" in lib.vfm_last_error() or len(lib.vfm_last_error()) > 0
     p.B, p.B_global, p.T, p.F, p.d, p.id_bits, p.n_samples = 4, 4, 10, 2, 8, 64, 1
     assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1          # NULL pointers
+    p.n_samples = 65
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1          # S outside [1,64]
     p.n_samples = 3
-    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -2          # unsupported S > 1
+    assert lib.vfm_elbo_bwd_acc_f32(C.byref(p), *([None] * 7)) == -2       # the multi-rank stages carry one sample
+    assert b"n_samples" in lib.vfm_last_error()
     p.n_samples, p.d = 1, 1027
     assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -2          # unsupported d
     assert lib.vfm_adam_f32(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, 1, None) == -1

@@ -22,7 +22,7 @@ def _setup(c, dev, id_dtype=torch.int64):
     from vae_amd import ops, _lib
     lik = _lib.LIK_NORMAL if c.output == "reg" else _lib.LIK_BERNOULLI
     spec = ops.Spec(T=c.T, F=2, d=c.d, group_hi=tuple(c.group_hi), group_n=tuple(c.group_n),
-                    likelihood=lik, nb_train=c.nb_train)
+                    likelihood=lik, nb_train=c.nb_train, n_samples=c.n_samples, link=c.link)
     P = c.params()
     ent = torch.tensor(P["entity_params"], device=dev)
     bia = torch.tensor(P["bias_params"], device=dev)

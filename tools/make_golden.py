@@ -11,7 +11,9 @@ gradients, a short Adam trajectory) is written to `tests/golden/*.npz`.
 The loss line is vfm-torch.py:359, the optimiser vfm-torch.py:339, the
 learning-rate rule vfm-torch.py:92.
 
-Usage:  python tools/make_golden.py            (writes tests/golden/)
+Usage:  python tools/make_golden.py [--only name1,name2]     (writes tests/golden/)
+(the reference's fp32 sums are not bitwise reproducible from run to run, so regenerate a committed
+fixture only on purpose: `--only` limits the run to the named cases)
 """
 import ast
 import os
@@ -60,9 +62,17 @@ class EpsRecorder:
         self.tn._standard_normal = self.orig
 
 
-def make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed):
+LINKS = {"abs": torch.abs, "softplus": nn.functional.softplus}     # vfm-torch.py:126 / :125
+ONLY = None
+
+
+def wanted(name):
+    return ONLY is None or name in ONLY
+
+
+def make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed, n_samples=1, link="abs"):
     ns.update(N=N, M=M, nb_occ=nb_occ, EMBEDDING_SIZE=d,
-              N_VARIATIONAL_SAMPLES=1, LINK=torch.abs)
+              N_VARIATIONAL_SAMPLES=n_samples, LINK=LINKS[link])
     torch.manual_seed(seed)
     model = CF(d, output=output)
     if dtype == torch.float64:
@@ -93,12 +103,17 @@ def one_step(model, x, y, nb_train):
     model.zero_grad()
     loss.backward()
     uniq = torch.unique(x)
+    S = eps0.shape[0]                                       # N_VARIATIONAL_SAMPLES
     out = {
         "uniq": uniq.numpy(),
-        "eps0": eps0.numpy().reshape(-1),
-        "eps_w": eps_w.numpy().reshape(-1),                 # [U] over sorted uniq
-        "eps_v": eps_v.numpy().reshape(len(uniq), -1),      # [U, d]
-        "pred": lik.mean.detach().numpy().reshape(-1),      # sigmoid(logit) for 'class'
+        "eps0": eps0.numpy().reshape(-1),                   # [S]
+        # [U] / [U,d] over sorted uniq; with S > 1 samples: [S,U] / [S,U,d]
+        "eps_w": eps_w.numpy().reshape(-1) if S == 1 else eps_w.numpy().reshape(S, -1),
+        "eps_v": (eps_v.numpy().reshape(len(uniq), -1) if S == 1
+                  else eps_v.numpy().reshape(S, len(uniq), -1)),
+        # sigmoid(logit) for 'class'; [B], with S > 1 samples [S,B]
+        "pred": (lik.mean.detach().numpy().reshape(-1) if S == 1
+                 else lik.mean.detach().numpy().reshape(S, -1)),
         "kl": kl.detach().numpy().reshape(-1),
         "loss": loss.detach().numpy().reshape(-1),
         # alpha takes no part in the Bernoulli likelihood (vfm-torch.py:270): grad None
@@ -110,22 +125,27 @@ def one_step(model, x, y, nb_train):
         "g_entity_params": model.entity_params.weight.grad.numpy().copy(),
     }
     if model.output != "reg":
-        out["logits"] = lik.logits.detach().numpy().reshape(-1)
+        out["logits"] = (lik.logits.detach().numpy().reshape(-1) if S == 1
+                         else lik.logits.detach().numpy().reshape(S, -1))
     return out
 
 
 def single_case(ns, CF, name, N, M, d, x, y, nb_train, nb_occ, output,
-                seed=42, eps_seed=7, also_f64=True, sparse_rows=False):
+                seed=42, eps_seed=7, also_f64=True, sparse_rows=False, n_samples=1, link="abs"):
+    if not wanted(name):
+        return
     x = torch.as_tensor(x, dtype=torch.int64)
     y = torch.as_tensor(y, dtype=torch.float32)
     nb_occ = torch.as_tensor(nb_occ, dtype=torch.int64)
     rec = {"N": N, "M": M, "d": d, "nb_train": nb_train,
            "output": np.array(output), "x": x.numpy(), "y": y.numpy(),
            "nb_occ": nb_occ.numpy()}
+    if n_samples != 1 or link != "abs":
+        rec["n_samples"], rec["link"] = n_samples, np.array(link)
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         if dtype == torch.float64 and not also_f64:
             continue
-        model = make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed)
+        model = make_model(ns, CF, N, M, d, nb_occ, output, dtype, seed, n_samples, link)
         if dtype == torch.float32:
             p = param_dict(model)
         torch.manual_seed(eps_seed)
@@ -161,17 +181,22 @@ def single_case(ns, CF, name, N, M, d, x, y, nb_train, nb_occ, output,
 
 
 def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
-                    seed=42, eps_seed=11):
+                    seed=42, eps_seed=11, n_samples=1, link="abs"):
     """The loop of vfm-torch.py:347-370 for a few steps (incl. a short last batch)."""
+    if not wanted(name):
+        return
     X = torch.as_tensor(X, dtype=torch.int64)
     Y = torch.as_tensor(Y, dtype=torch.float32)
     nb_train = len(Y)
     nb_occ = torch.bincount(X.flatten(), minlength=N + M)   # vfm-torch.py:89
     lr = 1 / (1 + nb_train // batch)                        # vfm-torch.py:92
-    model = make_model(ns, CF, N, M, d, nb_occ, output, torch.float32, seed)
+    model = make_model(ns, CF, N, M, d, nb_occ, output, torch.float32, seed, n_samples, link)
     rec = {"N": N, "M": M, "d": d, "nb_train": nb_train, "batch": batch,
            "lr": lr, "n_epochs": n_epochs, "output": np.array(output),
            "x": X.numpy(), "y": Y.numpy(), "nb_occ": nb_occ.numpy()}
+    if n_samples != 1 or link != "abs":
+        rec["n_samples"], rec["link"] = n_samples, np.array(link)
+    S = n_samples
     for k, v in param_dict(model).items():
         rec[f"p0_{k}"] = v
     opt = torch.optim.Adam(model.parameters(), lr=lr)       # vfm-torch.py:339
@@ -191,9 +216,11 @@ def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
             uniq = torch.unique(x)
             rec[f"s{step}_uniq"] = uniq.numpy()
             rec[f"s{step}_eps0"] = e0.numpy().reshape(-1)
-            rec[f"s{step}_eps_w"] = ew.numpy().reshape(-1)
-            rec[f"s{step}_eps_v"] = ev.numpy().reshape(len(uniq), -1)
-            rec[f"s{step}_pred"] = lik.mean.detach().numpy().reshape(-1)
+            rec[f"s{step}_eps_w"] = ew.numpy().reshape(-1) if S == 1 else ew.numpy().reshape(S, -1)
+            rec[f"s{step}_eps_v"] = (ev.numpy().reshape(len(uniq), -1) if S == 1
+                                     else ev.numpy().reshape(S, len(uniq), -1))
+            rec[f"s{step}_pred"] = (lik.mean.detach().numpy().reshape(-1) if S == 1
+                                    else lik.mean.detach().numpy().reshape(S, -1))
             losses.append(float(loss))
             step += 1
     rec["n_steps"] = step
@@ -205,6 +232,9 @@ def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
 
 
 def main():
+    global ONLY
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     os.makedirs(OUT, exist_ok=True)
     ns = {"torch": torch, "nn": nn, "distributions": distributions, "np": np}
     CF, span = lift_cf(ns)
@@ -220,6 +250,12 @@ def main():
     assert (x[:, 1] == N).any() and nb_occ.min() > 0
     y = g.integers(1, 6, B).astype(np.float32)
     single_case(ns, CF, "quirk_reg_d8", N, M, d, x, y, nb_train, nb_occ, "reg")
+    # (1b) the reference's two other globals of the path (vfm-torch.py:19,125-126) on the same batch:
+    # N_VARIATIONAL_SAMPLES = 3, LINK = softplus, and both
+    single_case(ns, CF, "multi_reg_d8_s3", N, M, d, x, y, nb_train, nb_occ, "reg", n_samples=3)
+    single_case(ns, CF, "softplus_reg_d8", N, M, d, x, y, nb_train, nb_occ, "reg", link="softplus")
+    single_case(ns, CF, "softplus_multi_class_d8_s2", N, M, d, x, (y >= 3).astype(np.float32), nb_train, nb_occ,
+                "class", n_samples=2, link="softplus")
 
     # (2) fraction data set (reference data/fraction/data.csv: user,item,outcome), d=5, Bernoulli
     import pandas as pd
@@ -268,6 +304,7 @@ def main():
     single_case(ns, CF, "dup_reg_d12", N, M, d, x, y, nb_train, nb_occ, "reg")
     single_case(ns, CF, "dup_class_d12", N, M, d, x, (y >= 3).astype(np.float32), nb_train, nb_occ, "class",
                 also_f64=False)
+    single_case(ns, CF, "dup_multi_reg_d12_s2", N, M, d, x, y, nb_train, nb_occ, "reg", n_samples=2)
 
     # (5) 3 batches/epoch (1000,1000,500) x 2 epochs Adam trajectory, short last batch
     g = np.random.default_rng(3)
@@ -276,6 +313,7 @@ def main():
     X = np.stack([g.integers(0, N, nb), N + g.integers(0, M, nb)], 1)
     Y = g.integers(1, 6, nb).astype(np.float32)
     trajectory_case(ns, CF, "traj_reg_d16", N, M, d, X, Y, 1000, "reg")
+    trajectory_case(ns, CF, "traj_softplus_s2_reg_d16", N, M, d, X, Y, 1000, "reg", n_samples=2, link="softplus")
 
 
 if __name__ == "__main__":

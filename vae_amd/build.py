@@ -18,17 +18,38 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+# translation units of libvfm_hip.so: (source, object suffix, extra flags).  The row kernels are
+# compiled once per link function (vfm-torch.py:125-126: |.| and softplus).
+_UNITS = [("vfm_abi.hip", "", []),
+          ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
+          ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"])]
+
+
 def build_hip_library(force=False, verbose=False):
-    """libvfm_hip.so: kernels + C ABI (include/vfm_hip.h), gfx950 only."""
-    src = os.path.join(HERE, "csrc", "vfm_kernels.hip")
+    """libvfm_hip.so: kernels + C ABI (include/vfm_hip.h), gfx950 only.  The translation units are
+    compiled in parallel (hipcc -c) and linked into one shared object."""
+    csrc = os.path.join(HERE, "csrc")
     hdr = os.path.join(ROOT, "include", "vfm_hip.h")
-    parts = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc")))
-             if f.endswith(".hpp")]             # the kernels, included by vfm_kernels.hip (one TU)
+    parts = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hpp", ".hip"))]
     out = os.path.join(HERE, "libvfm_hip.so")
-    if not force and not _stale(out, [src, hdr] + parts):
+    if not force and not _stale(out, [hdr] + parts):
         return out
-    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-o", out, src]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden",
+              "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
+    jobs, objs = [], []
+    for src, suffix, extra in _UNITS:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + suffix + ".o")
+        cmd = common + extra + ["-c", os.path.join(csrc, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -1,35 +1,36 @@
-// vfm_kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels + C ABI for the
-// Variational-FM ELBO step.  Wave = 64 lanes; no MFMA: the path is gather + elementwise +
-// reduction and is bounded by HBM / Infinity-Cache bandwidth.
+// vfm_abi.hip -- the C ABI of libvfm_hip.so (include/vfm_hip.h): argument checks, kernel-argument
+// set-up and dispatch for the hand-written gfx950 (MI355X, CDNA4) kernels of the Variational-FM ELBO
+// step.  Wave = 64 lanes; no MFMA: the path is gather + elementwise + reduction and is bounded by
+// HBM / Infinity-Cache bandwidth.
 //
 // Replaces the per-batch body of the reference: vfm-torch.py:189-324 (CF.forward), the loss
 // line :359 and autograd through them (:368-369).  Math: SURVEY.md Appendix A.
 //
-// Kernels (details at each definition)
+// Kernels (details at each definition; translation units: vfm_args.hpp)
 //   k_fwd     : a *lane group* of LPE lanes owns one batch row, each lane CPL chunks of VEC
 //               coordinates; rows of a workgroup are contiguous; ids -> table rows -> arithmetic are
 //               software-pipelined in registers; FM reduction with DPP / permlane swaps; per-block
-//               partial sums to private slots (no atomics).
+//               partial sums to private slots (no atomics).                             [vfm_fwd.hip]
 //   k_finalize: adds the slots, forms the loss (also foldable into the fused backward).
 //   k_bwd     : entity-centric.  A lane group owns one TABLE row e, sums grow[r]*sumz[r,:] over the
 //               batch rows containing e (inverted index) and either stores the dense gradient row,
 //               applies dense Adam in place (ADAM), or -- multi-rank -- stores / consumes the
-//               gradient's sufficient statistics (STAGE_ACC / STAGE_APPLY).
+//               gradient's sufficient statistics (STAGE_ACC / STAGE_APPLY).             [vfm_bwd.hip]
 //   k_heavy   : parallel pre-reduction of occurrence lists longer than VFM_HEAVY_LIST (skewed data).
 //   k_adam    : dense Adam on a flat buffer (unfused path).  k_norms, k_inv_occ: per-batch / per-dataset
 //               normalisers.  k_philox_dump: the eps stream, for tests.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
 #include <stdlib.h>
 
-#include "vfm_hip.h"
+#include "vfm_args.hpp"
+
+namespace vfm {
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
 int fail(int code, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -39,26 +40,24 @@ int fail_hip(hipError_t e, const char* where) {
   snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
   return (int)e;
 }
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 
-constexpr int BLOCK = 256;
-constexpr float LOG_SQRT_2PI = 0.918938533204672742f;
-constexpr float LN2 = 0.693147180559945309f;
+namespace {
 
 #include "vfm_rng.hpp"
 #include "vfm_common.hpp"
+#include "vfm_reduce.hpp"
 #include "vfm_small_kernels.hpp"
-#include "vfm_fwd.hpp"
-#include "vfm_bwd.hpp"
+#include "vfm_heavy.hpp"
 #include "vfm_shard.hpp"
 #include "vfm_adam.hpp"
 
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-struct Shape {
-  int lpe, cpl, vec;
-};
-
 bool pick_shape(int d, Shape* s) {
   auto pow2ceil = [](int v) { int p = 1; while (p < v) p <<= 1; return p; };
   if (d % 4 == 0) {
@@ -84,7 +83,9 @@ int check_problem(const vfm_problem_t* p) {
   if (p->id_bits != 32 && p->id_bits != 64) return fail(VFM_E_INVALID, "id_bits must be 32 or 64");
   if (p->likelihood != VFM_LIK_NORMAL && p->likelihood != VFM_LIK_BERNOULLI)
     return fail(VFM_E_INVALID, "unknown likelihood");
-  if (p->n_samples != 1) return fail(VFM_E_UNSUPPORTED, "only n_samples == 1 is supported");
+  if (p->n_samples < 1 || p->n_samples > MAX_SAMPLES) return fail(VFM_E_INVALID, "n_samples out of range [1,64]");
+  if (p->n_samples > 1 && (p->step >> 48) != 0) return fail(VFM_E_INVALID, "step must stay below 2^48 when n_samples > 1");
+  if (p->n_samples > 1 && (p->flags & VFM_FLAG_ZPRE)) return fail(VFM_E_UNSUPPORTED, "n_samples > 1 with VFM_FLAG_ZPRE (entity-sharded mode)");
   if (p->B_global < p->B) return fail(VFM_E_INVALID, "B_global < B");
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
   if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
@@ -94,10 +95,14 @@ int check_problem(const vfm_problem_t* p) {
   return 0;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
+// the multi-rank stages exchange single-sample statistics
+int single_sample_only(const vfm_problem_t* p, const char* who) {
+  if (p->n_samples == 1) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: n_samples > 1 is not supported by this entry point", who);
+  return VFM_E_UNSUPPORTED;
 }
+
+bool softplus(const vfm_problem_t* p) { return (p->flags & VFM_FLAG_LINK_SOFTPLUS) != 0; }
 
 // eps source of a call: VFM_FLAG_EPS_ZERO > tables > Philox
 int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const float* eg, int* mode) {
@@ -108,16 +113,23 @@ int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const flo
   return 0;
 }
 
+// `sample`: the variational sample a forward launch handles (S > 1: one launch per sample; the eps
+// tables of sample s are the s-th [T,d] / [T] blocks).  Backward launches take sample 0 = the base.
 KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const float* entity,
                 const float* bias, const float* inv_occ, const float* scalars, const double* W,
-                const float* ee, const float* eb, const float* eg) {
+                const float* ee, const float* eb, const float* eg, int sample = 0) {
   KArgs a;
   memset(&a, 0, sizeof(a));
+  a.S = p->n_samples; a.sample = sample; a.inv_S = 1.0f / (float)p->n_samples;
+  if (sample > 0) {
+    if (ee) ee += (size_t)sample * (size_t)p->T * (size_t)p->d;
+    if (eb) eb += (size_t)sample * (size_t)p->T;
+  }
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.lik = p->likelihood;
   a.e_lo = p->e_lo; a.e_hi = (p->e_hi > 0 && p->e_hi < p->T) ? p->e_hi : p->T;
   a.own_mod = p->own_mod > 1 ? p->own_mod : 1; a.own_rank = p->own_mod > 1 ? p->own_rank : 0;
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
-  a.ll_scale_d = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
+  a.ll_scale_d = (double)p->nb_train / ((double)(p->B_global > 0 ? p->B_global : 1) * (double)p->n_samples);
   a.ll_scale = (float)a.ll_scale_d;
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
   a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32);
@@ -127,94 +139,23 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   return a;
 }
 
-// ---- forward dispatch: shape x eps source x mode x (F == 2 ?) ----
-template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF, bool ID64>
-int launch_fwd_t(KArgs& a, const FwdOut& o, hipStream_t st) {
-  constexpr int GPB = BLOCK / LPE;
-  // persistent-ish grid: enough groups that each owns a few rows (pipelined), capped at
-  // VFM_FWD_BLOCKS_PER_CU resident workgroups on each of the 256 CUs
-  const int per_cu = env_int("VFM_FWD_BLOCKS_PER_CU", 4);
-  int64_t nb = (a.B + GPB - 1) / GPB;
-  int64_t cap = 256LL * per_cu;
-  if (cap > VFM_MAX_FWD_BLOCKS) cap = VFM_MAX_FWD_BLOCKS;
-  if (nb > cap) nb = cap;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((k_fwd<LPE, CPL, VEC, EPS, MODE, FF, ID64>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
-  return 0;
-}
-
-template <int LPE, int CPL, int VEC>
-int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream_t st) {
-#define FWD(E_, M_)                                                              \
-  if (eps == E_ && mode == M_) {                                                 \
-    if constexpr (VEC == 4) {                                                    \
-      if constexpr (LPE >= 2) {                                                              \
-        if (ff == 2 && a.id64) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2, true>(a, o, st);  \
-        if (ff == 2) return launch_fwd_t<LPE, CPL, VEC, E_, M_, 2, false>(a, o, st);           \
-      }                                                                                      \
-    }                                                                            \
-    return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0, true>(a, o, st);               \
-  }
-  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN) FWD(EPS_ZPRE, MODE_TRAIN)
-  FWD(EPS_PHILOX, MODE_PREDICT) FWD(EPS_TABLE, MODE_PREDICT) FWD(EPS_ZERO, MODE_PREDICT)
-#undef FWD
-  return fail(VFM_E_UNSUPPORTED, "forward: unsupported eps source / mode combination");
-}
-
-template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
-int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
-  constexpr int GPB = BLOCK / LPE;
-  const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
-  int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
-  const int64_t cap = 256LL * per_cu;
-  if (nb > cap) nb = cap;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
-  return 0;
-}
-
-template <int LPE, int CPL, int VEC>
-int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
-  if (eps == EPS_PHILOX && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 0>(a, b, ad, st);
-  if (eps == EPS_TABLE && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 0>(a, b, ad, st);
-  if (eps == EPS_PHILOX && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1>(a, b, ad, st);
-  if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
-  if (eps == EPS_PHILOX && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 2>(a, b, ad, st);
-  if (eps == EPS_TABLE && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 2>(a, b, ad, st);
-  if (adam == 10) return launch_bwd_t<LPE, CPL, VEC, EPS_ZERO, 0, STAGE_ACC>(a, b, ad, st);
-  if (eps == EPS_PHILOX && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1, STAGE_APPLY>(a, b, ad, st);
-  if (eps == EPS_TABLE && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1, STAGE_APPLY>(a, b, ad, st);
-  return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
-}
-
-#define FOR_SHAPES(X)                                                                          \
-  X(1, 1, 4) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(32, 1, 4) X(64, 1, 4) X(64, 2, 4) \
-  X(64, 4, 4) X(8, 1, 1) X(64, 1, 1) X(64, 4, 1)
-
-int dispatch_fwd(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream_t st) {
-#define X(L_, C_, V_) \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return launch_fwd_s<L_, C_, V_>(eps, mode, ff, a, o, st);
-  FOR_SHAPES(X)
-#undef X
-  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
-}
-
-int dispatch_bwd(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad,
+int dispatch_fwd(const vfm_problem_t* p, const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,
                  hipStream_t st) {
-#define X(L_, C_, V_) \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return launch_bwd_s<L_, C_, V_>(eps, adam, a, b, ad, st);
-  FOR_SHAPES(X)
-#undef X
-  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+  return softplus(p) ? launch_fwd_softplus(s, eps, mode, ff, a, o, st) : launch_fwd_abs(s, eps, mode, ff, a, o, st);
+}
+int dispatch_bwd(const vfm_problem_t* p, const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,
+                 const AdamArgs& ad, hipStream_t st) {
+  return softplus(p) ? launch_bwd_softplus(s, eps, adam, a, b, ad, st) : launch_bwd_abs(s, eps, adam, a, b, ad, st);
 }
 
 template <int LPE, int CPL, int VEC>
-int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, int d, hipStream_t st) {
+int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, float* heavy_acc, int d,
+                   hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
   int64_t nb = ((int64_t)idx->n_items + GPB - 1) / GPB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
-                     (int)idx->n_items, idx->occ_rows, sumz, grow, idx->heavy_acc, d);
+                     (int)idx->n_items, idx->occ_rows, sumz, grow, heavy_acc, d);
   return 0;
 }
 
@@ -226,14 +167,19 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
   if (!idx->heavy_ids || !idx->heavy_items || !idx->heavy_acc)
     return fail(VFM_E_INVALID, "index: heavy_ids / heavy_items / heavy_acc missing");
   const size_t xs = 4 + (((size_t)p->d + 3) & ~(size_t)3);
-  hipError_t e = hipMemsetAsync(idx->heavy_acc, 0, sizeof(float) * xs * (size_t)idx->n_heavy, st);
+  const size_t per_sample = xs * (size_t)idx->n_heavy;       // heavy_acc: one block of records per sample
+  hipError_t e = hipMemsetAsync(idx->heavy_acc, 0, sizeof(float) * per_sample * (size_t)p->n_samples, st);
   if (e != hipSuccess) return fail_hip(e, "heavy_acc memset");
   Shape s;
   pick_shape(p->d, &s);
+  for (int sm = 0; sm < p->n_samples; ++sm) {
+    const float* sz = sumz + (size_t)sm * (size_t)p->B * (size_t)p->d;
+    float* hacc = idx->heavy_acc + (size_t)sm * per_sample;
 #define X(L_, C_, V_) \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(idx, sumz, grow, p->d, st);
-  FOR_SHAPES(X)
+    if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(idx, sz, grow, hacc, p->d, st);
+    VFM_FOR_SHAPES(X)
 #undef X
+  }
   b->heavy_ids = idx->heavy_ids; b->heavy_acc = idx->heavy_acc; b->n_heavy = idx->n_heavy;
   return 0;
 }
@@ -260,6 +206,9 @@ void adam_consts(float lr, float beta1, float beta2, int64_t step, float* step_s
 }
 
 }  // namespace
+}  // namespace vfm
+
+using namespace vfm;
 
 extern "C" {
 
@@ -313,12 +262,14 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   if (zpre) eps = EPS_ZPRE;
   hipStream_t st = (hipStream_t)stream;
-  KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
-                      eps_global);
   FwdOut o{pred, partials, sumz, grow};
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_fwd(s, eps, train ? MODE_TRAIN : MODE_PREDICT, p->F == 2 ? 2 : 0, a, o, st)) return rc;
+  for (int sm = 0; sm < p->n_samples; ++sm) {      // one launch per variational sample (vfm_fwd.hpp)
+    KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
+                        eps_global, sm);
+    if (int rc = dispatch_fwd(p, s, eps, train ? MODE_TRAIN : MODE_PREDICT, p->F == 2 ? 2 : 0, a, o, st)) return rc;
+  }
   return after_launch("vfm_elbo_fwd_f32");
 }
 
@@ -326,7 +277,7 @@ int vfm_elbo_finalize_f32(const vfm_problem_t* p, double* partials, const float*
                           float* loss, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!partials || !scalars || !loss) return fail(VFM_E_INVALID, "vfm_elbo_finalize_f32: NULL pointer");
-  const double ll_scale = (double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1);
+  const double ll_scale = (double)p->nb_train / ((double)(p->B_global > 0 ? p->B_global : 1) * (double)p->n_samples);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, partials, scalars, ll_scale,
                      (int)p->flags, loss);
   return after_launch("vfm_elbo_finalize_f32");
@@ -356,7 +307,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   memset(&ad, 0, sizeof(ad));
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(s, eps, 0, a, b, ad, (hipStream_t)stream)) return rc;
+  if (int rc = dispatch_bwd(p, s, eps, 0, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_f32");
 }
 
@@ -389,7 +340,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
+  if (int rc = dispatch_bwd(p, s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
     return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");
 }
@@ -398,6 +349,7 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                          const float* sumz, const float* grow, const double* partials, float* acc,
                          float* sums, void* stream) {
   if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_elbo_bwd_acc_f32")) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_acc_f32")) return rc;
   if (!partials || !acc || !sums || (p->B > 0 && (!sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
@@ -412,7 +364,7 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   memset(&ad, 0, sizeof(ad));
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(s, EPS_ZERO, 10, a, b, ad, (hipStream_t)stream)) return rc;
+  if (int rc = dispatch_bwd(p, s, EPS_ZERO, 10, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_acc_f32");
 }
 
@@ -424,6 +376,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
                             const int32_t* rec_pos, void* stream) {
   if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_elbo_apply_adam_f32")) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: bad argument");
@@ -442,7 +395,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
+  if (int rc = dispatch_bwd(p, s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
   if (kl_ws) hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, kl_ws);
   return after_launch("vfm_elbo_apply_adam_f32");
 }
@@ -451,6 +404,7 @@ int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, 
                          const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
                          void* stream) {
   if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_shard_sample_f32")) return rc;
   if (n < 0 || n > 0x7FFFFFFFLL || (n > 0 && (!ids || !entity_params || !bias_params || !out)))
     return fail(VFM_E_INVALID, "vfm_shard_sample_f32: bad argument");
   if ((eps_entity == nullptr) != (eps_bias == nullptr))
@@ -461,18 +415,10 @@ int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, 
   Shape s;
   pick_shape(p->d, &s);
   hipStream_t st = (hipStream_t)stream;
-#define X(L_, C_, V_)                                                                              \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                 \
-    constexpr int GPB = BLOCK / L_;                                                                \
-    int64_t nb = (n + GPB - 1) / GPB;   /* one record per lane group: latency is hidden by occupancy */ \
-    if (nb > 65535) nb = 65535;                                                                    \
-    if (eps_entity)                                                                                \
-      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_TABLE>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, (int)n, out); \
-    else                                                                                           \
-      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_PHILOX>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, (int)n, out); \
-  }
-  FOR_SHAPES(X)
-#undef X
+  const int em = eps_entity ? EPS_TABLE : EPS_PHILOX;
+  if (int rc = softplus(p) ? launch_sample_softplus(s, em, a, ids, (int)n, out, st)
+                           : launch_sample_abs(s, em, a, ids, (int)n, out, st))
+    return rc;
   return after_launch("vfm_shard_sample_f32");
 }
 
@@ -524,10 +470,13 @@ int vfm_philox_eps_f32(const vfm_problem_t* p, float* eps_entity, float* eps_bia
                        void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!eps_entity || !eps_bias || !eps_global) return fail(VFM_E_INVALID, "vfm_philox_eps_f32: NULL pointer");
-  KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                      nullptr);
-  hipLaunchKernelGGL(k_philox_dump, dim3(1024), dim3(256), 0, (hipStream_t)stream, a, eps_entity, eps_bias,
-                     eps_global);
+  for (int sm = 0; sm < p->n_samples; ++sm) {     // tables of sample s: the s-th [T,d] / [T] / [1] blocks
+    KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, sm);
+    hipLaunchKernelGGL(k_philox_dump, dim3(1024), dim3(256), 0, (hipStream_t)stream, a,
+                       eps_entity + (size_t)sm * (size_t)p->T * (size_t)p->d, eps_bias + (size_t)sm * (size_t)p->T,
+                       eps_global + sm);
+  }
   return after_launch("vfm_philox_eps_f32");
 }
 

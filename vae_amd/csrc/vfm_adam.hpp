@@ -1,5 +1,5 @@
 // vfm_adam.hpp -- k_adam (dense Adam on a flat buffer), k_philox_dump.
-// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+// Included inside `namespace vfm { namespace {` of vfm_abi.hip.
 #pragma once
 
 // ---------------------------------------------------------------------------------------
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(BLOCK) void k_adam(float* __restrict__ p, const flo
 
 // eps dump (tests)
 __global__ void k_philox_dump(const KArgs a, float* eps_entity, float* eps_bias, float* eps_global) {
+  const RngKey key = key_of_sample(a.key, a.sample);
   const int64_t n8 = ((int64_t)a.d + 7) / 8;
   const int64_t total = a.T * n8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -48,14 +49,14 @@ __global__ void k_philox_dump(const KArgs a, float* eps_entity, float* eps_bias,
     const int64_t e = i / n8;
     const int p = (int)(i % n8);
     float n[8], nb;
-    normal8b(a.key, (uint32_t)e, (uint32_t)p, n, nb);
+    normal8b(key, (uint32_t)e, (uint32_t)p, n, nb);
     for (int t = 0; t < 8; ++t)
       if (p * 8 + t < a.d) eps_entity[e * a.d + p * 8 + t] = n[t];
     if (p == 0) eps_bias[e] = nb;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float n[8], nb;
-    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+    normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
     eps_global[0] = n[0];
   }
 }

@@ -1,0 +1,117 @@
+// vfm_args.hpp -- kernel argument structs and the host-side declarations shared by the translation
+// units of libvfm_hip.so:
+//   vfm_abi.hip  C ABI (include/vfm_hip.h), argument checks, small / Adam / shard glue kernels, k_heavy
+//   vfm_fwd.hip  k_fwd instances + dispatch            (compiled once per link function, -DVFM_LINK=0|1)
+//   vfm_bwd.hip  k_bwd, k_sample instances + dispatch  (compiled once per link function)
+// Splitting keeps every kernel family in its own object (built in parallel by vae_amd/build.py); a
+// kernel is always launched from the unit that defines it, so no relocatable device code is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vfm_hip.h"
+
+#define VFM_INTERNAL __attribute__((visibility("hidden")))
+
+namespace vfm {
+
+constexpr int BLOCK = 256;
+constexpr float LOG_SQRT_2PI = 0.918938533204672742f;
+constexpr float LN2 = 0.693147180559945309f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct RngKey {
+  uint32_t seed_lo, seed_hi, step_lo, step_hi;   // step_hi carries the sample index in bits 16.. (S > 1)
+};
+
+// Kernel arguments (by value)
+struct KArgs {
+  int64_t B, T;
+  int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
+  int32_t own_mod, own_rank;   // entity-sharded apply: this rank owns e = own_rank (mod own_mod)
+  int32_t F, d, lik, id64, G, flags;
+  int32_t S, sample;    // variational samples: S of them; the forward runs one launch per sample
+  float inv_S;
+  float ll_scale;  // nb_train / (B_global * S)
+  double ll_scale_d;
+  RngKey key;
+  const void* x;
+  const float* y;
+  const float* entity;
+  const float* bias;
+  const float* inv_occ;
+  const float* scalars;
+  const double* W;
+  const float* eps_entity;
+  const float* eps_bias;
+  const float* eps_global;
+  int64_t group_hi[VFM_MAX_FIELDS];
+  double group_n[VFM_MAX_FIELDS];
+};
+
+struct FwdOut {
+  float* pred;
+  double* partials;
+  float* sumz;
+  float* grow;
+};
+
+struct BwdArgs {
+  const int32_t* occ_ptr;
+  const int32_t* occ_rows;
+  const float* sumz;
+  const float* grow;
+  double* partials;
+  const float* grad_out;
+  float* g_entity;
+  float* g_bias;
+  float* g_scalars;
+  float* loss;   // non-NULL: this launch also reduces the forward's partial slots and forms the loss
+  // staged (multi-rank) form: sufficient statistics of the gradient, exchanged instead of the gradient
+  float* acc;    // [T, 4 + round4(d)] record per entity: (sum_r grow_r, occurrences, 0, 0 | A_e[0..d-1]),
+                 //   A_e = sum_r grow_r * sumz_r      (STAGE_ACC writes, STAGE_APPLY reads)
+  float* sums;   // [2]    (sum_r grow_r over all rows, alpha term)
+  // entities whose occurrence list is longer than VFM_HEAVY_LIST: pre-reduced by k_heavy
+  const int32_t* heavy_ids;   // [n_heavy] sorted
+  const float* heavy_acc;     // [S, n_heavy, 4 + round4(d)] records (sum grow, count, 0, 0 | A_e) per sample
+  int32_t n_heavy;
+  double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
+};
+
+struct AdamArgs {
+  float* m_entity; float* v_entity; float* m_bias; float* v_bias; float* m_scal; float* v_scal;
+  float b1, b2, eps, step_size, bc2_sqrt;
+};
+
+// lane-group shape of the row kernels for an embedding size (see pick_shape in vfm_abi.hip)
+struct Shape {
+  int lpe, cpl, vec;
+};
+
+enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3 };
+enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
+enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
+enum { LINK_ABS = 0, LINK_SOFTPLUS = 1 };
+constexpr int MAX_SAMPLES = 64;
+
+// thread-local error string behind vfm_last_error() (defined in vfm_abi.hip)
+VFM_INTERNAL int fail(int code, const char* msg);
+VFM_INTERNAL int fail_hip(hipError_t e, const char* where);
+VFM_INTERNAL int env_int(const char* name, int dflt);
+
+// per-link-function launchers (vfm_fwd.hip / vfm_bwd.hip, one object per link)
+#define VFM_DECLARE_LAUNCHERS(SUFFIX)                                                                          \
+  VFM_INTERNAL int launch_fwd_##SUFFIX(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,   \
+                                       hipStream_t st);                                                        \
+  VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
+                                       const AdamArgs& ad, hipStream_t st);                                    \
+  VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \
+                                          float* out, hipStream_t st);
+VFM_DECLARE_LAUNCHERS(abs)
+VFM_DECLARE_LAUNCHERS(softplus)
+
+#define VFM_FOR_SHAPES(X)                                                                      \
+  X(1, 1, 4) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(32, 1, 4) X(64, 1, 4) X(64, 2, 4) \
+  X(64, 4, 4) X(8, 1, 1) X(64, 1, 1) X(64, 4, 1)
+
+}  // namespace vfm

@@ -1,0 +1,94 @@
+// vfm_bwd.hip -- k_bwd (entity-centric gradients / fused Adam / multi-rank stages) and k_sample
+// instances with their dispatch.  Compiled once per link function: -DVFM_LINK=0 (|.|) / 1 (softplus).
+// gfx950 only, wave = 64.  See vfm_args.hpp for how libvfm_hip.so is split into translation units.
+#include <math.h>
+
+#include "vfm_args.hpp"
+
+#ifndef VFM_LINK
+#error "compile with -DVFM_LINK=0 (abs) or -DVFM_LINK=1 (softplus)"
+#endif
+
+namespace vfm {
+namespace {
+
+#include "vfm_rng.hpp"
+#include "vfm_common.hpp"
+#include "vfm_reduce.hpp"
+#include "vfm_bwd.hpp"
+#include "vfm_sample.hpp"
+
+constexpr int LINK = VFM_LINK;
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
+int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  constexpr int GPB = BLOCK / LPE;
+  const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
+  int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
+  const int64_t cap = 256LL * per_cu;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+  return 0;
+}
+
+// adam: 0 gradients, 1 dense Adam fused, 2 row-sparse Adam fused, 10 statistics (STAGE_ACC), 11 apply (STAGE_APPLY)
+template <int LPE, int CPL, int VEC>
+int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  if (eps == EPS_PHILOX && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 0>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 0>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 2>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 2>(a, b, ad, st);
+  if (adam == 10) return launch_bwd_t<LPE, CPL, VEC, EPS_ZERO, 0, STAGE_ACC>(a, b, ad, st);
+  if (eps == EPS_PHILOX && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1, STAGE_APPLY>(a, b, ad, st);
+  if (eps == EPS_TABLE && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1, STAGE_APPLY>(a, b, ad, st);
+  return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
+}
+
+int dispatch_bwd(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad,
+                 hipStream_t st) {
+#define X(L_, C_, V_) \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) return launch_bwd_s<L_, C_, V_>(eps, adam, a, b, ad, st);
+  VFM_FOR_SHAPES(X)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+}
+
+int dispatch_sample(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
+#define X(L_, C_, V_)                                                                                   \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                      \
+    constexpr int GPB = BLOCK / L_;                                                                     \
+    int64_t nb = ((int64_t)n + GPB - 1) / GPB;   /* one record per lane group: latency is hidden by occupancy */ \
+    if (nb > 65535) nb = 65535;                                                                         \
+    if (eps == EPS_TABLE)                                                                               \
+      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_TABLE, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, n, out); \
+    else                                                                                                \
+      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_PHILOX, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, n, out); \
+    return 0;                                                                                           \
+  }
+  VFM_FOR_SHAPES(X)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+}
+
+}  // namespace
+
+#if VFM_LINK == 0
+int launch_bwd_abs(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  return dispatch_bwd(s, eps, adam, a, b, ad, st);
+}
+int launch_sample_abs(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
+  return dispatch_sample(s, eps, a, ids, n, out, st);
+}
+#else
+int launch_bwd_softplus(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+  return dispatch_bwd(s, eps, adam, a, b, ad, st);
+}
+int launch_sample_softplus(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
+  return dispatch_sample(s, eps, a, ids, n, out, st);
+}
+#endif
+
+}  // namespace vfm

@@ -1,5 +1,5 @@
-// vfm_bwd.hpp -- k_heavy, k_bwd: entity-centric gradients / fused Adam / multi-rank stages.
-// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+// vfm_bwd.hpp -- k_bwd: entity-centric gradients / fused Adam / multi-rank stages.
+// Included inside `namespace vfm { namespace {` of vfm_bwd.hip (one object per link function).
 #pragma once
 
 // ---------------------------------------------------------------------------------------
@@ -13,74 +13,16 @@
 // are read, so the in-place update is race free.  All loads that do not depend on the index
 // chain (own row, Adam moments, next entity's offsets) are issued before walking it.
 // ---------------------------------------------------------------------------------------
-struct AdamArgs {
-  float* m_entity; float* v_entity; float* m_bias; float* v_bias; float* m_scal; float* v_scal;
-  float b1, b2, eps, step_size, bc2_sqrt;
-};
-
+//
+// Variational samples S > 1 (STAGE_FULL only): sumz holds one [B,d] block per sample and grow[r] the
+// sum over samples of dloss/dpred[s,r]; with A^s = sum_r grow_r sumz^s_r and gs = sum_r grow_r,
+//   dloss/dmu_e = 1/S sum_s (A^s - z^s gs),   dloss/ds_e = link'(s_e) 1/S sum_s eps^s (A^s - z^s gs)
+// (+ the KL part, which does not depend on the sample): the list of e is walked once per sample.
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamArgs& ad) {
   m = m + (g - m) * (1.0f - ad.b1);
   v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
   const float denom = __fsqrt_rn(v) / ad.bc2_sqrt + ad.eps;
   return p + (-ad.step_size * m) / denom;
-}
-
-// Skewed batches (a popular item can own 10^4 of the 10^5 rows): an occurrence list longer than
-// VFM_HEAVY_LIST is cut in chunks of that length (work items built with the index), each walked by
-// its own lane group here and added -- a few float atomics per chunk -- into the entity's record of a
-// small scratch table; the main kernel then reads that record instead of walking the list.  Without
-// it one lane group serialises the whole list (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
-template <int LPE, int CPL, int VEC>
-__global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ items, int n_items,
-                                                 const int32_t* __restrict__ occ_rows,
-                                                 const float* __restrict__ sumz, const float* __restrict__ grow,
-                                                 float* __restrict__ heavy_acc, int d) {
-  constexpr int GPB = BLOCK / LPE;
-  const int lig = threadIdx.x % LPE;
-  const int C = (d + VEC - 1) / VEC;
-  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
-  for (int it = blockIdx.x * GPB + threadIdx.x / LPE; it < n_items; it += gridDim.x * GPB) {
-    const int slot = items[4 * it], beg = items[4 * it + 1], end = items[4 * it + 2];
-    Chunk<VEC> A[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
-    float gs = 0.f;
-    for (int o = beg; o < end; o += 4) {      // four occurrences in flight
-      int r[4]; float g[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = o + u < end;
-        r[u] = occ_rows[ok ? o + u : beg];
-        g[u] = ok ? grow[r[u]] : 0.f;
-        gs += g[u];
-      }
-#pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int j = lig + i * LPE;
-        if (j < C) {
-          Chunk<VEC> sv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sv[u] = ld_chunk<VEC>(sumz + (size_t)r[u] * d + (size_t)j * VEC);
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g[u], sv[u].v[t], A[i].v[t]);
-        }
-      }
-    }
-    float* rec = heavy_acc + (size_t)slot * xs;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int j = lig + i * LPE;
-      if (j < C) {
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) atomicAdd(rec + 4 + (size_t)j * VEC + t, A[i].v[t]);
-      }
-    }
-    if (lig == 0) { atomicAdd(rec, gs); atomicAdd(rec + 1, (float)(end - beg)); }
-  }
 }
 
 __device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
@@ -92,14 +34,12 @@ __device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
   return (n > 0 && ids[lo] == e) ? lo : -1;
 }
 
-enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
-
-template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE>
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK>
 __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
-  __shared__ double sh_fin[5][BLOCK / 64];
+  __shared__ double sh_fin[6][BLOCK / 64];
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int d = a.d;
@@ -111,7 +51,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   __syncthreads();
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
 
-  double fin[5] = {0, 0, 0, 0, 0};
+  double fin[6] = {0, 0, 0, 0, 0, 0};
   const bool fold = STAGE == STAGE_FULL && b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
@@ -131,12 +71,14 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
       e0 = n[0];
     }
-    const float as0 = fabsf(s0);
+    const float as0 = link_f<LINK>(s0);
     const float prior = (a.flags & VFM_FLAG_NO_PRIOR_TERMS) ? 0.f : 1.f;
     const float ga = (a.lik == VFM_LIK_NORMAL)
-                         ? gout * signf(alpha) * a.ll_scale * sum_a : 0.f;
+                         ? gout * dlink_f<LINK>(alpha) * a.ll_scale * sum_a : 0.f;
     const float gm = gout * (sum_g + prior * m0);
-    const float gs = gout * signf(s0) * (e0 * sum_g + prior * (as0 - inv_sigma(as0)));
+    // S > 1: every sample has its own eps0 -- the forward accumulated sum_s eps0^s sum_r g_sr
+    const float ge0 = (a.S > 1) ? (float)(fold ? fin[VFM_P_GE0] : b.partials[VFM_P_GE0]) : e0 * sum_g;
+    const float gs = gout * dlink_f<LINK>(s0) * (ge0 + prior * (as0 - inv_sigma(as0)));
     if constexpr (ADAM) {
       float* sc = const_cast<float*>(a.scalars);
       const float gg[3] = {ga, gm, gs};
@@ -220,18 +162,19 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       }
     }
 
-    // walk the inverted index: A = sum_r g_r * sumz_r, gs = sum_r g_r
-    Chunk<VEC> A[CPL];
+    // walk the inverted index: A = sum_r g_r * sumz_r, gs = sum_r g_r  (sz / hacc: the sample's blocks)
+    int hslot = -1;
+    if (STAGE != STAGE_APPLY && b.n_heavy > 0 && end - beg > VFM_HEAVY_MIN)
+      hslot = heavy_slot_of(b.heavy_ids, b.n_heavy, (int)e);
+    auto walk = [&](const float* __restrict__ sz, const float* __restrict__ hacc, Chunk<VEC>(&A)[CPL], float& gs) {
 #pragma unroll
-    for (int i = 0; i < CPL; ++i)
+      for (int i = 0; i < CPL; ++i)
 #pragma unroll
-      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
-    float gs = 0.f;
-    int o = beg;
-    if (STAGE != STAGE_APPLY && b.n_heavy > 0 && end - beg > VFM_HEAVY_MIN) {
-      const int slot = heavy_slot_of(b.heavy_ids, b.n_heavy, (int)e);
-      if (slot >= 0) {      // pre-reduced by k_heavy: read the record, skip the walk
-        const float* rec = b.heavy_acc + (size_t)slot * xs;
+        for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
+      gs = 0.f;
+      int o = beg;
+      if (hslot >= 0) {      // pre-reduced by k_heavy: read the record, skip the walk
+        const float* rec = hacc + (size_t)hslot * xs;
         gs = rec[0];
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
@@ -240,36 +183,39 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         }
         o = end;
       }
-    }
-    for (; o + 1 < end; o += 2) {       // two occurrences in flight
-      const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
-      const float g0 = b.grow[r0], g1 = b.grow[r1];
-      gs += g0 + g1;
+      for (; o + 1 < end; o += 2) {       // two occurrences in flight
+        const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
+        const float g0 = b.grow[r0], g1 = b.grow[r1];
+        gs += g0 + g1;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int j = lig + i * LPE;
-        if (j < C) {
-          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
-          const Chunk<VEC> s1v = ld_chunk<VEC>(b.sumz + (size_t)r1 * d + (size_t)j * VEC);
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) {
+            const Chunk<VEC> s0v = ld_chunk<VEC>(sz + (size_t)r0 * d + (size_t)j * VEC);
+            const Chunk<VEC> s1v = ld_chunk<VEC>(sz + (size_t)r1 * d + (size_t)j * VEC);
 #pragma unroll
-          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g1, s1v.v[t], fmaf(g0, s0v.v[t], A[i].v[t]));
+            for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g1, s1v.v[t], fmaf(g0, s0v.v[t], A[i].v[t]));
+          }
         }
       }
-    }
-    if (o < end) {
-      const int r0 = b.occ_rows[o];
-      const float g0 = b.grow[r0];
-      gs += g0;
+      if (o < end) {
+        const int r0 = b.occ_rows[o];
+        const float g0 = b.grow[r0];
+        gs += g0;
 #pragma unroll
-      for (int i = 0; i < CPL; ++i) {
-        const int j = lig + i * LPE;
-        if (j < C) {
-          const Chunk<VEC> s0v = ld_chunk<VEC>(b.sumz + (size_t)r0 * d + (size_t)j * VEC);
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) {
+            const Chunk<VEC> s0v = ld_chunk<VEC>(sz + (size_t)r0 * d + (size_t)j * VEC);
 #pragma unroll
-          for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g0, s0v.v[t], A[i].v[t]);
+            for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g0, s0v.v[t], A[i].v[t]);
+          }
         }
       }
-    }
+    };
+    Chunk<VEC> A[CPL];
+    float gs;
+    walk(b.sumz, b.heavy_acc, A, gs);
 
     if constexpr (STAGE == STAGE_ACC) {   // store the statistics (dense: zeros for rows not in this shard)
 #pragma unroll
@@ -327,12 +273,63 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       c = sh_cs[group_index(sh_hi, a.G, e)] * io * cntf;
     }
     float nb_eps = 0.f;
+    // S > 1 (uniform): g1s = 1/S sum_s (A^s - z^s gs), g2s = 1/S sum_s eps^s (A^s - z^s gs), nb_eps = mean_s eps_w^s
+    const bool multi = STAGE == STAGE_FULL && a.S > 1;
+    Chunk<VEC> g1s[CPL], g2s[CPL];
+    if (multi && touched) {
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) { g1s[i].v[t] = 0.f; g2s[i].v[t] = 0.f; }
+      for (int sm = 0; sm < a.S; ++sm) {
+        if (sm > 0)
+          walk(b.sumz + (size_t)sm * (size_t)a.B * d, b.heavy_acc + (size_t)sm * (size_t)b.n_heavy * xs, A, gs);
+        const RngKey ks = key_of_sample(a.key, sm);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) {
+            Chunk<VEC> epc;
+            if constexpr (EPS == EPS_TABLE) {
+              epc = ld_chunk<VEC>(a.eps_entity + ((size_t)sm * (size_t)a.T + (size_t)e) * d + (size_t)j * VEC);
+            } else if constexpr (EPS == EPS_ZERO) {
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) epc.v[t] = 0.f;
+            } else {
+              float nb;
+              eps_of_chunk<VEC>(ks, (uint32_t)e, j, epc.v, nb);
+              if (i == 0) nb_eps += nb;
+            }
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+              const float z = fmaf(link_f<LINK>(s[i].v[t]), epc.v[t], mu[i].v[t]);
+              const float gz = A[i].v[t] - z * gs;
+              g1s[i].v[t] += gz;
+              g2s[i].v[t] = fmaf(gz, epc.v[t], g2s[i].v[t]);
+            }
+          }
+        }
+        if constexpr (EPS == EPS_TABLE) nb_eps += a.eps_bias[(size_t)sm * (size_t)a.T + (size_t)e];
+      }
+      nb_eps *= a.inv_S;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) { g1s[i].v[t] *= a.inv_S; g2s[i].v[t] *= a.inv_S; }
+    }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int j = lig + i * LPE;
       if (j < C) {
         Chunk<VEC> gm, gv;
-        if (touched) {
+        if (touched && multi) {
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            const float sg = link_f<LINK>(s[i].v[t]);
+            gm.v[t] = gout * (g1s[i].v[t] + c * mu[i].v[t]);
+            gv.v[t] = gout * dlink_f<LINK>(s[i].v[t]) * (g2s[i].v[t] + c * (sg - inv_sigma(sg)));
+          }
+        } else if (touched) {
           Chunk<VEC> epc;
           if constexpr (EPS == EPS_TABLE) {
             epc = ep[i];
@@ -346,11 +343,11 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
           }
 #pragma unroll
           for (int t = 0; t < VEC; ++t) {
-            const float sg = fabsf(s[i].v[t]);
+            const float sg = link_f<LINK>(s[i].v[t]);
             const float z = fmaf(sg, epc.v[t], mu[i].v[t]);
             const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
             gm.v[t] = gout * (gz + c * mu[i].v[t]);
-            gv.v[t] = gout * signf(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
+            gv.v[t] = gout * dlink_f<LINK>(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
             if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(mu[i].v[t], sg), klacc);
           }
         } else {
@@ -378,10 +375,11 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     if (lig == 0) {
       float g0 = 0.f, g1 = 0.f;
       if (touched) {
-        if constexpr (EPS == EPS_TABLE) nb_eps = epw;
-        const float sg = fabsf(th.y);
+        if constexpr (EPS == EPS_TABLE)
+          if (!multi) nb_eps = epw;
+        const float sg = link_f<LINK>(th.y);
         g0 = gout * (gs + c * th.x);
-        g1 = gout * signf(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
+        g1 = gout * dlink_f<LINK>(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
         if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(th.x, sg), klacc);
       }
       if constexpr (ADAM) {

@@ -1,60 +1,6 @@
 // vfm_common.hpp -- kernel argument structs, chunk loads/stores, lane-group reductions, KL helpers.
-// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+// Included inside `namespace vfm { namespace {` of a translation unit (argument structs: vfm_args.hpp).
 #pragma once
-
-// ---------------------------------------------------------------------------------------
-// Kernel arguments (by value)
-// ---------------------------------------------------------------------------------------
-struct KArgs {
-  int64_t B, T;
-  int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
-  int32_t own_mod, own_rank;   // entity-sharded apply: this rank owns e = own_rank (mod own_mod)
-  int32_t F, d, lik, id64, G, flags;
-  float ll_scale;  // nb_train / B_global
-  double ll_scale_d;
-  RngKey key;
-  const void* x;
-  const float* y;
-  const float* entity;
-  const float* bias;
-  const float* inv_occ;
-  const float* scalars;
-  const double* W;
-  const float* eps_entity;
-  const float* eps_bias;
-  const float* eps_global;
-  int64_t group_hi[VFM_MAX_FIELDS];
-  double group_n[VFM_MAX_FIELDS];
-};
-
-struct FwdOut {
-  float* pred;
-  double* partials;
-  float* sumz;
-  float* grow;
-};
-
-struct BwdArgs {
-  const int32_t* occ_ptr;
-  const int32_t* occ_rows;
-  const float* sumz;
-  const float* grow;
-  double* partials;
-  const float* grad_out;
-  float* g_entity;
-  float* g_bias;
-  float* g_scalars;
-  float* loss;   // non-NULL: this launch also reduces the forward's partial slots and forms the loss
-  // staged (multi-rank) form: sufficient statistics of the gradient, exchanged instead of the gradient
-  float* acc;    // [T, 4 + round4(d)] record per entity: (sum_r grow_r, occurrences, 0, 0 | A_e[0..d-1]),
-                 //   A_e = sum_r grow_r * sumz_r      (STAGE_ACC writes, STAGE_APPLY reads)
-  float* sums;   // [2]    (sum_r grow_r over all rows, alpha term)
-  // entities whose occurrence list is longer than VFM_HEAVY_LIST: pre-reduced by k_heavy
-  const int32_t* heavy_ids;   // [n_heavy] sorted
-  const float* heavy_acc;     // [n_heavy, 4 + round4(d)] records (sum grow, count, 0, 0 | A_e)
-  int32_t n_heavy;
-  double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
-};
 
 template <int VEC>
 struct Chunk {
@@ -129,6 +75,33 @@ __device__ __forceinline__ float kl_std_normal(float mu, float sg) {
 __device__ __forceinline__ float inv_sigma(float sg) { return 1.0f / fmaxf(sg, SIGMA_MIN); }
 
 __device__ __forceinline__ float signf(float s) { return (s < 0.f) ? -1.f : 1.f; }
+
+// Link function of the scale parameters (the reference's global LINK, vfm-torch.py:125-126):
+//   LINK_ABS      sigma = |s|            dsigma/ds = sign(s)       (the assignment that wins, :126)
+//   LINK_SOFTPLUS sigma = log(1 + e^s)   dsigma/ds = sigmoid(s)    (:125; vfm.py:88)
+// softplus on the hardware exp2 / log2 units; log1p(t) = log(u) * t / (u - 1), u = 1 + t (exact
+// where 1 + t rounds to 1) keeps sigma accurate for very negative s.
+template <int LINK>
+__device__ __forceinline__ float link_f(float s) {
+  if constexpr (LINK == LINK_ABS) {
+    return fabsf(s);
+  } else {
+    const float t = __builtin_amdgcn_exp2f(-LOG2E * fabsf(s));
+    const float u = 1.0f + t;
+    const float l1p = (u == 1.0f) ? t : LN2 * __builtin_amdgcn_logf(u) * (t / (u - 1.0f));
+    return fmaxf(s, 0.f) + l1p;
+  }
+}
+template <int LINK>
+__device__ __forceinline__ float dlink_f(float s) {
+  if constexpr (LINK == LINK_ABS) {
+    return signf(s);
+  } else {
+    const float t = __builtin_amdgcn_exp2f(-LOG2E * fabsf(s));
+    const float inv = 1.0f / (1.0f + t);
+    return (s >= 0.f) ? inv : t * inv;
+  }
+}
 
 // all-reduce (sum) over aligned groups of W lanes, on the VALU: DPP row operations inside a
 // 16-lane row, v_permlane16/32_swap (gfx950) across rows -- no LDS round trips.

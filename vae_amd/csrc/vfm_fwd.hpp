@@ -1,5 +1,5 @@
 // vfm_fwd.hpp -- k_fwd: gather -> reparameterised sample -> FM -> ELBO.
-// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+// Included inside `namespace vfm { namespace {` of vfm_fwd.hip (one object per link function).
 #pragma once
 
 // ---------------------------------------------------------------------------------------
@@ -16,8 +16,13 @@
 // ---------------------------------------------------------------------------------------
 // EPS_ZPRE: the "table" holds precomputed samples, one record (w, 0, 0, 0 | z[0..d-1]) per slot
 // (entity-sharded multi-rank mode: the owner of an entity samples it once and ships z, not mu / s)
-enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3 };
-enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
+//
+// Variational samples S > 1 (the reference's global N_VARIATIONAL_SAMPLES, vfm-torch.py:19,238-245,265):
+// one launch per sample s.  Launch s draws its own eps (RngKey::step_hi carries s), stores sumz[s] and
+// adds its row value  b_r^s + q_r^s  to a running sum kept in pred[0..B); the LAST launch turns the mean
+// over samples into the S predictions  pred[s,r] = w0^s + mean_s'(b_r^s' + q_r^s')  (the reference
+// averages the entity terms over samples BEFORE the likelihood but not w0, :244-245,265), the
+// likelihood terms, grow[r] = sum_s dloss/dpred[s,r] and the KL term.
 
 template <int CPL, int VEC, int EPS>
 struct FieldRegs {            // everything one (row, field) occurrence needs, in registers
@@ -106,7 +111,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // z = mu + |s| eps for one chunk, FM partial sums and the KL polynomial / log parts.
 // VEC == 4 uses packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two coordinates per
 // instruction).  `valid` masks the lanes past the last chunk (they hold a re-loaded copy).
-template <int VEC, int MODE>
+template <int VEC, int MODE, int LINK>
 __device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC>& s, const float (&ep)[VEC],
                                            bool valid, Chunk<VEC>& sz, float& zz, float& klv) {
   if constexpr (VEC == 4) {
@@ -115,7 +120,7 @@ __device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const v2f m2 = {mu.v[2 * h], mu.v[2 * h + 1]};
-      const v2f g2 = {fabsf(s.v[2 * h]), fabsf(s.v[2 * h + 1])};
+      const v2f g2 = {link_f<LINK>(s.v[2 * h]), link_f<LINK>(s.v[2 * h + 1])};
       const v2f e2 = {ep[2 * h], ep[2 * h + 1]};
       const v2f z2 = g2 * e2 + m2;
       v2f a2 = {sz.v[2 * h], sz.v[2 * h + 1]};
@@ -132,7 +137,7 @@ __device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC
     zz += valid ? zq.x + zq.y : 0.f;
     if constexpr (MODE == MODE_TRAIN) klv += valid ? fmaf(0.5f, kq.x + kq.y, fmaf(-LN2, lg, -2.0f)) : 0.f;
   } else {
-    const float sg = fabsf(s.v[0]);
+    const float sg = link_f<LINK>(s.v[0]);
     const float z = valid ? fmaf(sg, ep[0], mu.v[0]) : 0.f;
     sz.v[0] += z;
     zz = fmaf(z, z, zz);
@@ -141,16 +146,16 @@ __device__ __forceinline__ void chunk_math(const Chunk<VEC>& mu, const Chunk<VEC
 }
 
 // first-order weight of one occurrence (the lane that owns it): sample + KL
-template <int MODE>
+template <int MODE, int LINK>
 __device__ __forceinline__ void bias_math(const float2 th, float epw, bool owner, float& part, float& klv) {
-  const float sgw = fabsf(th.y);
+  const float sgw = link_f<LINK>(th.y);
   part += owner ? fmaf(sgw, epw, th.x) : 0.f;
   if constexpr (MODE == MODE_TRAIN) klv += owner ? kl_std_normal(th.x, sgw) : 0.f;
 }
 
 // arithmetic of one occurrence (generic path): every lane draws its own chunk's eps
-template <int LPE, int CPL, int VEC, int EPS, int MODE>
-__device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CPL, VEC, EPS>& R, int lig,
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int LINK>
+__device__ __forceinline__ void consume_field(const RngKey& key, const FieldRegs<CPL, VEC, EPS>& R, int lig,
                                               int C, float cs, RowAcc<CPL, VEC>& acc) {
   float klv = 0.f;
   float epw = 0.f;
@@ -168,13 +173,13 @@ __device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CP
       for (int t = 0; t < VEC; ++t) ep[t] = 0.f;
     } else {
       float nb;
-      eps_of_chunk<VEC>(a.key, R.e, j, ep, nb);
+      eps_of_chunk<VEC>(key, R.e, j, ep, nb);
       if (i == 0) epw = nb;   // only the lane that owns coordinate 0 (lig == 0) uses it
     }
-    chunk_math<VEC, MODE>(R.mu[i], R.s[i], ep, valid, acc.sz[i], acc.zz, klv);
+    chunk_math<VEC, MODE, LINK>(R.mu[i], R.s[i], ep, valid, acc.sz[i], acc.zz, klv);
   }
   if constexpr (EPS == EPS_TABLE) epw = R.epw;
-  bias_math<MODE>(R.th, epw, lig == 0, acc.part, klv);
+  bias_math<MODE, LINK>(R.th, epw, lig == 0, acc.part, klv);
   if constexpr (MODE == MODE_TRAIN) acc.kl = fmaf(cs * R.io, klv, acc.kl);
 }
 
@@ -183,8 +188,8 @@ __device__ __forceinline__ void consume_field(const KArgs& a, const FieldRegs<CP
 // the odd lane those of field 1's entity, and they exchange one half over DPP (quad_perm
 // [1,0,3,2]).  Lane 0 / lane 1 own the first-order weights of field 0 / field 1 (their calls have
 // p == 0 and carry the bias normal).
-template <int LPE, int CPL, int EPS, int MODE>
-__device__ __forceinline__ void consume_row2(const KArgs& a, const FieldRegs<CPL, 4, EPS>& R0,
+template <int LPE, int CPL, int EPS, int MODE, int LINK>
+__device__ __forceinline__ void consume_row2(const RngKey& key, const FieldRegs<CPL, 4, EPS>& R0,
                                              const FieldRegs<CPL, 4, EPS>& R1, int lig, int C, float cs0,
                                              float cs1, RowAcc<CPL, 4>& acc) {
   static_assert(LPE >= 2, "lane pairing needs at least two lanes per row");
@@ -205,7 +210,7 @@ __device__ __forceinline__ void consume_row2(const KArgs& a, const FieldRegs<CPL
     } else {
       float n[8], nb;
       // pair index of chunk j is j >> 1 (LPE is even, so both lanes of a pair agree on it)
-      normal8b(a.key, odd ? R1.e : R0.e, (uint32_t)j >> 1, n, nb);
+      normal8b(key, odd ? R1.e : R0.e, (uint32_t)j >> 1, n, nb);
       if (i == 0) epw = nb;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -215,23 +220,47 @@ __device__ __forceinline__ void consume_row2(const KArgs& a, const FieldRegs<CPL
         ep1[t] = odd ? n[4 + t] : recv;               // field 1, my chunk
       }
     }
-    chunk_math<4, MODE>(R0.mu[i], R0.s[i], ep0, valid, acc.sz[i], acc.zz, kl0);
-    chunk_math<4, MODE>(R1.mu[i], R1.s[i], ep1, valid, acc.sz[i], acc.zz, kl1);
+    chunk_math<4, MODE, LINK>(R0.mu[i], R0.s[i], ep0, valid, acc.sz[i], acc.zz, kl0);
+    chunk_math<4, MODE, LINK>(R1.mu[i], R1.s[i], ep1, valid, acc.sz[i], acc.zz, kl1);
   }
   if constexpr (EPS == EPS_TABLE) epw = odd ? R1.epw : R0.epw;
   float klb = 0.f;
-  bias_math<MODE>(odd ? R1.th : R0.th, epw, lig < 2, acc.part, klb);
+  bias_math<MODE, LINK>(odd ? R1.th : R0.th, epw, lig < 2, acc.part, klb);
   if constexpr (MODE == MODE_TRAIN) {
     const float c0 = cs0 * R0.io, c1 = cs1 * R1.io;
     acc.kl = fmaf(c0, kl0, fmaf(c1, kl1, fmaf(odd ? c1 : c0, klb, acc.kl)));
   }
 }
 
+// log-likelihood of one (row, sample) and its derivative wrt the prediction
+__device__ __forceinline__ void lik_terms(int lik, float y, float pred, float aabs, float half_log_a, float& ll,
+                                          float& dll, float& aterm) {
+  if (lik == VFM_LIK_NORMAL) {
+    const float diff = y - pred;
+    ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
+    dll = aabs * diff;
+    aterm = 0.5f * diff * diff - 0.5f / aabs;
+  } else {
+    // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
+    const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
+    ll = y * pred - (fmaxf(pred, 0.f) + LN2 * __builtin_amdgcn_logf(1.0f + e1));
+    const float inv = __builtin_amdgcn_rcpf(1.0f + e1);
+    dll = y - ((pred >= 0.f) ? inv : e1 * inv);
+    aterm = 0.f;
+  }
+}
+
+// per-block constants of the row loop
+struct RowConsts {
+  float w0, aabs, half_log_a;
+  const float* sh_w0;   // S > 1: w0 of every sample
+  const float* sh_e0;   //        and the global-bias eps behind it
+};
+
 // finish a row: FM reduction over the group, likelihood, outputs
 template <int LPE, int CPL, int VEC, int MODE>
 __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, int64_t r, int lig, int C,
-                                           float w0, float aabs, float half_log_a, float y,
-                                           RowAcc<CPL, VEC>& acc, float (&tot)[5]) {
+                                           const RowConsts& rc, float y, RowAcc<CPL, VEC>& acc, float (&tot)[6]) {
   float q = -acc.zz;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -240,45 +269,64 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
     for (int t = 0; t < VEC; ++t) qi = fmaf(acc.sz[i].v[t], acc.sz[i].v[t], qi);
     q += (lig + i * LPE < C) ? qi : 0.f;
   }
-  const float pred = w0 + group_sum<LPE>(fmaf(0.5f, q, acc.part));
+  const float val = group_sum<LPE>(fmaf(0.5f, q, acc.part));
   if constexpr (MODE == MODE_TRAIN) {
     tot[1] += acc.kl;
+    float* srow = out.sumz + ((size_t)a.sample * (size_t)a.B + (size_t)r) * a.d;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int j = lig + i * LPE;
-      if (j < C) st_chunk<VEC>(out.sumz + (size_t)r * a.d + (size_t)j * VEC, acc.sz[i]);
+      if (j < C) st_chunk<VEC>(srow + (size_t)j * VEC, acc.sz[i]);
     }
   }
+  if (a.S > 1) {                      // uniform: one launch per sample, see the header comment
+    if (lig == 0) {
+      float m = val;
+      if (a.sample > 0) m += out.pred[r];
+      if (a.sample + 1 < a.S) {
+        out.pred[r] = m;
+      } else {
+        m *= a.inv_S;
+        float gsum = 0.f;
+        for (int s = 0; s < a.S; ++s) {
+          const float pred = rc.sh_w0[s] + m;
+          out.pred[(size_t)s * (size_t)a.B + (size_t)r] = pred;
+          if constexpr (MODE == MODE_TRAIN) {
+            float ll, dll, at;
+            lik_terms(a.lik, y, pred, rc.aabs, rc.half_log_a, ll, dll, at);
+            const float g = -a.ll_scale * dll;
+            tot[0] += ll; tot[2] += g; tot[3] += at;
+            tot[5] = fmaf(rc.sh_e0[s], g, tot[5]);
+            gsum += g;
+          }
+        }
+        if constexpr (MODE == MODE_TRAIN) out.grow[r] = gsum;
+      }
+    }
+    return;
+  }
+  const float pred = rc.w0 + val;
   if (lig == 0) {
     out.pred[r] = pred;
     if constexpr (MODE == MODE_TRAIN) {
-      float ll, dll;
-      if (a.lik == VFM_LIK_NORMAL) {
-        const float diff = y - pred;
-        ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
-        dll = aabs * diff;
-        tot[3] += 0.5f * diff * diff - 0.5f / aabs;
-      } else {
-        // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
-        const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
-        ll = y * pred - (fmaxf(pred, 0.f) + LN2 * __builtin_amdgcn_logf(1.0f + e1));
-        const float inv = __builtin_amdgcn_rcpf(1.0f + e1);
-        dll = y - ((pred >= 0.f) ? inv : e1 * inv);
-      }
+      float ll, dll, at;
+      lik_terms(a.lik, y, pred, rc.aabs, rc.half_log_a, ll, dll, at);
       const float g = -a.ll_scale * dll;
       tot[0] += ll;
       tot[2] += g;
+      tot[3] += at;
       out.grow[r] = g;
     }
   }
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF, bool ID64>
+template <int LPE, int CPL, int VEC, int EPS, int MODE, int FF, bool ID64, int LINK>
 __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
-  __shared__ float sh_red[5 * 4];
+  __shared__ float sh_red[6 * 4];
+  __shared__ float sh_w0[MAX_SAMPLES], sh_e0[MAX_SAMPLES];
 
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
@@ -286,11 +334,13 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   const int C = (a.d + VEC - 1) / VEC;
 
   if (MODE == MODE_TRAIN && tid < a.G) {
-    sh_cs[tid] = (EPS == EPS_ZPRE) ? 0.f : (float)(a.group_n[tid] / a.W[tid]);
+    // (S > 1: the KL term is formed by the last sample's launch only)
+    sh_cs[tid] = (EPS == EPS_ZPRE || a.sample + 1 < a.S) ? 0.f : (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
-  const float aabs = fabsf(alpha);
+  const float aabs = link_f<LINK>(alpha);
+  const RngKey key = key_of_sample(a.key, a.sample);   // this launch's sample (a.key: sample 0)
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
   if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZPRE) {     // (ZPRE: the scalars are replicated, w0 is local)
@@ -298,15 +348,27 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
       e0 = a.eps_global[0];
     } else {
       float n[8], nb;
-      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
       e0 = n[0];
     }
   }
-  const float w0 = fmaf(fabsf(s0), e0, m0);
+  const float w0 = fmaf(link_f<LINK>(s0), e0, m0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
-  if (MODE == MODE_TRAIN) __syncthreads();
+  if (a.S > 1 && a.sample + 1 == a.S && tid < a.S) {   // uniform in a.S: w0 of every sample for the final pass
+    float es = 0.f;
+    if constexpr (EPS == EPS_TABLE) es = a.eps_global[tid];
+    if constexpr (EPS == EPS_PHILOX) {
+      float n[8], nb;
+      normal8b(key_of_sample(a.key, tid), 0xFFFFFFFFu, 0u, n, nb);
+      es = n[0];
+    }
+    sh_e0[tid] = es;
+    sh_w0[tid] = fmaf(link_f<LINK>(s0), es, m0);
+  }
+  if (MODE == MODE_TRAIN || a.S > 1) __syncthreads();
+  const RowConsts rc{w0, aabs, half_log_a, sh_w0, sh_e0};
 
-  float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids
+  float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids, sum_s eps0^s * g (S > 1)
   // Each workgroup owns a CONTIGUOUS chunk of rows (its GPB lane groups interleave inside it): with
   // the rows of a batch ordered by item id, the rows that share an item row are then gathered by the
   // same CU at about the same time and hit L1 / the XCD's L2 instead of HBM.
@@ -353,9 +415,9 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
         }
         // stage 2: arithmetic of row r from A while B's loads are in flight
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE>(a, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
-        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yA, acc, tot);
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yA, acc, tot);
         r = rn;
         if (r >= rend) break;
         // the same with the roles of A and B swapped (static register naming, no copies)
@@ -374,9 +436,9 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           if constexpr (MODE == MODE_TRAIN) yA = a.y[rc];
         }
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE>(a, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
-        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, yB, acc, tot);
+        finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yB, acc, tot);
         r = rn;
         if (r >= rend) break;
       }
@@ -424,11 +486,11 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, Bq);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE>(a, A, lig, C, cs_of(A.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, A, lig, C, cs_of(A.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];
-          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, y, acc, tot);
           acc.reset();
         }
         r = rn; f = fn;
@@ -444,11 +506,11 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, A);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE>(a, Bq, lig, C, cs_of(Bq.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, Bq, lig, C, cs_of(Bq.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];
-          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, w0, aabs, half_log_a, y, acc, tot);
+          finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, y, acc, tot);
           acc.reset();
         }
         r = rn; f = fn;
@@ -460,11 +522,11 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   // per-block partial sums go to the block's own slot (plain stores: no same-address atomics --
   // 5 fp64 atomics from each of ~10^3 blocks finishing together serialised for tens of
   // microseconds -- and the sums become bitwise reproducible); k_finalize adds the slots up.
-  block_sum<5>(tot, sh_red);
+  block_sum<6>(tot, sh_red);
   if (tid == 0) {
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) slot[i] = (double)tot[i];
+    for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
     if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
   }
 }

@@ -1,5 +1,5 @@
 // vfm_rng.hpp -- counter-based eps stream (Philox4x32-10 + Box-Muller).
-// Part of vfm_kernels.hip (one translation unit; included inside its anonymous namespace).
+// Included inside `namespace vfm { namespace {` of a translation unit (see vfm_args.hpp).
 #pragma once
 
 // ---------------------------------------------------------------------------------------
@@ -8,9 +8,12 @@
 // step `step` depends on (seed, step, e, coordinate) only: every row -- and every rank -- that
 // touches e regenerates the same eps, no eps tensor is ever stored.
 // ---------------------------------------------------------------------------------------
-struct RngKey {
-  uint32_t seed_lo, seed_hi, step_lo, step_hi;
-};
+// (struct RngKey: vfm_args.hpp.)  Variational sample s > 0 of a step uses counter word 3 =
+// step_hi | (s << 16) (steps stay below 2^48 when S > 1; checked on the host): one scalar OR per launch.
+__device__ __forceinline__ RngKey key_of_sample(RngKey k, int s) {
+  k.step_hi |= (uint32_t)s << 16;
+  return k;
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {

@@ -32,13 +32,15 @@ float* fptr_mut(const optional<Tensor>& t, const char* name) { return const_cast
 
 vfm_problem_t problem(const Tensor& x_like, int64_t B, int64_t B_global, int64_t T, int64_t F, int64_t d,
                       int64_t nb_train, int64_t likelihood, int64_t id_bits, int64_t flags,
-                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step) {
+                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step,
+                      int64_t n_samples = 1) {
   TORCH_CHECK(F >= 1 && F <= VFM_MAX_FIELDS, "F out of range");
+  TORCH_CHECK(n_samples >= 1 && n_samples <= 64, "n_samples out of range [1,64]");
   TORCH_CHECK((int64_t)group_hi.size() == F && (int64_t)group_n.size() == F, "group_hi / group_n need F entries");
   vfm_problem_t p{};
   p.B = B; p.B_global = B_global; p.T = T; p.nb_train = nb_train;
   p.F = (int32_t)F; p.d = (int32_t)d; p.likelihood = (int32_t)likelihood; p.id_bits = (int32_t)id_bits;
-  p.n_samples = 1; p.flags = (int32_t)flags;
+  p.n_samples = (int32_t)n_samples; p.flags = (int32_t)flags;
   for (int64_t g = 0; g < F; ++g) { p.group_hi[g] = group_hi[g]; p.group_n[g] = group_n[g]; }
   p.seed = (uint64_t)seed; p.step = (uint64_t)step;
   return p;
@@ -61,19 +63,24 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
               const optional<Tensor>& eps_global, Tensor pred, Tensor partials,
               const optional<Tensor>& sumz, const optional<Tensor>& grow, at::IntArrayRef group_hi,
               at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
-              int64_t flags, int64_t seed, int64_t step) {
+              int64_t flags, int64_t seed, int64_t step, int64_t n_samples) {
   const Ids id = ids_of(x);
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   dev_tensor(scalars, at::kFloat, "scalars"); dev_tensor(pred, at::kFloat, "pred");
   dev_tensor(partials, at::kDouble, "partials");
   TORCH_CHECK(entity.dim() == 2 && bias.dim() == 2 && bias.size(1) == 2 && bias.size(0) == entity.size(0) &&
               entity.size(1) % 2 == 0, "table shapes");
-  TORCH_CHECK(pred.numel() >= id.B && partials.numel() >= VFM_PARTIALS_LEN && scalars.numel() >= 3, "output sizes");
+  TORCH_CHECK(n_samples >= 1 && pred.numel() >= n_samples * id.B && partials.numel() >= VFM_PARTIALS_LEN &&
+              scalars.numel() >= 3, "output sizes");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
-  if (sumz.has_value() && sumz->defined()) TORCH_CHECK(sumz->numel() >= id.B * d, "sumz too small");
+  if (sumz.has_value() && sumz->defined()) TORCH_CHECK(sumz->numel() >= n_samples * id.B * d, "sumz too small");
+  if (eps_entity.has_value() && eps_entity->defined())
+    TORCH_CHECK(eps_entity->numel() >= n_samples * T * d && eps_bias.has_value() && eps_bias->defined() &&
+                eps_bias->numel() >= n_samples * T && eps_global.has_value() && eps_global->defined() &&
+                eps_global->numel() >= n_samples, "eps tables too small for n_samples");
   c10::hip::HIPGuard guard(x.get_device());
   vfm_problem_t p = problem(x, id.B, B_global, T, id.F, d, nb_train, likelihood, id.id_bits, flags, group_hi,
-                            group_n, seed, step);
+                            group_n, seed, step, n_samples);
   const double* Wp = (W.has_value() && W->defined()) ? dev_tensor(*W, at::kDouble, "W").data_ptr<double>() : nullptr;
   check(vfm_elbo_fwd_f32(&p, id.ptr, fptr(y, "y"), entity.data_ptr<float>(), bias.data_ptr<float>(),
                          fptr(inv_occ, "inv_occ"), scalars.data_ptr<float>(), Wp, fptr(eps_entity, "eps_entity"),
@@ -84,14 +91,15 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
 }
 
 void elbo_finalize(Tensor partials, const Tensor& scalars, Tensor loss, int64_t nb_train, int64_t B_global,
-                   int64_t flags) {
+                   int64_t flags, int64_t n_samples) {
   dev_tensor(partials, at::kDouble, "partials"); dev_tensor(scalars, at::kFloat, "scalars");
   dev_tensor(loss, at::kFloat, "loss");
   TORCH_CHECK(loss.numel() >= 3, "loss needs 3 entries");
   c10::hip::HIPGuard guard(partials.get_device());
   vfm_problem_t p{};
   p.B = 0; p.B_global = B_global; p.T = 1; p.nb_train = nb_train; p.F = 1; p.d = 4; p.id_bits = 64;
-  p.n_samples = 1; p.flags = (int32_t)flags; p.group_hi[0] = 1; p.group_n[0] = 1;
+  TORCH_CHECK(n_samples >= 1 && n_samples <= 64, "n_samples out of range [1,64]");
+  p.n_samples = (int32_t)n_samples; p.flags = (int32_t)flags; p.group_hi[0] = 1; p.group_n[0] = 1;
   check(vfm_elbo_finalize_f32(&p, partials.data_ptr<double>(), scalars.data_ptr<float>(), loss.data_ptr<float>(),
                               stream_of(partials)),
         "vfm_elbo_finalize_f32");
@@ -100,7 +108,7 @@ void elbo_finalize(Tensor partials, const Tensor& scalars, Tensor loss, int64_t 
 int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
 
 // index = [occ_ptr, occ_rows] or [occ_ptr, occ_rows, heavy_ids, heavy_items, heavy_acc]
-vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int64_t d) {
+vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int64_t d, int64_t n_samples = 1) {
   TORCH_CHECK(index.size() == 2 || index.size() == 5, "index = [occ_ptr, occ_rows] (+ [heavy_ids, heavy_items, heavy_acc])");
   dev_tensor(index[0], at::kInt, "occ_ptr"); dev_tensor(index[1], at::kInt, "occ_rows");
   TORCH_CHECK(index[0].numel() == T + 1 && index[1].numel() == B * F, "inverted index sizes");
@@ -109,7 +117,8 @@ vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int6
   if (index.size() == 5 && index[2].numel() > 0) {
     dev_tensor(index[2], at::kInt, "heavy_ids"); dev_tensor(index[3], at::kInt, "heavy_items");
     dev_tensor(index[4], at::kFloat, "heavy_acc");
-    TORCH_CHECK(index[3].numel() % 4 == 0 && index[4].numel() >= index[2].numel() * rec_len(d), "heavy index sizes");
+    TORCH_CHECK(index[3].numel() % 4 == 0 && index[4].numel() >= n_samples * index[2].numel() * rec_len(d),
+                "heavy index sizes");
     ix.heavy_ids = index[2].data_ptr<int32_t>(); ix.heavy_items = index[3].data_ptr<int32_t>();
     ix.heavy_acc = index[4].data_ptr<float>();
     ix.n_heavy = (int32_t)index[2].numel(); ix.n_items = (int32_t)(index[3].numel() / 4);
@@ -123,11 +132,19 @@ struct BwdCommon {
 
 BwdCommon bwd_common(at::TensorList index, const Tensor& entity, const Tensor& bias,
                      int64_t B, int64_t F, int64_t B_global, int64_t nb_train, int64_t likelihood, int64_t flags,
-                     at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step) {
+                     at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step,
+                     int64_t n_samples, const Tensor& sumz, const optional<Tensor>& eps_entity,
+                     const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global) {
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
-  return {problem(entity, B, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step),
-          index_of(index, T, B, F, d)};
+  TORCH_CHECK(n_samples >= 1 && sumz.numel() >= n_samples * B * d, "sumz too small for n_samples");
+  if (eps_entity.has_value() && eps_entity->defined())
+    TORCH_CHECK(eps_entity->numel() >= n_samples * T * d && eps_bias.has_value() && eps_bias->defined() &&
+                eps_bias->numel() >= n_samples * T && eps_global.has_value() && eps_global->defined() &&
+                eps_global->numel() >= n_samples, "eps tables too small for n_samples");
+  return {problem(entity, B, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step,
+                  n_samples),
+          index_of(index, T, B, F, d, n_samples)};
 }
 
 void elbo_bwd(at::TensorList index, const Tensor& entity, const Tensor& bias,
@@ -135,10 +152,11 @@ void elbo_bwd(at::TensorList index, const Tensor& entity, const Tensor& bias,
               const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global, const Tensor& sumz,
               const Tensor& grow, const Tensor& partials, const Tensor& grad_out, Tensor g_entity, Tensor g_bias,
               Tensor g_scalars, int64_t F, at::IntArrayRef group_hi, at::ArrayRef<double> group_n,
-              int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed, int64_t step) {
+              int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed, int64_t step,
+              int64_t n_samples) {
   const int64_t B = grow.numel();
   BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
-                           group_n, seed, step);
+                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global);
   TORCH_CHECK(g_entity.sizes() == entity.sizes() && g_bias.sizes() == bias.sizes() && g_scalars.numel() >= 3,
               "gradient shapes");
   c10::hip::HIPGuard guard(entity.get_device());
@@ -164,10 +182,10 @@ void elbo_bwd_adam(at::TensorList index, Tensor entity, Tensor bias, Tensor scal
                    Tensor v_bias, Tensor m_scalars, Tensor v_scalars, int64_t F, at::IntArrayRef group_hi,
                    at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
                    int64_t flags, int64_t seed, int64_t step, double lr, double beta1, double beta2,
-                   double eps_adam, int64_t adam_step, const optional<Tensor>& loss) {
+                   double eps_adam, int64_t adam_step, const optional<Tensor>& loss, int64_t n_samples) {
   const int64_t B = grow.numel();
   BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
-                           group_n, seed, step);
+                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global);
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel() && m_scalars.numel() >= 3 &&
               v_scalars.numel() >= 3, "Adam moment shapes");
@@ -283,7 +301,7 @@ void elbo_fwd_zpre(const Tensor& x, const Tensor& y, const Tensor& zbuf, const T
 }
 
 void shard_sample(const Tensor& ids, const Tensor& entity, const Tensor& bias, const optional<Tensor>& eps_entity,
-                  const optional<Tensor>& eps_bias, Tensor out, int64_t seed, int64_t step) {
+                  const optional<Tensor>& eps_bias, Tensor out, int64_t seed, int64_t step, int64_t flags) {
   dev_tensor(ids, at::kInt, "ids"); dev_tensor(entity, at::kFloat, "entity_params");
   dev_tensor(bias, at::kFloat, "bias_params"); dev_tensor(out, at::kFloat, "out");
   const int64_t T = entity.size(0), d = entity.size(1) / 2, n = ids.numel();
@@ -291,7 +309,7 @@ void shard_sample(const Tensor& ids, const Tensor& entity, const Tensor& bias, c
   c10::hip::HIPGuard guard(entity.get_device());
   std::vector<int64_t> hi(1, T);
   std::vector<double> gn(1, 1.0);
-  vfm_problem_t p = problem(entity, 0, 0, T, 1, d, 1, 0, 64, 0, hi, gn, seed, step);
+  vfm_problem_t p = problem(entity, 0, 0, T, 1, d, 1, 0, 64, flags, hi, gn, seed, step);
   check(vfm_shard_sample_f32(&p, ids.data_ptr<int32_t>(), n, entity.data_ptr<float>(), bias.data_ptr<float>(),
                              fptr(eps_entity, "eps_entity"), fptr(eps_bias, "eps_bias"), out.data_ptr<float>(),
                              stream_of(entity)),
@@ -342,20 +360,22 @@ TORCH_LIBRARY(vfm_hip, m) {
   m.def("elbo_fwd(Tensor x, Tensor? y, Tensor entity_params, Tensor bias_params, Tensor? inv_occ, Tensor scalars, "
         "Tensor? W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor(a!) pred, Tensor(b!) partials, "
         "Tensor(c!)? sumz, Tensor(d!)? grow, int[] group_hi, float[] group_n, int nb_train, int B_global, "
-        "int likelihood, int flags, int seed, int step) -> ()", &elbo_fwd);
-  m.def("elbo_finalize(Tensor(a!) partials, Tensor scalars, Tensor(b!) loss, int nb_train, int B_global, int flags) -> ()",
+        "int likelihood, int flags, int seed, int step, int n_samples=1) -> ()", &elbo_fwd);
+  m.def("elbo_finalize(Tensor(a!) partials, Tensor scalars, Tensor(b!) loss, int nb_train, int B_global, int flags, "
+        "int n_samples=1) -> ()",
         &elbo_finalize);
   m.def("elbo_bwd(Tensor[] index, Tensor entity_params, Tensor bias_params, Tensor inv_occ, "
         "Tensor scalars, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor sumz, Tensor grow, "
         "Tensor partials, Tensor grad_out, Tensor(a!) g_entity, Tensor(b!) g_bias, Tensor(c!) g_scalars, int F, "
-        "int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, int flags, int seed, int step) -> ()",
+        "int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, int flags, int seed, int step, "
+        "int n_samples=1) -> ()",
         &elbo_bwd);
   m.def("elbo_bwd_adam(Tensor[] index, Tensor(a!) entity_params, Tensor(b!) bias_params, "
         "Tensor(c!) scalars, Tensor inv_occ, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, "
         "Tensor sumz, Tensor grow, Tensor partials, Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, "
         "Tensor(g!) v_bias, Tensor(h!) m_scalars, Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, "
         "int nb_train, int B_global, int likelihood, int flags, int seed, int step, float lr, float beta1, "
-        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss) -> ()", &elbo_bwd_adam);
+        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss, int n_samples=1) -> ()", &elbo_bwd_adam);
   m.def("elbo_bwd_acc(Tensor[] index, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
         "Tensor(c!) sums, int T, int F, int d, int e_lo, int e_hi) -> ()", &elbo_bwd_acc);
   m.def("elbo_apply_adam(Tensor acc, Tensor sums, Tensor(a!) entity_params, Tensor(b!) bias_params, "
@@ -369,7 +389,7 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor(b!) partials, Tensor(c!) sumz, Tensor(d!) grow, int d, int nb_train, int B_global, int likelihood, "
         "int flags, int seed, int step) -> ()", &elbo_fwd_zpre);
   m.def("shard_sample(Tensor ids, Tensor entity_params, Tensor bias_params, Tensor? eps_entity, Tensor? eps_bias, "
-        "Tensor(a!) out, int seed, int step) -> ()", &shard_sample);
+        "Tensor(a!) out, int seed, int step, int flags=0) -> ()", &shard_sample);
   m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d, bool atomic) -> ()", &records_add);
   m.def("shard_pack(Tensor(a!) small, Tensor loss_local, Tensor kl_ws) -> ()", &shard_pack);
   m.def("shard_loss(Tensor small, Tensor(a!) loss3) -> ()", &shard_loss);

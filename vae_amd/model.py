@@ -26,12 +26,13 @@ from .dist import shard_rows, allreduce_flat, prior_terms_flag
 
 class LikelihoodResult:
     """Stand-in for the torch.distributions object `CF.forward` returns (vfm-torch.py:267-270):
-    `.mean` and `.log_prob(y)` with batch shape [1, B] (S = 1 sample)."""
+    `.mean` and `.log_prob(y)` with batch shape [S, B] (S variational samples)."""
 
-    def __init__(self, pred: torch.Tensor, output: str, alpha: torch.Tensor):
-        self.logits = pred.reshape(1, -1)
+    def __init__(self, pred: torch.Tensor, output: str, alpha: torch.Tensor, link: str = "abs"):
+        self.logits = pred.reshape(1, -1) if pred.dim() == 1 else pred
         self.output = output
         self._alpha = alpha
+        self._link = link
 
     @property
     def mean(self):
@@ -40,7 +41,7 @@ class LikelihoodResult:
     def log_prob(self, y):
         y = y.to(self.logits.dtype).reshape(1, -1)
         if self.output == "reg":
-            a = self._alpha.abs()
+            a = self._alpha.abs() if self._link == "abs" else torch.nn.functional.softplus(self._alpha)
             return -0.5 * a * (y - self.logits) ** 2 + 0.5 * torch.log(a) - 0.5 * math.log(2 * math.pi)
         return y * self.logits - torch.nn.functional.softplus(self.logits)
 
@@ -61,8 +62,14 @@ class VFM(nn.Module):
 
     def __init__(self, N: Optional[int] = None, M: Optional[int] = None, embedding_size: int = 20,
                  output: str = "reg", field_sizes: Optional[Sequence[int]] = None,
-                 quirk_le_N: bool = True, device="cuda", rng_seed: int = 0, sparse_adam: bool = False):
+                 quirk_le_N: bool = True, device="cuda", rng_seed: int = 0, sparse_adam: bool = False,
+                 n_samples: int = 1, link: str = "abs"):
+        """n_samples = the reference's global N_VARIATIONAL_SAMPLES (vfm-torch.py:19); link = its global
+        LINK (:125-126): "abs" is the assignment in effect there, "softplus" the one it overwrites."""
         super().__init__()
+        self.n_samples, self.link = int(n_samples), str(link)
+        ops.Spec(T=1, F=1, d=1, group_hi=(1,), group_n=(1.0,), likelihood=0, n_samples=self.n_samples,
+                 link=self.link)     # validates both
         if field_sizes is None:
             if N is None or M is None:
                 raise ValueError("give N and M, or field_sizes")
@@ -215,7 +222,7 @@ class VFM(nn.Module):
     def spec(self) -> ops.Spec:
         lik = _lib.LIK_NORMAL if self.output == "reg" else _lib.LIK_BERNOULLI
         return ops.Spec(T=self.T, F=self.F, d=self.d, group_hi=self.group_hi, group_n=self.group_n,
-                        likelihood=lik, nb_train=int(self.nb_train))
+                        likelihood=lik, nb_train=int(self.nb_train), n_samples=self.n_samples, link=self.link)
 
     # ------------------------------------------------------------------ data-dependent state
     def set_training_data(self, X_train: torch.Tensor, nb_train: Optional[int] = None,
@@ -239,6 +246,8 @@ class VFM(nn.Module):
             y = torch.as_tensor(y).to(self.device)
             if self.inv_occ is None:
                 raise RuntimeError("call set_training_data() before building training plans")
+        if process_group is not None and self.n_samples > 1 and y is not None:
+            self.exchange = "grads"      # the statistics / sharded exchanges carry one sample
         if process_group is not None and self.exchange == "auto" and y is not None:
             table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
             self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
@@ -278,9 +287,9 @@ class VFM(nn.Module):
         ent, bia, scal = self._views(self._flat)
         step = self.global_step
         self.global_step += 1
-        st = ops.elbo_forward(plan, ent, bia, scal, None, eps=eps, seed=self.rng_seed, step=step,
-                              train=False, flags=0 if sample else ops.FLAG_EPS_ZERO)
-        lik = LikelihoodResult(st.pred, self.output, self.alpha.detach())
+        st = ops.elbo_forward(plan if sample else _single_sample(plan), ent, bia, scal, None, eps=eps,
+                              seed=self.rng_seed, step=step, train=False, flags=0 if sample else ops.FLAG_EPS_ZERO)
+        lik = LikelihoodResult(st.pred, self.output, self.alpha.detach(), self.link)
         last = mean = None
         if self._n_saved > 0:
             last = self._mean_logits(plan, self._last_flat)
@@ -289,7 +298,7 @@ class VFM(nn.Module):
 
     def _mean_logits(self, plan, flat):
         ent, bia, scal = self._views(flat)
-        st = ops.elbo_forward(plan, ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
+        st = ops.elbo_forward(_single_sample(plan), ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
         return st.pred
 
     def sync_params(self, process_group):
@@ -351,13 +360,14 @@ class VFM(nn.Module):
             self._shard_klws = torch.zeros(4097, dtype=torch.float64, device=self.device)
 
     def _step_buffers(self, B):
-        """Persistent per-step training state (sumz [B,d], grow [B], pred [B]) -- no allocator
+        """Persistent per-step training state (sumz [S*B,d], grow [B], pred [B] or [S,B]) -- no allocator
         traffic inside the step."""
         b = self._state_bufs.get(B)
         if b is None:
-            b = (torch.empty(B, self.d, dtype=torch.float32, device=self.device),
+            S = self.n_samples
+            b = (torch.empty(S * B, self.d, dtype=torch.float32, device=self.device),
                  torch.empty(B, dtype=torch.float32, device=self.device),
-                 torch.empty(B, dtype=torch.float32, device=self.device))
+                 torch.empty((B,) if S == 1 else (S, B), dtype=torch.float32, device=self.device))
             if len(self._state_bufs) > 4:
                 self._state_bufs.clear()
             self._state_bufs[B] = b
@@ -372,7 +382,7 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
-        if process_group is not None and self.exchange == "sharded":
+        if process_group is not None and self.exchange == "sharded" and self.n_samples == 1:
             from .sharded import train_step_sharded
             if not adam:
                 raise ValueError("the entity-sharded step always applies Adam")
@@ -401,7 +411,7 @@ class VFM(nn.Module):
                                    sparse=self.sparse_adam)
             mark("bwd_adam")
             return loss3, st.pred
-        if process_group is not None and adam and self.exchange == "stats":
+        if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             # multi-rank: exchange the gradient's sufficient statistics (sum grow, count, A_e) -- half
             # the bytes of the gradient -- then epilogue + Adam on every rank.  The table is cut in
             # `exchange_chunks` entity ranges: the all-reduce of chunk k overlaps the statistics kernel
@@ -474,7 +484,11 @@ class VFM(nn.Module):
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
         for epoch in range(n_epochs):
             for i, (plan, (a, b)) in enumerate(zip(plans, spans)):
-                loss3, _ = self.train_step(plan, out_pred=train_pred[a:b], process_group=process_group)
+                if self.n_samples == 1:
+                    loss3, _ = self.train_step(plan, out_pred=train_pred[a:b], process_group=process_group)
+                else:       # [S,B] predictions: the train metrics use their mean over the samples
+                    loss3, pr = self.train_step(plan, process_group=process_group)
+                    train_pred[a:b] = pr.mean(0)
                 losses[i] = loss3[0]
             # ---- end of epoch (vfm-torch.py:378-384)
             if self.output == "reg":
@@ -516,7 +530,7 @@ class VFM(nn.Module):
         epoch-averaged posterior means; None until save_weights() has run).  'reg' outputs are
         clipped to [1, 5] like the reference (:405-406); 'class' outputs are probabilities."""
         lik, last, mean, _ = self.forward(X)
-        y_pred = lik.mean.reshape(-1)
+        y_pred = lik.mean.mean(0)          # (S = 1: the sample itself; S > 1: mean over the S samples)
         if self.output == "reg":
             y_pred = y_pred.clamp(1, 5)
             mean = mean.clamp(1, 5) if mean is not None else None
@@ -546,7 +560,8 @@ class VFM(nn.Module):
         for _ in range(int(n_samples)):
             step = self.global_step
             self.global_step += 1
-            logit = ops.elbo_forward(plan, ent, bia, scal, None, seed=self.rng_seed, step=step, train=False).pred
+            logit = ops.elbo_forward(_single_sample(plan), ent, bia, scal, None, seed=self.rng_seed, step=step,
+                                     train=False).pred
             n += 1
             delta = logit - mean
             mean += delta / n
@@ -567,6 +582,17 @@ class VFM(nn.Module):
                     "rmse_of_last": rm(out["y_pred_of_last"]), "rmse_of_mean": rm(out["y_pred_of_mean"])}
         auc, ap = _auc_map(y, out["y_pred"])
         return {"auc": auc, "map": ap}
+
+
+def _single_sample(plan):
+    """The plan with n_samples = 1 (deterministic predictions / one draw per launch)."""
+    if plan.spec.n_samples == 1:
+        return plan
+    import copy
+    import dataclasses
+    p = copy.copy(plan)
+    p.spec = dataclasses.replace(plan.spec, n_samples=1)
+    return p
 
 
 def sort_rows_within_batches(X, y, batch_size):

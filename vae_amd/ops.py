@@ -27,6 +27,9 @@ from ._lib import Problem, check, ptr, current_stream_ptr
 FLAG_NO_PRIOR_TERMS = 1
 FLAG_EPS_ZERO = 2
 FLAG_SPARSE_ADAM = 4
+FLAG_ZPRE = 8
+FLAG_LINK_SOFTPLUS = 16
+MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
 
 
@@ -41,6 +44,18 @@ class Spec:
     group_n: tuple       # n_g multipliers (N, M in the reference)
     likelihood: int      # _lib.LIK_NORMAL / LIK_BERNOULLI
     nb_train: int = 1
+    n_samples: int = 1   # N_VARIATIONAL_SAMPLES (vfm-torch.py:19)
+    link: str = "abs"    # LINK (vfm-torch.py:125-126): "abs" (the one in effect) or "softplus"
+
+    def __post_init__(self):
+        if self.link not in ("abs", "softplus"):
+            raise ValueError("link must be 'abs' or 'softplus'")
+        if not 1 <= int(self.n_samples) <= MAX_SAMPLES:
+            raise ValueError(f"n_samples must be in [1,{MAX_SAMPLES}]")
+
+    @property
+    def link_flag(self) -> int:
+        return FLAG_LINK_SOFTPLUS if self.link == "softplus" else 0
 
 
 def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, step: int = 0,
@@ -48,7 +63,7 @@ def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, ste
     p = Problem()
     p.B, p.B_global, p.T, p.nb_train = B, B_global, spec.T, spec.nb_train
     p.F, p.d, p.likelihood, p.id_bits = spec.F, spec.d, spec.likelihood, id_bits
-    p.n_samples, p.flags = 1, flags
+    p.n_samples, p.flags = int(spec.n_samples), flags | spec.link_flag
     for g in range(spec.F):
         p.group_hi[g] = int(spec.group_hi[g])
         p.group_n[g] = float(spec.group_n[g])
@@ -144,7 +159,8 @@ class BatchPlan:
             items = torch.stack([slot, ib, ie, torch.zeros_like(slot)], 1).to(torch.int32).contiguous()
             rec = 4 + (self.spec.d + 3) // 4 * 4
             self.heavy = (heavy.to(torch.int32).contiguous(), items,
-                          torch.zeros(heavy.numel() * rec, dtype=torch.float32, device=flat.device))
+                          torch.zeros(self.spec.n_samples * heavy.numel() * rec, dtype=torch.float32,
+                                      device=flat.device))
 
     def index_tensors(self):
         """What the backward-family ops take as `index`."""
@@ -156,7 +172,7 @@ class BatchPlan:
 
 @dataclass
 class FwdState:
-    pred: torch.Tensor          # [B] unscaled prediction / logit
+    pred: torch.Tensor          # [B] unscaled prediction / logit ([S,B] when n_samples = S > 1)
     partials: torch.Tensor      # [8] fp64
     sumz: Optional[torch.Tensor]
     grow: Optional[torch.Tensor]
@@ -168,7 +184,8 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
                  seed=0, step=0, train=True, flags=0, out_pred=None, out_sumz=None,
                  out_grow=None, out_partials=None) -> FwdState:
     """Launch vfm_elbo_fwd_f32 on the current stream.  `eps` = (eps_entity[T,d], eps_bias[T],
-    eps_global[1]) tables indexed by entity id, or None for the in-kernel Philox stream."""
+    eps_global[1]) tables indexed by entity id ([S,T,d], [S,T], [S] with S = spec.n_samples > 1), or
+    None for the in-kernel Philox stream."""
     spec = plan.spec
     dev = plan.x.device
     for t, n in ((entity_params, "entity_params"), (bias_params, "bias_params"), (scalars, "scalars")):
@@ -177,20 +194,21 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
         raise ValueError("table shapes do not match the spec")
     have_y = plan.y is not None
     train = train and have_y
-    B = plan.B
-    pred = out_pred if out_pred is not None else torch.empty(B, dtype=torch.float32, device=dev)
+    B, S = plan.B, int(spec.n_samples)
+    pshape = (B,) if S == 1 else (S, B)
+    pred = out_pred if out_pred is not None else torch.empty(pshape, dtype=torch.float32, device=dev)
     partials = out_partials if out_partials is not None else torch.empty(
         _lib.PARTIALS_LEN, dtype=torch.float64, device=dev)
     sumz = grow = None
     if train:
-        sumz = out_sumz if out_sumz is not None else torch.empty(B, spec.d, dtype=torch.float32, device=dev)
+        sumz = out_sumz if out_sumz is not None else torch.empty(S * B, spec.d, dtype=torch.float32, device=dev)
         grow = out_grow if out_grow is not None else torch.empty(B, dtype=torch.float32, device=dev)
     p = _problem(spec, B, plan.B_global, plan.id_bits, seed, step, flags)
     e = eps if eps is not None else (None, None, None)
     _lib.ops().elbo_fwd(plan.x, plan.y, entity_params, bias_params, inv_occ if have_y else None, scalars,
                         plan.W if have_y else None, e[0], e[1], e[2], pred, partials, sumz, grow,
                         list(spec.group_hi), list(spec.group_n), spec.nb_train, plan.B_global,
-                        spec.likelihood, flags, p.seed & _I63, p.step)
+                        spec.likelihood, p.flags, p.seed & _I63, p.step, S)
     return FwdState(pred, partials, sumz, grow, p, eps)
 
 
@@ -198,7 +216,7 @@ def elbo_finalize(st: FwdState, scalars, out=None) -> torch.Tensor:
     """loss[3] = (loss, likelihood term, KL term) from (rank-summed) partials."""
     loss = out if out is not None else torch.empty(3, dtype=torch.float32, device=scalars.device)
     p = st.problem
-    _lib.ops().elbo_finalize(st.partials, scalars, loss, p.nb_train, p.B_global, p.flags)
+    _lib.ops().elbo_finalize(st.partials, scalars, loss, p.nb_train, p.B_global, p.flags, p.n_samples)
     return loss
 
 
@@ -219,7 +237,7 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
     _lib.ops().elbo_bwd(plan.index_tensors(), entity_params, bias_params, inv_occ, scalars, plan.W,
                         e[0], e[1], e[2], st.sumz, st.grow, st.partials, grad_out, g_entity, g_bias, g_scalars,
                         spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
-                        p.flags, p.seed & _I63, p.step)
+                        p.flags, p.seed & _I63, p.step, p.n_samples)
     return g_entity, g_bias, g_scalars
 
 
@@ -238,7 +256,7 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
                              p.flags | (FLAG_SPARSE_ADAM if sparse else 0),
-                             p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out)
+                             p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples)
 
 
 def exchange_record_len(d: int) -> int:
@@ -280,10 +298,13 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 def philox_eps(spec: Spec, seed: int, step: int, device):
-    """The eps tables the kernels generate for (seed, step) -- test helper."""
-    ee = torch.empty(spec.T, spec.d, dtype=torch.float32, device=device)
-    eb = torch.empty(spec.T, dtype=torch.float32, device=device)
-    eg = torch.empty(1, dtype=torch.float32, device=device)
+    """The eps tables the kernels generate for (seed, step) -- test helper.  [T,d], [T], [1]; with
+    S = spec.n_samples > 1: [S,T,d], [S,T], [S]."""
+    S = int(spec.n_samples)
+    lead = () if S == 1 else (S,)
+    ee = torch.empty(*lead, spec.T, spec.d, dtype=torch.float32, device=device)
+    eb = torch.empty(*lead, spec.T, dtype=torch.float32, device=device)
+    eg = torch.empty(S, dtype=torch.float32, device=device)
     p = _problem(spec, 0, 0, 64, seed, step)
     lib = _lib.load()
     check(lib.vfm_philox_eps_f32(C.byref(p), ptr(ee), ptr(eb), ptr(eg), current_stream_ptr(ee.device)),

@@ -38,6 +38,8 @@ class ShardedPlan:
 
     def __init__(self, spec: ops.Spec, x: torch.Tensor, y: torch.Tensor, inv_occ: torch.Tensor, B_global: int,
                  group, rank: int, world: int):
+        if spec.n_samples != 1:
+            raise NotImplementedError("entity-sharded exchange supports n_samples == 1 only (use exchange='grads')")
         dev = x.device
         self.rank, self.world, self.group = rank, world, group
         self.spec = spec
@@ -80,7 +82,8 @@ class ShardedPlan:
         self.rec_ptr = rp.to(torch.int32).contiguous()
         # --- inverted index over slots (what vfm_elbo_bwd_acc_f32 walks)
         sspec = ops.Spec(T=max(self.U, 1), F=spec.F, d=spec.d, group_hi=tuple([max(self.U, 1)] * spec.F),
-                         group_n=tuple([1.0] * spec.F), likelihood=spec.likelihood, nb_train=spec.nb_train)
+                         group_n=tuple([1.0] * spec.F), likelihood=spec.likelihood, nb_train=spec.nb_train,
+                         link=spec.link)
         self.slot_plan = ops.BatchPlan(sspec, self.x_slots, self.y, None, B_global=B_global,
                                        build_index=True, validate=False)
         self.slot_plan.W = self.W
@@ -116,7 +119,8 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     mark("start")
     # 1. owners sample what was requested; 2. ship
     if plan.R:
-        _lib.ops().shard_sample(plan.req_ids, ent, bia, e[0], e[1], plan.zsend, model.rng_seed & ops._I63, step)
+        _lib.ops().shard_sample(plan.req_ids, ent, bia, e[0], e[1], plan.zsend, model.rng_seed & ops._I63, step,
+                                spec.link_flag)
     dist.all_to_all_single(plan.zrecv[: plan.U * plan.rl], plan.zsend[: plan.R * plan.rl],
                            plan.splits(plan.need_counts), plan.splits(plan.req_counts), group=plan.group)
     mark("sample_a2a")
@@ -127,7 +131,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     partials = model._partials
     flags = 0 if r == 0 else ops.FLAG_NO_PRIOR_TERMS
     _lib.ops().elbo_fwd_zpre(plan.x_slots, plan.y, plan.zrecv, scal, e[2], pred, partials, sumz, grow,
-                             spec.d, spec.nb_train, plan.B_global, spec.likelihood, flags,
+                             spec.d, spec.nb_train, plan.B_global, spec.likelihood, flags | spec.link_flag,
                              model.rng_seed & ops._I63, step)
     st = ops.FwdState(pred, partials, sumz, grow, ops._problem(plan.slot_plan.spec, plan.B, plan.B_global, 32,
                                                              model.rng_seed, step, flags), None)
