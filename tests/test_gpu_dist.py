@@ -25,7 +25,7 @@ def _free_port():
 def _make_model(c, dev):
     from vae_amd.model import VFM
     torch.manual_seed(42)
-    m = VFM(c.N, c.M, c.d, output=c.output, device=dev, rng_seed=77)
+    m = VFM(c.N, c.M, c.d, output=c.output, device=dev, rng_seed=77, n_samples=c.n_samples, link=c.link)
     m.set_training_data(torch.tensor(c.x), nb_train=c.nb_train, nb_occ=torch.tensor(c.nb_occ))
     return m
 
@@ -52,8 +52,10 @@ def _worker(rank, world, port, name, out_dir, exchange="stats"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["stats", "grads"])
-@pytest.mark.parametrize("name", ["ml100k_reg_d20"])
+@pytest.mark.parametrize("name,exchange", [("ml100k_reg_d20", "stats"), ("ml100k_reg_d20", "grads"),
+                                           ("softplus_reg_d8", "stats"),
+                                           ("multi_reg_d8_s3", "auto"),             # S > 1: falls back to "grads"
+                                           ("softplus_multi_class_d8_s2", "auto")])
 def test_two_ranks_match_one_rank(name, exchange, tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), exchange), nprocs=world, join=True)
@@ -141,7 +143,7 @@ def _sharded_worker(rank, world, port, name, out_dir, use_tables):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name,use_tables", [("ml100k_reg_d20", True), ("ml100k_reg_d20", False),
-                                             ("dup_class_d12", True)])
+                                             ("dup_class_d12", True), ("softplus_reg_d8", False)])
 def test_entity_sharded_step_matches_one_rank(name, use_tables, world, tmp_path):
     """Entity-sharded mode (tables partitioned by e mod N, two all-to-alls per step) == the 1-rank step:
     losses, and after sync_params every parameter."""
