@@ -125,22 +125,22 @@ def main():
             us.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
         return ps, us
 
-    exchange_note = None
-    try:
-        plans, uniq = build_plans()
-    except Exception as exc:          # communication-pattern fallback only (never a compute fallback)
-        if world > 1 and model.exchange == "sharded":
-            exchange_note = "sharded plan failed (%s: %s); using the statistics all-reduce" % (
-                type(exc).__name__, str(exc)[:200])
-            print("[bench] " + exchange_note, file=sys.stderr)
-            model.exchange = "stats"
-            plans, uniq = build_plans()
-        else:
-            raise
-    U = sum(uniq) / len(uniq)
-
     events = []
     dummy = torch.zeros(1, device=dev)
+    plans = uniq = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(group=pg)
+            torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
+            v = float(t.item())
+        return v
 
     def run(n, record):
         for s in range(n):
@@ -160,11 +160,54 @@ def main():
             if os.environ.get("VFM_DBG_TORCHOP"):
                 dummy.add_(1)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(group=pg)
-            torch.cuda.synchronize()
+    # ---- N > 1, --exchange auto: which exchange pattern is faster depends on the fabric (all-to-all of the
+    # touched rows vs chunk-overlapped all-reduce of the statistics table), so both are timed for a few
+    # steps from the same initial state -- outside the timed region -- and the faster one is benchmarked.
+    exchange_note, tune = None, None
+    if world > 1 and args.exchange == "auto":
+        init = model._flat.clone()
+        model._ensure_opt_state()
+
+        def reset_state():
+            model._flat.copy_(init)
+            model._adam_m.zero_(); model._adam_v.zero_()
+            model._adam_t, model.global_step, model._stale_group = 0, 0, None
+
+        tune, built = {}, {}
+        table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
+        for mode in (("sharded", "stats") if table_bytes >= (4 << 20) else ("stats",)):
+            model.exchange = mode
+            try:
+                plans, uniq = build_plans()
+            except Exception as exc:      # communication-pattern fallback only (never a compute fallback)
+                exchange_note = "%s plan failed (%s: %s)" % (mode, type(exc).__name__, str(exc)[:200])
+                print("[bench] " + exchange_note, file=sys.stderr)
+                continue
+            run(3, False)
+            barrier()
+            t0 = time.perf_counter()
+            run(10, False)
+            barrier()
+            tune[mode] = round(max_over_ranks(time.perf_counter() - t0) / 10 * 1e3, 4)
+            built[mode] = (plans, uniq)
+            reset_state()
+        best = min(tune, key=tune.get)
+        model.exchange = best
+        plans, uniq = built[best]
+        del built
+    else:
+        try:
+            plans, uniq = build_plans()
+        except Exception as exc:          # communication-pattern fallback only (never a compute fallback)
+            if world > 1 and model.exchange == "sharded":
+                exchange_note = "sharded plan failed (%s: %s); using the statistics all-reduce" % (
+                    type(exc).__name__, str(exc)[:200])
+                print("[bench] " + exchange_note, file=sys.stderr)
+                model.exchange = "stats"
+                plans, uniq = build_plans()
+            else:
+                raise
+    U = sum(uniq) / len(uniq)
 
     run(args.warmup, False)
     barrier()
@@ -172,11 +215,7 @@ def main():
     run(args.steps, not args.no_events)
     t_host = time.perf_counter() - t0          # host time to enqueue all steps (before the sync)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
     loss = float(model._gflat[model._n_flat].item())
     if world > 1 and model.exchange == "sharded":
         model.sync_params(pg)
@@ -280,7 +319,11 @@ def main():
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
-                       "step": ("fwd+loss+bwd_acc+allreduce(stats)+apply_adam" if world > 1 else "fwd+loss+bwd+dense-adam") if
+                       "exchange_autotune_ms_per_step": tune,
+                       "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
+                                 "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
+                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)"}[model.exchange]
+                                if world > 1 else "fwd+loss+bwd+dense-adam") if
                                (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
                        "parallelism": f"row-sharded dp{world}"},
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
