@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--sync-each-step", action="store_true", help="debug: host sync after every step")
     ap.add_argument("--unfused", action="store_true", help="separate backward and Adam kernels (as N>1 does)")
+    ap.add_argument("--plain-moments", action="store_true",
+                    help="A/B: keep the Adam moments in the plain form (no VFM_FLAG_SCALED_MOMENTS)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +100,7 @@ def main():
     torch.manual_seed(42)
     model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
     model.exchange = args.exchange
+    model.scaled_moments = not args.plain_moments
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -126,7 +129,6 @@ def main():
         return ps, us
 
     events = []
-    dummy = torch.zeros(1, device=dev)
     plans = uniq = None
 
     def barrier():
@@ -157,8 +159,6 @@ def main():
             model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused)
             if args.sync_each_step:
                 torch.cuda.synchronize()
-            if os.environ.get("VFM_DBG_TORCHOP"):
-                dummy.add_(1)
 
     # ---- N > 1, --exchange auto: which exchange pattern is faster depends on the fabric (all-to-all of the
     # touched rows vs chunk-overlapped all-reduce of the statistics table), so both are timed for a few
@@ -171,7 +171,7 @@ def main():
         def reset_state():
             model._flat.copy_(init)
             model._adam_m.zero_(); model._adam_v.zero_()
-            model._adam_t, model.global_step, model._stale_group = 0, 0, None
+            model._adam_t, model.global_step, model._stale_group, model._moments_scaled = 0, 0, None, False
 
         tune, built = {}, {}
         table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
@@ -238,7 +238,9 @@ def main():
         alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
                "allreduce": 4.0 * n_params,
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
-               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params,
+               # (scaled moments: the rows a batch does not touch read p, m, v and write p only: 16 B/param)
+               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params -
+                           (8.0 * (model.T - U) * (2 * d + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0),
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
                "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
                # all-reduce of the statistics overlapped with the epilogue + dense Adam kernels
@@ -318,6 +320,8 @@ def main():
                        "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
+                       "adam_moments": "scaled form (untouched rows do not write m, v)" if (
+                           model.scaled_moments and world == 1 and not args.unfused) else "plain",
                        "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
                        "exchange_autotune_ms_per_step": tune,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",

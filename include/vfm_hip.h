@@ -51,6 +51,15 @@ extern "C" {
 #define VFM_FLAG_SPARSE_ADAM 4    /* vfm_elbo_bwd_adam_f32 only, OPT-IN, changes results: rows that are not
                                      in the batch are skipped (no momentum drift), unlike the reference's
                                      dense Adam (vfm-torch.py:339); bias corrections use the global step   */
+#define VFM_FLAG_SCALED_MOMENTS 32 /* vfm_elbo_bwd_adam_f32 / vfm_elbo_apply_adam_f32: the moment buffers hold
+                                     m / beta1^k and v / beta2^k, k = t mod VFM_MOMENT_PERIOD after Adam step t
+                                     (k = 0: the plain moments).  The decay of a row without gradient is then
+                                     implicit, so the rows a batch does not touch read their moments but do not
+                                     write them back: 16 instead of 24 bytes per parameter.  Same dense Adam
+                                     (every row moves every step); results equal the plain form up to fp32
+                                     rounding.  Every VFM_MOMENT_PERIOD-th step writes the plain moments for all
+                                     rows.  vfm_moments_rescale_f32 converts a buffer between the two forms.   */
+#define VFM_MOMENT_PERIOD 128
 #define VFM_FLAG_ZPRE 8           /* vfm_elbo_fwd_f32: `entity_params` holds PRECOMPUTED samples, one record
                                      (w, 0, 0, 0 | z[0..d-1]) of 4 + round4(d) floats per slot, and x holds
                                      slot numbers (entity-sharded mode: the owner of an entity samples it
@@ -265,6 +274,12 @@ int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
  * pointers 16-byte aligned. */
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, void* stream);
+
+/* Convert Adam moment buffers (n floats each) between the plain form and the scaled form of
+ * VFM_FLAG_SCALED_MOMENTS, `step` = number of Adam steps applied so far: to_scaled != 0 divides m by
+ * beta1^(step mod VFM_MOMENT_PERIOD) and v by beta2^(...), to_scaled == 0 multiplies. */
+int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float beta2, int64_t step, int32_t to_scaled,
+                            void* stream);
 
 /* Debug / test helper: write the eps the kernels would generate from (seed, step) into
  * tables (eps_entity [S,T,d], eps_bias [S,T], eps_global [S]; S = n_samples). */

@@ -29,6 +29,7 @@ EXPORTS = (
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
+    "vfm_moments_rescale_f32",
 )
 
 
@@ -94,6 +95,7 @@ def load():
     lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.vfm_shard_pack_f32.argtypes = [vp, vp, vp, vp]
     lib.vfm_shard_loss_f32.argtypes = [vp, vp, vp]
+    lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":

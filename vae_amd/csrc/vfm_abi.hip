@@ -205,6 +205,22 @@ void adam_consts(float lr, float beta1, float beta2, int64_t step, float* step_s
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
+// VFM_FLAG_SCALED_MOMENTS: scale factors of Adam step `step` (k = position inside the period, 1..R)
+int scaled_moment_consts(const vfm_problem_t* p, float beta1, float beta2, int64_t step, AdamArgs* ad) {
+  ad->scaled = 0; ad->store_true = 0; ad->s1 = ad->s2 = 1.f; ad->c1 = 1.f - beta1; ad->c2 = 1.f - beta2;
+  if (!(p->flags & VFM_FLAG_SCALED_MOMENTS)) return 0;
+  if (p->flags & VFM_FLAG_SPARSE_ADAM)
+    return fail(VFM_E_INVALID, "VFM_FLAG_SCALED_MOMENTS and VFM_FLAG_SPARSE_ADAM exclude each other");
+  const int64_t k = (step - 1) % VFM_MOMENT_PERIOD + 1;
+  const double s1 = pow((double)beta1, (double)k), s2 = pow((double)beta2, (double)k);
+  if (!(s1 > 1e-30) || !(s2 > 1e-30))
+    return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_SCALED_MOMENTS: beta^128 underflows (use the plain moments for such betas)");
+  ad->scaled = 1; ad->store_true = (k == VFM_MOMENT_PERIOD);
+  ad->s1 = (float)s1; ad->s2 = (float)s2;
+  ad->c1 = (float)((1.0 - (double)beta1) / s1); ad->c2 = (float)((1.0 - (double)beta2) / s2);
+  return 0;
+}
+
 }  // namespace
 }  // namespace vfm
 
@@ -338,6 +354,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
@@ -393,6 +410,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
@@ -464,6 +482,20 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
   hipLaunchKernelGGL(k_adam, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
                      beta2, eps, step_size, bc2_sqrt);
   return after_launch("vfm_adam_f32");
+}
+
+int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float beta2, int64_t step, int32_t to_scaled,
+                            void* stream) {
+  if (!m || !v || n < 0 || step < 0) return fail(VFM_E_INVALID, "vfm_moments_rescale_f32: bad argument");
+  const int64_t k = step % VFM_MOMENT_PERIOD;
+  if (k == 0 || n == 0) return 0;       // at a period boundary both forms coincide
+  double c1 = pow((double)beta1, (double)k), c2 = pow((double)beta2, (double)k);
+  if (!(c1 > 1e-30) || !(c2 > 1e-30)) return fail(VFM_E_UNSUPPORTED, "vfm_moments_rescale_f32: beta^k underflows");
+  if (to_scaled) { c1 = 1.0 / c1; c2 = 1.0 / c2; }
+  int64_t nb = (n + BLOCK - 1) / BLOCK;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_rescale2, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, m, v, n, (float)c1, (float)c2);
+  return after_launch("vfm_moments_rescale_f32");
 }
 
 int vfm_philox_eps_f32(const vfm_problem_t* p, float* eps_entity, float* eps_bias, float* eps_global,

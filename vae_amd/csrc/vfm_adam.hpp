@@ -39,6 +39,15 @@ __global__ __launch_bounds__(BLOCK) void k_adam(float* __restrict__ p, const flo
   }
 }
 
+// m *= c1, v *= c2 (conversion between the plain and the scaled moment representation)
+__global__ __launch_bounds__(BLOCK) void k_rescale2(float* __restrict__ m, float* __restrict__ v, int64_t n, float c1,
+                                                    float c2) {
+  for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    m[i] *= c1;
+    v[i] *= c2;
+  }
+}
+
 // eps dump (tests)
 __global__ void k_philox_dump(const KArgs a, float* eps_entity, float* eps_bias, float* eps_global) {
   const RngKey key = key_of_sample(a.key, a.sample);

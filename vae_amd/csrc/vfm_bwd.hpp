@@ -18,7 +18,22 @@
 // sum over samples of dloss/dpred[s,r]; with A^s = sum_r grow_r sumz^s_r and gs = sum_r grow_r,
 //   dloss/dmu_e = 1/S sum_s (A^s - z^s gs),   dloss/ds_e = link'(s_e) 1/S sum_s eps^s (A^s - z^s gs)
 // (+ the KL part, which does not depend on the sample): the list of e is walked once per sample.
+// Scaled moments (VFM_FLAG_SCALED_MOMENTS): with ms = m / b1^k and vs = v / b2^k stored instead of m and
+// v (k = steps since the last period boundary), the decay of a row WITHOUT gradient is implicit -- its ms
+// and vs do not change, so they are read but not written back: 16 instead of 24 bytes per parameter for
+// the rows a batch does not touch.  Same dense-Adam mathematics (every row still moves every step):
+//   ms += (1-b1) g / b1^k,  vs += (1-b2) g^2 / b2^k,  m = ms b1^k,  v = vs b2^k,  p -= lr_t m / (sqrt(v)/.. + eps)
+// At the end of a period of VFM_MOMENT_PERIOD steps the true m, v are written for every row (k restarts),
+// which bounds 1 / b1^k (0.9^-128 = 7e5).
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamArgs& ad) {
+  if (ad.scaled) {                     // uniform
+    m = fmaf(ad.c1, g, m);
+    v = fmaf(ad.c2 * g, g, v);
+    const float mt = m * ad.s1, vt = v * ad.s2;
+    const float denom = __fsqrt_rn(vt) / ad.bc2_sqrt + ad.eps;
+    if (ad.store_true) { m = mt; v = vt; }
+    return p + (-ad.step_size * mt) / denom;
+  }
   m = m + (g - m) * (1.0f - ad.b1);
   v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
   const float denom = __fsqrt_rn(v) / ad.bc2_sqrt + ad.eps;
@@ -364,8 +379,10 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
           const size_t o2 = (size_t)e * (2 * (size_t)d) + (size_t)j * VEC;
           st_chunk<VEC>(prow + (size_t)j * VEC, pm);
           st_chunk<VEC>(prow + d + (size_t)j * VEC, ps);
-          st_chunk_nt<VEC>(ad.m_entity + o2, mm[i]); st_chunk_nt<VEC>(ad.m_entity + o2 + d, ms[i]);
-          st_chunk_nt<VEC>(ad.v_entity + o2, vm[i]); st_chunk_nt<VEC>(ad.v_entity + o2 + d, vs[i]);
+          if (!ad.scaled || touched || ad.store_true) {     // (scaled: rows without gradient keep ms, vs)
+            st_chunk_nt<VEC>(ad.m_entity + o2, mm[i]); st_chunk_nt<VEC>(ad.m_entity + o2 + d, ms[i]);
+            st_chunk_nt<VEC>(ad.v_entity + o2, vm[i]); st_chunk_nt<VEC>(ad.v_entity + o2 + d, vs[i]);
+          }
         } else {
           st_chunk_nt<VEC>(grow_e + (size_t)j * VEC, gm);
           st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, gv);
@@ -387,8 +404,10 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         pn.x = adam_update(th.x, g0, mb.x, vb.x, ad);
         pn.y = adam_update(th.y, g1, mb.y, vb.y, ad);
         *reinterpret_cast<float2*>(const_cast<float*>(a.bias) + 2 * (size_t)e) = pn;
-        *reinterpret_cast<float2*>(ad.m_bias + 2 * (size_t)e) = mb;
-        *reinterpret_cast<float2*>(ad.v_bias + 2 * (size_t)e) = vb;
+        if (!ad.scaled || touched || ad.store_true) {
+          *reinterpret_cast<float2*>(ad.m_bias + 2 * (size_t)e) = mb;
+          *reinterpret_cast<float2*>(ad.v_bias + 2 * (size_t)e) = vb;
+        }
       } else {
         *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(g0, g1);
       }

@@ -351,6 +351,15 @@ void adam(Tensor p, const Tensor& g, Tensor m, Tensor v, double lr, double beta1
         "vfm_adam_f32");
 }
 
+void moments_rescale(Tensor m, Tensor v, double beta1, double beta2, int64_t step, bool to_scaled) {
+  dev_tensor(m, at::kFloat, "m"); dev_tensor(v, at::kFloat, "v");
+  TORCH_CHECK(m.numel() == v.numel(), "moment sizes");
+  c10::hip::HIPGuard guard(m.get_device());
+  check(vfm_moments_rescale_f32(m.data_ptr<float>(), v.data_ptr<float>(), m.numel(), (float)beta1, (float)beta2, step,
+                                to_scaled ? 1 : 0, stream_of(m)),
+        "vfm_moments_rescale_f32");
+}
+
 int64_t abi_version() { return vfm_abi_version(); }
 
 }  // namespace
@@ -393,6 +402,8 @@ TORCH_LIBRARY(vfm_hip, m) {
   m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d, bool atomic) -> ()", &records_add);
   m.def("shard_pack(Tensor(a!) small, Tensor loss_local, Tensor kl_ws) -> ()", &shard_pack);
   m.def("shard_loss(Tensor small, Tensor(a!) loss3) -> ()", &shard_loss);
+  m.def("moments_rescale(Tensor(a!) m, Tensor(b!) v, float beta1, float beta2, int step, bool to_scaled) -> ()",
+        &moments_rescale);
   m.def("adam(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
         "int step) -> ()", &adam);
 }

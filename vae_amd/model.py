@@ -93,6 +93,10 @@ class VFM(nn.Module):
         # OPT-IN, changes results: Adam only on the rows of the batch (no momentum drift of the
         # other rows); the reference's dense Adam (vfm-torch.py:339) moves every row every step
         self.sparse_adam = bool(sparse_adam)
+        # fused single-rank step: keep the Adam moments in the scaled form (VFM_FLAG_SCALED_MOMENTS: rows the
+        # batch does not touch do not write their moments back; same dense Adam up to fp32 rounding)
+        self.scaled_moments = True
+        self._moments_scaled = False       # which form _adam_m / _adam_v are in right now
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
@@ -193,7 +197,7 @@ class VFM(nn.Module):
         opt = None
         if self._adam_m is not None:
             opt = {"m": self._adam_m.detach().cpu().clone(), "v": self._adam_v.detach().cpu().clone(),
-                   "t": int(self._adam_t)}
+                   "t": int(self._adam_t), "scaled_form": bool(self._moments_scaled)}   # (buffers stored as they are)
         snap = None
         if self._n_saved:
             snap = {"n": int(self._n_saved), "mean": self._mean_flat.detach().cpu().clone(),
@@ -210,6 +214,7 @@ class VFM(nn.Module):
             self._adam_m.copy_(state["adam"]["m"].to(self.device))
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
+            self._moments_scaled = bool(state["adam"].get("scaled_form", False))
         if state.get("snapshots") is not None:
             self._n_saved = int(state["snapshots"]["n"])
             self._mean_flat = state["snapshots"]["mean"].to(self.device).clone()
@@ -337,6 +342,12 @@ class VFM(nn.Module):
             self._partials = torch.zeros(_lib.PARTIALS_LEN, dtype=torch.float64, device=self.device)
             self._state_bufs = {}
 
+    def _set_moment_form(self, scaled: bool):
+        """Bring _adam_m / _adam_v into the scaled / plain form (a no-op unless the form changes)."""
+        if self._adam_m is not None and scaled != self._moments_scaled:
+            ops.moments_rescale(self._adam_m, self._adam_v, self._adam_t, to_scaled=scaled)
+        self._moments_scaled = bool(scaled)
+
     def _xviews(self):
         """Flat exchange buffer: T records [sum grow, count, 0, 0 | A_e (d)] then [row sums: 2 | pad: 2 |
         loss: 3 | pad]; plus the entity boundaries of the exchange chunks."""
@@ -386,6 +397,7 @@ class VFM(nn.Module):
             from .sharded import train_step_sharded
             if not adam:
                 raise ValueError("the entity-sharded step always applies Adam")
+            self._set_moment_form(False)
             return train_step_sharded(self, plan, lr, eps=eps, out_pred=out_pred, mark=mark)
         ent, bia, scal = self._views(self._flat)
         g_ent, g_bias, g_scal = self._views(self._gflat)
@@ -405,12 +417,15 @@ class VFM(nn.Module):
             fused = self.fuse_adam
         if fused and adam and process_group is None:
             # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
+            scaled = self.scaled_moments and not self.sparse_adam
+            self._set_moment_form(scaled)
             self._adam_t += 1
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
                                    self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                   sparse=self.sparse_adam)
+                                   sparse=self.sparse_adam, scaled_moments=scaled)
             mark("bwd_adam")
             return loss3, st.pred
+        self._set_moment_form(False)
         if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             # multi-rank: exchange the gradient's sufficient statistics (sum grow, count, A_e) -- half
             # the bytes of the gradient -- then epilogue + Adam on every rank.  The table is cut in

@@ -29,6 +29,8 @@ FLAG_EPS_ZERO = 2
 FLAG_SPARSE_ADAM = 4
 FLAG_ZPRE = 8
 FLAG_LINK_SOFTPLUS = 16
+FLAG_SCALED_MOMENTS = 32
+MOMENT_PERIOD = 128
 MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
 
@@ -243,10 +245,11 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
 
 def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
                        m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None,
-                       sparse=False):
+                       sparse=False, scaled_moments=False):
     """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
     m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
-    work of elbo_finalize in the same launch."""
+    work of elbo_finalize in the same launch.  `scaled_moments`: the buffers are in the scaled form of
+    VFM_FLAG_SCALED_MOMENTS (see include/vfm_hip.h; `moments_rescale` converts)."""
     if plan.occ_ptr is None:
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
@@ -255,7 +258,8 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              e[0], e[1], e[2], st.sumz, st.grow, st.partials, m_views[0], v_views[0],
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
-                             p.flags | (FLAG_SPARSE_ADAM if sparse else 0),
+                             p.flags | (FLAG_SPARSE_ADAM if sparse else 0) |
+                             (FLAG_SCALED_MOMENTS if scaled_moments else 0),
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples)
 
 
@@ -288,6 +292,11 @@ def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bia
                                p.B_global, p.likelihood, p.flags & ~FLAG_NO_PRIOR_TERMS, p.seed & _I63, p.step,
                                lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi, own_mod, own_rank, kl_ws,
                                rec_index[0] if rec_index else None, rec_index[1] if rec_index else None)
+
+
+def moments_rescale(m, v, step, to_scaled, beta1=0.9, beta2=0.999):
+    """Convert flat Adam moment buffers between the plain and the scaled form (`step` = Adam steps so far)."""
+    _lib.ops().moments_rescale(m, v, beta1, beta2, int(step), bool(to_scaled))
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
