@@ -208,6 +208,7 @@ void adam_consts(float lr, float beta1, float beta2, int64_t step, float* step_s
 // VFM_FLAG_SCALED_MOMENTS: scale factors of Adam step `step` (k = position inside the period, 1..R)
 int scaled_moment_consts(const vfm_problem_t* p, float beta1, float beta2, int64_t step, AdamArgs* ad) {
   ad->scaled = 0; ad->store_true = 0; ad->s1 = ad->s2 = 1.f; ad->c1 = 1.f - beta1; ad->c2 = 1.f - beta2;
+  ad->inv_bc2_sqrt = 1.0f / ad->bc2_sqrt;
   if (!(p->flags & VFM_FLAG_SCALED_MOMENTS)) return 0;
   if (p->flags & VFM_FLAG_SPARSE_ADAM)
     return fail(VFM_E_INVALID, "VFM_FLAG_SCALED_MOMENTS and VFM_FLAG_SPARSE_ADAM exclude each other");

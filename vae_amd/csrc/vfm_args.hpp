@@ -84,7 +84,7 @@ struct AdamArgs {
   // VFM_FLAG_SCALED_MOMENTS: the buffers hold m / b1^k, v / b2^k; s1 = b1^k, s2 = b2^k of THIS step,
   // c1 = (1-b1)/s1, c2 = (1-b2)/s2; store_true: this step ends a period (write the true moments back)
   int32_t scaled, store_true;
-  float s1, s2, c1, c2;
+  float s1, s2, c1, c2, inv_bc2_sqrt;
 };
 
 // lane-group shape of the row kernels for an embedding size (see pick_shape in vfm_abi.hip)

@@ -28,7 +28,13 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+  if constexpr (STAGE == STAGE_FULL) {
+    if (a.S > 1) {       // variational samples: the instance with the per-sample walk
+      hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
   return 0;
 }
 

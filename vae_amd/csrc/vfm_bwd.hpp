@@ -27,12 +27,15 @@
 // which bounds 1 / b1^k (0.9^-128 = 7e5).
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamArgs& ad) {
   if (ad.scaled) {                     // uniform
+    // (this form is not bitwise torch's anyway: hardware sqrt / rcp, 1 ulp each, instead of the IEEE
+    // sqrt and the two IEEE divisions of the plain form below -- ~10 instead of ~45 VALU instructions
+    // per coordinate, which the kernel would otherwise not hide behind its memory traffic)
     m = fmaf(ad.c1, g, m);
     v = fmaf(ad.c2 * g, g, v);
     const float mt = m * ad.s1, vt = v * ad.s2;
-    const float denom = __fsqrt_rn(vt) / ad.bc2_sqrt + ad.eps;
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(vt), ad.inv_bc2_sqrt, ad.eps);
     if (ad.store_true) { m = mt; v = vt; }
-    return p + (-ad.step_size * mt) / denom;
+    return fmaf(-ad.step_size * mt, __builtin_amdgcn_rcpf(denom), p);
   }
   m = m + (g - m) * (1.0f - ad.b1);
   v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
@@ -49,7 +52,7 @@ __device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
   return (n > 0 && ids[lo] == e) ? lo : -1;
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK>
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[VFM_MAX_FIELDS];
@@ -92,18 +95,19 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
                          ? gout * dlink_f<LINK>(alpha) * a.ll_scale * sum_a : 0.f;
     const float gm = gout * (sum_g + prior * m0);
     // S > 1: every sample has its own eps0 -- the forward accumulated sum_s eps0^s sum_r g_sr
-    const float ge0 = (a.S > 1) ? (float)(fold ? fin[VFM_P_GE0] : b.partials[VFM_P_GE0]) : e0 * sum_g;
+    const float ge0 = MULTI ? (float)(fold ? fin[VFM_P_GE0] : b.partials[VFM_P_GE0]) : e0 * sum_g;
     const float gs = gout * dlink_f<LINK>(s0) * (ge0 + prior * (as0 - inv_sigma(as0)));
     if constexpr (ADAM) {
       float* sc = const_cast<float*>(a.scalars);
-      const float gg[3] = {ga, gm, gs};
-      for (int i = 0; i < 3; ++i) {
+      auto upd = [&](int i, float g) {
         float m = ad.m_scal[i], v = ad.v_scal[i];
-        // alpha has no gradient under the Bernoulli likelihood (reference: grad None, Adam skips it)
-        if (i == 0 && a.lik != VFM_LIK_NORMAL) continue;
-        sc[i] = adam_update(sc[i], gg[i], m, v, ad);
+        sc[i] = adam_update(sc[i], g, m, v, ad);
         ad.m_scal[i] = m; ad.v_scal[i] = v;
-      }
+      };
+      // alpha has no gradient under the Bernoulli likelihood (reference: grad None, Adam skips it)
+      if (a.lik == VFM_LIK_NORMAL) upd(0, ga);
+      upd(1, gm);
+      upd(2, gs);
     } else {
       b.g_scalars[0] = ga; b.g_scalars[1] = gm; b.g_scalars[2] = gs;
     }
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     }
     float nb_eps = 0.f;
     // S > 1 (uniform): g1s = 1/S sum_s (A^s - z^s gs), g2s = 1/S sum_s eps^s (A^s - z^s gs), nb_eps = mean_s eps_w^s
-    const bool multi = STAGE == STAGE_FULL && a.S > 1;
+    // (MULTI is a template parameter so that the S = 1 instances carry none of this: registers, occupancy)
+    constexpr bool multi = MULTI && STAGE == STAGE_FULL;
     Chunk<VEC> g1s[CPL], g2s[CPL];
     if (multi && touched) {
 #pragma unroll
