@@ -60,6 +60,14 @@ extern "C" {
                                      rounding.  Every VFM_MOMENT_PERIOD-th step writes the plain moments for all
                                      rows.  vfm_moments_rescale_f32 converts a buffer between the two forms.   */
 #define VFM_MOMENT_PERIOD 128
+#define VFM_FLAG_ROWS_UNTOUCHED 64 /* vfm_elbo_bwd_adam_f32: handle ONLY the table rows the batch does not contain.
+                                     Their update is pure Adam decay (zero gradient) and depends on nothing the
+                                     step's forward produces, and the forward reads none of those rows, so the
+                                     caller may run this call CONCURRENTLY with vfm_elbo_fwd_f32 on another stream
+                                     (memory-bound work beside the arithmetic-bound forward).  sumz, grow, partials,
+                                     inv_occ, W, loss may be NULL.                                              */
+#define VFM_FLAG_ROWS_TOUCHED 128  /* ... and the complement: the rows of the batch, the three scalars, the loss.
+                                     The two calls together equal one call without either flag.                */
 #define VFM_FLAG_ZPRE 8           /* vfm_elbo_fwd_f32: `entity_params` holds PRECOMPUTED samples, one record
                                      (w, 0, 0, 0 | z[0..d-1]) of 4 + round4(d) floats per slot, and x holds
                                      slot numbers (entity-sharded mode: the owner of an entity samples it
@@ -148,7 +156,8 @@ const char* vfm_last_error(void);
 int vfm_inv_occ_f32(const int64_t* nb_occ, float* inv_occ, int64_t T, void* stream);
 
 /* W[f] = sum_r inv_occ[x[r,f]] -- the user/item normalisers of vfm-torch.py:305-306 in
- * row-wise form.  `W` (fp64 [F]) is zeroed by the call.  Parameter-free: depends on the
+ * row-wise form.  `W` (fp64 [F]) is overwritten; the sums are bitwise reproducible (fixed order).
+ * Parameter-free: depends on the
  * batch only, so it can be computed once per batch and cached over epochs.  With several
  * ranks the caller sums W over ranks before the forward call. */
 int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ, double* W,

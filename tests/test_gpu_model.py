@@ -405,3 +405,26 @@ def test_scaled_moments_equal_plain_dense_adam(n_steps):
     assert torch.allclose(la, lb, rtol=2e-5)
     assert rel(a._flat, b._flat) < tol_p
     assert rel(a._adam_m, b._adam_m) < tol_m and rel(a._adam_v, b._adam_v) < tol_m
+
+
+def test_untouched_rows_split_equals_single_launch():
+    """VFM_FLAG_ROWS_UNTOUCHED + VFM_FLAG_ROWS_TOUCHED (two launches, the first on a side stream beside the
+    forward) == one fused launch: same arithmetic per row, so bitwise equal parameters and moments."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([300, 200], 2000, seed=3)
+
+    def run(split):
+        torch.manual_seed(9)
+        m = VFM(300, 200, 12, device="cuda", rng_seed=4)
+        m.set_training_data(X, nb_train=2000)
+        m.lr, m.overlap_untouched = 0.02, split
+        plans = [m.plan(X[i:i + 100], y[i:i + 100]) for i in range(0, 2000, 100)]
+        for s in range(140):                 # crosses a moment period boundary (128)
+            loss3, _ = m.train_step(plans[s % 20])
+        torch.cuda.synchronize()
+        return m, loss3.clone()
+
+    (a, la), (b, lb) = run(True), run(False)
+    assert torch.equal(la, lb)
+    assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)

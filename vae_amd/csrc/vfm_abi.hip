@@ -244,13 +244,12 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
   if (int rc = check_problem(p)) return rc;
   if (!W || (p->B > 0 && (!x || !inv_occ))) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);
-  const int64_t n_occ = p->B * p->F;
-  if (n_occ == 0) return 0;
-  const int64_t nb = (n_occ + BLOCK - 1) / BLOCK;
-  const int grid = (int)(nb < 1024 ? nb : 1024);
-  hipLaunchKernelGGL(k_norms, dim3(grid), dim3(BLOCK), 0, st, x, (int)(p->id_bits == 64), inv_occ,
-                     n_occ, (int)p->F, p->T, W);
+  if (p->B == 0) {                       // empty shard: W = 0
+    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);
+    return after_launch("vfm_batch_norms");
+  }
+  hipLaunchKernelGGL(k_norms, dim3((unsigned)p->F), dim3(NORMS_BLOCK), 0, st, x, (int)(p->id_bits == 64), inv_occ,
+                     p->B, (int)p->F, p->T, W);
   return after_launch("vfm_batch_norms");
 }
 
@@ -339,9 +338,15 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                           void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_f32")) return rc;
-  if (!entity_params || !bias_params || !inv_occ || !scalars || !W || !partials || !m_entity ||
+  const int rows_flags = p->flags & (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED);
+  if (rows_flags == (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED))
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: VFM_FLAG_ROWS_UNTOUCHED and VFM_FLAG_ROWS_TOUCHED exclude each other");
+  if (rows_flags && (p->flags & VFM_FLAG_SPARSE_ADAM))
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: the row filters do not combine with VFM_FLAG_SPARSE_ADAM");
+  const bool untouched_only = rows_flags == VFM_FLAG_ROWS_UNTOUCHED;     // pure Adam decay: no forward state needed
+  if (!entity_params || !bias_params || !scalars || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1 ||
-      (p->B > 0 && (!sumz || !grow)))
+      (!untouched_only && (!inv_occ || !W || !partials || (p->B > 0 && (!sumz || !grow)))))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: bad argument");
   if (p->flags & VFM_FLAG_NO_PRIOR_TERMS)
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: single-rank only (gradients never leave the kernel)");
@@ -350,9 +355,11 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
+  a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
             nullptr, nullptr, nullptr, 0, nullptr};
-  if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
+  if (!untouched_only)
+    if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;

@@ -23,7 +23,8 @@ constexpr int LINK = VFM_LINK;
 template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
 int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
-  const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
+  // (the untouched-rows launch shares the chip with the forward kernel: a small grid by default)
+  const int per_cu = a.row_filter == 1 ? env_int("VFM_ADAMU_BLOCKS_PER_CU", 1) : env_int("VFM_BWD_BLOCKS_PER_CU", 8);
   int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;

@@ -63,21 +63,24 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   const int d = a.d;
   const int C = (d + VEC - 1) / VEC;
   if (STAGE != STAGE_ACC && tid < a.G) {
-    sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
+    sh_cs[tid] = a.W ? (float)(a.group_n[tid] / a.W[tid]) : 0.f;     // (W == NULL: untouched-rows launch)
     sh_hi[tid] = a.group_hi[tid];
   }
   __syncthreads();
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
 
   double fin[6] = {0, 0, 0, 0, 0, 0};
-  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr;   // uniform: fold vfm_elbo_finalize_f32 in
+  // a.row_filter (fused Adam, STAGE_FULL): 0 = every row; 1 = only the rows the batch does NOT touch (pure Adam
+  // decay, independent of this step's forward: the caller runs it concurrently with the forward kernel on
+  // another stream); 2 = only the touched rows (+ the scalars and the loss)
+  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr && a.row_filter != 1;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
   if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_lo == 0) {
     b.sums[0] = (float)b.partials[VFM_P_G];       // this rank's row sums, to be summed over ranks
     b.sums[1] = (float)b.partials[VFM_P_ALPHA];
   }
-  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T) {   // (last chunk of a chunked run)
+  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T && a.row_filter != 1) {   // (last chunk of a chunked run)
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
     const float sum_g = (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
     const float sum_a = (STAGE == STAGE_APPLY) ? b.sums[1]
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
     const bool touched = (STAGE == STAGE_APPLY) ? gc.y > 0.f : beg != end;
     const float cntf = (STAGE == STAGE_APPLY) ? gc.y : (float)(end - beg);
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
+    if (ADAM == 1 && STAGE == STAGE_FULL && a.row_filter != 0 && (a.row_filter == 1) == touched) continue;
 
     // loads that do not depend on the index chain
     Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];

@@ -15,25 +15,30 @@ __global__ void k_inv_occ(const int64_t* __restrict__ occ, float* __restrict__ i
     inv[i] = 1.0f / (float)occ[i];
 }
 
-__global__ __launch_bounds__(BLOCK) void k_norms(const void* __restrict__ x, int id64,
-                                                 const float* __restrict__ inv_occ, int64_t n_occ,
-                                                 int F, int64_t T, double* __restrict__ W) {
-  __shared__ float sh[VFM_MAX_FIELDS];
-  if (threadIdx.x < VFM_MAX_FIELDS) sh[threadIdx.x] = 0.f;
-  __syncthreads();
-  // each thread walks occurrences o = t, t + stride...; stride is a multiple of F so the
-  // field of a thread is fixed
-  const int64_t stride0 = (int64_t)gridDim.x * BLOCK;
-  const int64_t stride = stride0 / F * F;   // (threads t >= stride stay idle)
-  const int64_t t = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-  float acc = 0.f;
-  for (int64_t o = (t < stride ? t : n_occ); o < n_occ; o += stride) {
-    int64_t id = id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
-    if (id >= 0 && id < T) acc += inv_occ[id];
+// W[f] = sum_r inv_occ[x[r,f]]: one workgroup per column f, fp64, fixed summation order (thread-strided
+// partial sums, xor-shuffle tree inside each wave, waves added in order) -- bitwise reproducible, so the
+// KL scale n_g / W_g and everything downstream of it is too.  Once per batch, outside the step.
+constexpr int NORMS_BLOCK = 1024;
+__global__ __launch_bounds__(NORMS_BLOCK) void k_norms(const void* __restrict__ x, int id64,
+                                                       const float* __restrict__ inv_occ, int64_t B, int F,
+                                                       int64_t T, double* __restrict__ W) {
+  __shared__ double sh[NORMS_BLOCK / 64];
+  const int f = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t r = threadIdx.x; r < B; r += NORMS_BLOCK) {
+    const int64_t o = r * F + f;
+    const int64_t id = id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
+    if (id >= 0 && id < T) acc += (double)inv_occ[id];
   }
-  if (acc != 0.f) atomicAdd(&sh[t % F], acc);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x < F) atomicAdd(&W[threadIdx.x], (double)sh[threadIdx.x]);
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < NORMS_BLOCK / 64; ++w) t += sh[w];
+    W[f] = t;
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partials,

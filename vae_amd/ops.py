@@ -30,6 +30,8 @@ FLAG_SPARSE_ADAM = 4
 FLAG_ZPRE = 8
 FLAG_LINK_SOFTPLUS = 16
 FLAG_SCALED_MOMENTS = 32
+FLAG_ROWS_UNTOUCHED = 64
+FLAG_ROWS_TOUCHED = 128
 MOMENT_PERIOD = 128
 MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
@@ -245,11 +247,15 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
 
 def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
                        m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None,
-                       sparse=False, scaled_moments=False):
+                       sparse=False, scaled_moments=False, rows=None):
     """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
     m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
     work of elbo_finalize in the same launch.  `scaled_moments`: the buffers are in the scaled form of
-    VFM_FLAG_SCALED_MOMENTS (see include/vfm_hip.h; `moments_rescale` converts)."""
+    VFM_FLAG_SCALED_MOMENTS (see include/vfm_hip.h; `moments_rescale` converts).  `rows`: None = all
+    table rows; "untouched" = only the rows the batch does not contain (pure Adam decay -- may run
+    concurrently with the forward on another stream, `st` then only carries the problem and placeholder
+    buffers); "touched" = the complement (+ scalars, loss)."""
+    rows_flag = {None: 0, "untouched": FLAG_ROWS_UNTOUCHED, "touched": FLAG_ROWS_TOUCHED}[rows]
     if plan.occ_ptr is None:
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
@@ -259,7 +265,7 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
                              p.flags | (FLAG_SPARSE_ADAM if sparse else 0) |
-                             (FLAG_SCALED_MOMENTS if scaled_moments else 0),
+                             (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples)
 
 
