@@ -25,9 +25,24 @@ __global__ __launch_bounds__(NORMS_BLOCK) void k_norms(const void* __restrict__ 
   __shared__ double sh[NORMS_BLOCK / 64];
   const int f = blockIdx.x;
   double acc = 0.0;
-  for (int64_t r = threadIdx.x; r < B; r += NORMS_BLOCK) {
+  auto id_of = [&](int64_t r) -> int64_t {
     const int64_t o = r * F + f;
-    const int64_t id = id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
+    return id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
+  };
+  constexpr int UN = 8;                  // independent id -> 1/occ chains in flight per thread
+  int64_t r = threadIdx.x;
+  for (; r + (UN - 1) * (int64_t)NORMS_BLOCK < B; r += UN * (int64_t)NORMS_BLOCK) {
+    int64_t id[UN];
+    float v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) id[u] = id_of(r + u * (int64_t)NORMS_BLOCK);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = (id[u] >= 0 && id[u] < T) ? inv_occ[id[u]] : 0.f;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc += (double)v[u];
+  }
+  for (; r < B; r += NORMS_BLOCK) {
+    const int64_t id = id_of(r);
     if (id >= 0 && id < T) acc += (double)inv_occ[id];
   }
 #pragma unroll
