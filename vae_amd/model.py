@@ -403,7 +403,7 @@ class VFM(nn.Module):
             from .sharded import train_step_sharded
             if not adam:
                 raise ValueError("the entity-sharded step always applies Adam")
-            self._set_moment_form(False)
+            self._set_moment_form(self.scaled_moments)
             return train_step_sharded(self, plan, lr, eps=eps, out_pred=out_pred, mark=mark)
         ent, bia, scal = self._views(self._flat)
         g_ent, g_bias, g_scal = self._views(self._gflat)
@@ -448,8 +448,9 @@ class VFM(nn.Module):
                 torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
             mark("bwd_adam")
             return loss3, st.pred
-        self._set_moment_form(False)
-        if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
+        stats = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
+        self._set_moment_form(self.scaled_moments and stats)     # (the flat k_adam of the other paths: plain form)
+        if stats:
             # multi-rank: exchange the gradient's sufficient statistics (sum grow, count, A_e) -- half
             # the bytes of the gradient -- then epilogue + Adam on every rank.  The table is cut in
             # `exchange_chunks` entity ranges: the all-reduce of chunk k overlaps the statistics kernel
@@ -470,7 +471,8 @@ class VFM(nn.Module):
             for k in range(len(bounds) - 1):
                 works[k].wait()
                 ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                    self._views(self._adam_v), lr, self._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1])
+                                    self._views(self._adam_v), lr, self._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1],
+                                    scaled_moments=self._moments_scaled)
             mark("exchange_apply_adam")
             loss3.copy_(xl)
             return loss3, st.pred

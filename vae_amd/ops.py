@@ -287,7 +287,7 @@ def elbo_backward_acc(plan: BatchPlan, st: FwdState, acc, sums, e_lo=0, e_hi=0):
 
 def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bias_params, scalars,
                     inv_occ, m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, e_lo=0, e_hi=0,
-                    own_mod=1, own_rank=0, kl_ws=None, rec_index=None):
+                    own_mod=1, own_rank=0, kl_ws=None, rec_index=None, scaled_moments=False):
     """Multi-rank backward, stage 2: gradient epilogue + dense Adam from the rank-summed statistics of
     the entities [e_lo, e_hi) (the chunk that ends at T also updates the three scalars)."""
     e = st.eps if st.eps is not None else (None, None, None)
@@ -295,7 +295,9 @@ def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bia
     _lib.ops().elbo_apply_adam(acc, sums, entity_params, bias_params, scalars, inv_occ, plan.W,
                                e[0], e[1], e[2], m_views[0], v_views[0], m_views[1], v_views[1], m_views[2],
                                v_views[2], spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train,
-                               p.B_global, p.likelihood, p.flags & ~FLAG_NO_PRIOR_TERMS, p.seed & _I63, p.step,
+                               p.B_global, p.likelihood,
+                               (p.flags & ~FLAG_NO_PRIOR_TERMS) | (FLAG_SCALED_MOMENTS if scaled_moments else 0),
+                               p.seed & _I63, p.step,
                                lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi, own_mod, own_rank, kl_ws,
                                rec_index[0] if rec_index else None, rec_index[1] if rec_index else None)
 

@@ -170,7 +170,8 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     own_plan = _OwnPlan(spec, plan.W)
     ops.elbo_apply_adam(own_plan, st_own, acc, small[0:2], ent, bia, scal, model.inv_occ,
                         model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t,
-                        e_lo=0, e_hi=t_own, own_mod=N, own_rank=r, kl_ws=model._shard_klws, rec_index=rec_index)
+                        e_lo=0, e_hi=t_own, own_mod=N, own_rank=r, kl_ws=model._shard_klws, rec_index=rec_index,
+                        scaled_moments=model._moments_scaled)
     # 6. one tiny all-reduce: [sum g, alpha term, nll, KL(q(w0)) (rank 0 only), my KL share]
     _lib.ops().shard_pack(small, loss_local, model._shard_klws)
     dist.all_reduce(small[0:8], group=plan.group)
@@ -178,7 +179,8 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     if N > 1:
         ops.elbo_apply_adam(own_plan, st_own, acc, small[0:2], ent, bia, scal, model.inv_occ,
                             model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t,
-                            e_lo=spec.T, e_hi=spec.T, own_mod=N, own_rank=r, rec_index=rec_index)
+                            e_lo=spec.T, e_hi=spec.T, own_mod=N, own_rank=r, rec_index=rec_index,
+                            scaled_moments=model._moments_scaled)
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     _lib.ops().shard_loss(small, loss3)
