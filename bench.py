@@ -33,6 +33,10 @@ WORKLOADS = {
     "ml20m_d128": ([138493, 26744], 128, 100000, 16000210, "reg"),
     "ml100k_d20": ([943, 1682], 20, 80000, 80000, "reg"),
     "criteo_d256": ([31250] * 32, 256, 2048, 1 << 22, "class"),
+    # per-rank shapes of the embedding-dimension-sharded mode at cfg3 (d/N coordinates, N*B rows)
+    "ml20m_d64": ([138493, 26744], 64, 200000, 16000210, "reg"),
+    "ml20m_d32": ([138493, 26744], 32, 400000, 16000210, "reg"),
+    "ml20m_d16": ([138493, 26744], 16, 800000, 16000210, "reg"),
 }
 
 

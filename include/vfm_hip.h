@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VFM_ABI_VERSION 1
+#define VFM_ABI_VERSION 2
 #define VFM_MAX_FIELDS 64
 
 #define VFM_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported size)   */
@@ -68,6 +68,15 @@ extern "C" {
                                      inv_occ, W, loss may be NULL.                                              */
 #define VFM_FLAG_ROWS_TOUCHED 128  /* ... and the complement: the rows of the batch, the three scalars, the loss.
                                      The two calls together equal one call without either flag.                */
+#define VFM_FLAG_PARTIAL_PRED 256   /* vfm_elbo_fwd_f32 (training, n_samples == 1): stop before the likelihood --
+                                     pred[r] receives this call's share  sum_f w_f + 1/2 sum_k[..]  of the row
+                                     value over ITS coordinates only (no global bias); sumz and the KL slots are
+                                     written as usual.  The embedding-dimension-sharded multi-rank mode sums the
+                                     shares over ranks and finishes with vfm_elbo_lik_f32.                     */
+#define VFM_FLAG_NO_BIAS 512        /* this call leaves the first-order weights (bias_params) out: no sum_f w_f,
+                                     no KL of them, no gradient / Adam update for them (dimension-sharded mode:
+                                     rank 0 alone carries them; bias_params and its moments must still point to
+                                     [T,2] tables -- read, never written)                                       */
 #define VFM_FLAG_ZPRE 8           /* vfm_elbo_fwd_f32: `entity_params` holds PRECOMPUTED samples, one record
                                      (w, 0, 0, 0 | z[0..d-1]) of 4 + round4(d) floats per slot, and x holds
                                      slot numbers (entity-sharded mode: the owner of an entity samples it
@@ -126,6 +135,10 @@ typedef struct vfm_problem {
    * handles the owned entities e = own_rank + li * own_mod, li in [e_lo, e_hi) (LOCAL indices; the
    * statistics records are indexed by li).  own_mod <= 1: not sharded. */
   int32_t own_mod, own_rank;
+  /* embedding-dimension-sharded mode: the tables of this call hold the coordinates
+   * [coord_off, coord_off + d) of a wider model; only the Philox coordinate index is shifted by it
+   * (eps tables, if given, are local like the parameter tables).  Multiple of 8; 0 otherwise. */
+  int32_t coord_off, reserved0;
 } vfm_problem_t;
 
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
@@ -283,6 +296,20 @@ int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
  * pointers 16-byte aligned. */
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, void* stream);
+
+/* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
+ * both tables; the only per-step exchange is one all-reduce of B+1 floats):
+ *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED (+ coord_off; + VFM_FLAG_NO_BIAS | VFM_FLAG_NO_PRIOR_TERMS on
+ *      all ranks but one) -> pred[0..B) = this rank's share of the row values, sumz, KL slots;
+ *      vfm_elbo_finalize_f32 -> loss[2] = this rank's share of the KL term; the caller stores it in pred[B];
+ *   2. all-reduce (sum) of pred[0..B];
+ *   3. vfm_elbo_lik_f32: pred[r] <- w0 + pred[r] (the predictions), grow[r] = dloss/dpred_r, and a `partials`
+ *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = pred[B],
+ *      so finalise it with VFM_FLAG_NO_PRIOR_TERMS);
+ *   4. vfm_elbo_bwd_adam_f32 / vfm_elbo_bwd_f32 on the local coordinates with those partials (the three scalars
+ *      are replicated: every rank applies the same update). */
+int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,
+                     float* pred, float* grow, double* partials, void* stream);
 
 /* Convert Adam moment buffers (n floats each) between the plain form and the scaled form of
  * VFM_FLAG_SCALED_MOMENTS, `step` = number of Adam steps applied so far: to_scaled != 0 divides m by

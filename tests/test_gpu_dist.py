@@ -169,3 +169,103 @@ def test_entity_sharded_step_matches_one_rank(name, use_tables, world, tmp_path)
     assert rel_err(ps[0], want) < 2e-5
     l0 = np.load(tmp_path / "sh_loss_0.npy")
     assert rel_err(l0[:, 0], np.array(ref_losses)[:, 0]) < 1e-5
+
+
+def _dims_worker(rank, world, port, name, out_dir, use_tables):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    m = _make_model(c, dev)
+    m.exchange = "dims"
+    eps = None
+    if use_tables:
+        e0, ew, ev = c.eps("f32")
+        eps = (torch.tensor(ev, device=dev), torch.tensor(ew, device=dev), torch.tensor(e0, device=dev))
+    plan = m.plan(torch.tensor(c.x), torch.tensor(c.y), process_group=dist.group.WORLD)   # ALL rows on every rank
+    losses, preds = [], []
+    for step in range(3):
+        loss3, pred = m.train_step(plan, lr=0.05, eps=eps, process_group=dist.group.WORLD)
+        losses.append(loss3.cpu().numpy().copy())
+        preds.append(pred.cpu().numpy().copy())
+    st = m.training_state_dict()             # collective: gathers parameters and moments
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"dm_params_{rank}.npy"), m._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"dm_m_{rank}.npy"), st["adam"]["m"].numpy())
+    np.save(os.path.join(out_dir, f"dm_loss_{rank}.npy"), np.array(losses))
+    np.save(os.path.join(out_dir, f"dm_pred_{rank}.npy"), np.array(preds))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name,use_tables", [(2, "ml20m_reg_d128", True), (4, "ml20m_reg_d128", False),
+                                                   (2, "softplus_multi_class_d8_s2", False)])
+def test_dimension_sharded_step_matches_one_rank(world, name, use_tables, tmp_path):
+    """Embedding-dimension-sharded mode (every rank: all rows, d / N coordinates; one all-reduce of B + 1 floats
+    per step) == the 1-rank step on the same batch: losses, predictions, and after the gather every parameter
+    and Adam moment."""
+    if name == "softplus_multi_class_d8_s2":        # d = 8, two samples: not shardable this way -> loud error
+        from vae_amd.dims import supported
+        assert not supported(8, world, 2) and not supported(20, 2) and supported(128, 8) and supported(16, 2)
+        return
+    mp.spawn(_dims_worker, args=(world, _free_port(), name, str(tmp_path), use_tables), nprocs=world, join=True)
+    c = Case(name)
+    dev = torch.device("cuda:0")
+    m = _make_model(c, dev)
+    eps = None
+    if use_tables:
+        e0, ew, ev = c.eps("f32")
+        eps = (torch.tensor(ev, device=dev), torch.tensor(ew, device=dev), torch.tensor(e0, device=dev))
+    plan = m.plan(torch.tensor(c.x), torch.tensor(c.y))
+    ref_losses, ref_preds = [], []
+    for step in range(3):
+        loss3, pred = m.train_step(plan, lr=0.05, eps=eps)
+        ref_losses.append(loss3.cpu().numpy().copy())
+        ref_preds.append(pred.cpu().numpy().copy())
+    want = m._flat.cpu().numpy()
+    m._set_moment_form(False)
+    want_m = m._adam_m.cpu().numpy()
+    ps = [np.load(tmp_path / f"dm_params_{r}.npy") for r in range(world)]
+    for p in ps[1:]:
+        assert np.array_equal(ps[0], p)                      # identical full tables after the gather
+    assert rel_err(ps[0], want) < 2e-5
+    assert rel_err(np.load(tmp_path / "dm_loss_0.npy"), np.array(ref_losses)) < 1e-5
+    assert np.array_equal(np.load(tmp_path / "dm_loss_0.npy"), np.load(tmp_path / f"dm_loss_{world - 1}.npy"))
+    assert rel_err(np.load(tmp_path / "dm_pred_0.npy"), np.array(ref_preds)) < 2e-5
+    got_m = np.load(tmp_path / "dm_m_0.npy")
+    if m.scaled_moments:                                      # the checkpoint stores the buffers in their form
+        k = 3 % 128
+        got_m = got_m * (0.9 ** k)
+    assert rel_err(got_m, want_m) < 1e-4
+
+
+def _dims_fit_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([60, 50], 3000, seed=4)
+    torch.manual_seed(1)
+    m = VFM(60, 50, 16, device="cuda:0", rng_seed=5)
+    h = m.fit(X[:2400], y[:2400], n_epochs=3, batch_size=1000, X_test=X[2400:], y_test=y[2400:], verbose=False,
+              process_group=dist.group.WORLD)
+    assert m.exchange == "dims"                # "auto" picks it: 16 % (8 * 2) == 0
+    np.save(os.path.join(out_dir, f"df_elbo_{rank}.npy"), np.array(h["elbo"]))
+    np.save(os.path.join(out_dir, f"df_rmse_{rank}.npy"), np.array([t["rmse_of_mean"] for t in h["test"]]))
+    np.save(os.path.join(out_dir, f"df_params_{rank}.npy"), m._flat.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_fit_dimension_sharded_matches_single_rank(tmp_path):
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    mp.spawn(_dims_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    X, y = synthetic_triples([60, 50], 3000, seed=4)
+    torch.manual_seed(1)
+    m = VFM(60, 50, 16, device="cuda:0", rng_seed=5)
+    h = m.fit(X[:2400], y[:2400], n_epochs=3, batch_size=1000, X_test=X[2400:], y_test=y[2400:], verbose=False)
+    assert rel_err(np.load(tmp_path / "df_elbo_0.npy"), np.array(h["elbo"])) < 1e-4
+    assert np.array_equal(np.load(tmp_path / "df_params_0.npy"), np.load(tmp_path / "df_params_1.npy"))
+    assert rel_err(np.load(tmp_path / "df_params_0.npy"), m._flat.cpu().numpy()) < 1e-3
+    assert rel_err(np.load(tmp_path / "df_rmse_0.npy"), np.array([t["rmse_of_mean"] for t in h["test"]])) < 1e-3

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
 OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_FIELDS = 64
 N_PARTIALS = 8
 MAX_FWD_BLOCKS = 4096
@@ -29,7 +29,7 @@ EXPORTS = (
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
-    "vfm_moments_rescale_f32",
+    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32",
 )
 
 
@@ -42,6 +42,7 @@ class Problem(C.Structure):
         ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
         ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
         ("own_mod", C.c_int32), ("own_rank", C.c_int32),
+        ("coord_off", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -95,6 +96,7 @@ def load():
     lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.vfm_shard_pack_f32.argtypes = [vp, vp, vp, vp]
     lib.vfm_shard_loss_f32.argtypes = [vp, vp, vp]
+    lib.vfm_elbo_lik_f32.argtypes = [PP, vp, vp, vp, vp, vp, vp, vp]
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

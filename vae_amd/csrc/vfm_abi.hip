@@ -90,6 +90,10 @@ int check_problem(const vfm_problem_t* p) {
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
   if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
   if (p->own_mod > 1 && (p->own_rank < 0 || p->own_rank >= p->own_mod)) return fail(VFM_E_INVALID, "bad ownership (own_rank, own_mod)");
+  if (p->coord_off < 0 || (p->coord_off & 7) != 0) return fail(VFM_E_INVALID, "coord_off must be a non-negative multiple of 8");
+  if (p->coord_off != 0 && (p->d & 3) != 0) return fail(VFM_E_INVALID, "coord_off needs d % 4 == 0");
+  if ((p->flags & VFM_FLAG_PARTIAL_PRED) && (p->n_samples != 1 || (p->flags & VFM_FLAG_ZPRE)))
+    return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_PARTIAL_PRED needs n_samples == 1 and no VFM_FLAG_ZPRE");
   Shape s;
   if (!pick_shape(p->d, &s)) return fail(VFM_E_UNSUPPORTED, "embedding size d not supported (d%4==0: d<=1024, else d<=256)");
   return 0;
@@ -133,6 +137,7 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   a.ll_scale = (float)a.ll_scale_d;
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
   a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32);
+  a.key.chunk_off = (uint32_t)(p->coord_off / 4);
   a.x = x; a.y = y; a.entity = entity; a.bias = bias; a.inv_occ = inv_occ; a.scalars = scalars;
   a.W = W; a.eps_entity = ee; a.eps_bias = eb; a.eps_global = eg;
   for (int g = 0; g < p->F; ++g) { a.group_hi[g] = p->group_hi[g]; a.group_n[g] = p->group_n[g]; }
@@ -272,6 +277,8 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (train && (((!inv_occ || !W) && !zpre) || !sumz || !grow))
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: y given, so inv_occ, W, sumz and grow are required");
   if (zpre && !train) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_ZPRE needs y (training forward)");
+  if ((p->flags & VFM_FLAG_PARTIAL_PRED) && !train)
+    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_PARTIAL_PRED needs y (training forward)");
   if (!train && (sumz || grow)) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: sumz / grow need y");
   int eps;
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
@@ -490,6 +497,21 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
   hipLaunchKernelGGL(k_adam, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
                      beta2, eps, step_size, bc2_sqrt);
   return after_launch("vfm_adam_f32");
+}
+
+int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,
+                     float* pred, float* grow, double* partials, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_elbo_lik_f32")) return rc;
+  if (!scalars || !pred || !partials || (p->B > 0 && (!y || !grow)))
+    return fail(VFM_E_INVALID, "vfm_elbo_lik_f32: NULL pointer");
+  KArgs a = make_args(p, nullptr, y, nullptr, nullptr, nullptr, scalars, nullptr, nullptr, nullptr, eps_global);
+  FwdOut o{pred, partials, nullptr, grow};
+  int64_t nb = (p->B + BLOCK - 1) / BLOCK;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_lik, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, a, o);
+  return after_launch("vfm_elbo_lik_f32");
 }
 
 int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float beta2, int64_t step, int32_t to_scaled,

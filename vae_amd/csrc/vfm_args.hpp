@@ -22,6 +22,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct RngKey {
   uint32_t seed_lo, seed_hi, step_lo, step_hi;   // step_hi carries the sample index in bits 16.. (S > 1)
+  uint32_t chunk_off;   // global index of local chunk 0 (4 coordinates each; dimension-sharded mode), even
 };
 
 // Kernel arguments (by value)

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   }
   __syncthreads();
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
+  const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);     // (dimension-sharded mode: one rank carries bias_params)
 
   double fin[6] = {0, 0, 0, 0, 0, 0};
   // a.row_filter (fused Adam, STAGE_FULL): 0 = every row; 1 = only the rows the batch does NOT touch (pure Adam
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
           st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, zc);
         }
       }
-      if (lig == 0) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
+      if (lig == 0 && has_bias) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
       continue;
     }
 
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         }
       }
     }
-    if (lig == 0) {
+    if (lig == 0 && has_bias) {
       float g0 = 0.f, g1 = 0.f;
       if (touched) {
         if constexpr (EPS == EPS_TABLE)

@@ -152,3 +152,22 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV * 4] 
     for (int i = 0; i < NV; ++i) v[i] = sh[i * 4] + sh[i * 4 + 1] + sh[i * 4 + 2] + sh[i * 4 + 3];
   }
 }
+
+// log-likelihood of one (row, sample) and its derivative wrt the prediction
+__device__ __forceinline__ void lik_terms(int lik, float y, float pred, float aabs, float half_log_a, float& ll,
+                                          float& dll, float& aterm) {
+  if (lik == VFM_LIK_NORMAL) {
+    const float diff = y - pred;
+    ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
+    dll = aabs * diff;
+    aterm = 0.5f * diff * diff - 0.5f / aabs;
+  } else {
+    // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
+    const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
+    ll = y * pred - (fmaxf(pred, 0.f) + LN2 * __builtin_amdgcn_logf(1.0f + e1));
+    const float inv = __builtin_amdgcn_rcpf(1.0f + e1);
+    dll = y - ((pred >= 0.f) ? inv : e1 * inv);
+    aterm = 0.f;
+  }
+}
+

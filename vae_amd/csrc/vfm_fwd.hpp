@@ -155,8 +155,8 @@ __device__ __forceinline__ void bias_math(const float2 th, float epw, bool owner
 
 // arithmetic of one occurrence (generic path): every lane draws its own chunk's eps
 template <int LPE, int CPL, int VEC, int EPS, int MODE, int LINK>
-__device__ __forceinline__ void consume_field(const RngKey& key, const FieldRegs<CPL, VEC, EPS>& R, int lig,
-                                              int C, float cs, RowAcc<CPL, VEC>& acc) {
+__device__ __forceinline__ void consume_field(const RngKey& key, bool has_bias, const FieldRegs<CPL, VEC, EPS>& R,
+                                              int lig, int C, float cs, RowAcc<CPL, VEC>& acc) {
   float klv = 0.f;
   float epw = 0.f;
 #pragma unroll
@@ -179,7 +179,7 @@ __device__ __forceinline__ void consume_field(const RngKey& key, const FieldRegs
     chunk_math<VEC, MODE, LINK>(R.mu[i], R.s[i], ep, valid, acc.sz[i], acc.zz, klv);
   }
   if constexpr (EPS == EPS_TABLE) epw = R.epw;
-  bias_math<MODE, LINK>(R.th, epw, lig == 0, acc.part, klv);
+  bias_math<MODE, LINK>(R.th, epw, lig == 0 && has_bias, acc.part, klv);
   if constexpr (MODE == MODE_TRAIN) acc.kl = fmaf(cs * R.io, klv, acc.kl);
 }
 
@@ -189,7 +189,7 @@ __device__ __forceinline__ void consume_field(const RngKey& key, const FieldRegs
 // [1,0,3,2]).  Lane 0 / lane 1 own the first-order weights of field 0 / field 1 (their calls have
 // p == 0 and carry the bias normal).
 template <int LPE, int CPL, int EPS, int MODE, int LINK>
-__device__ __forceinline__ void consume_row2(const RngKey& key, const FieldRegs<CPL, 4, EPS>& R0,
+__device__ __forceinline__ void consume_row2(const RngKey& key, bool has_bias, const FieldRegs<CPL, 4, EPS>& R0,
                                              const FieldRegs<CPL, 4, EPS>& R1, int lig, int C, float cs0,
                                              float cs1, RowAcc<CPL, 4>& acc) {
   static_assert(LPE >= 2, "lane pairing needs at least two lanes per row");
@@ -210,7 +210,7 @@ __device__ __forceinline__ void consume_row2(const RngKey& key, const FieldRegs<
     } else {
       float n[8], nb;
       // pair index of chunk j is j >> 1 (LPE is even, so both lanes of a pair agree on it)
-      normal8b(key, odd ? R1.e : R0.e, (uint32_t)j >> 1, n, nb);
+      normal8b(key, odd ? R1.e : R0.e, ((uint32_t)j + key.chunk_off) >> 1, n, nb);
       if (i == 0) epw = nb;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -225,28 +225,10 @@ __device__ __forceinline__ void consume_row2(const RngKey& key, const FieldRegs<
   }
   if constexpr (EPS == EPS_TABLE) epw = odd ? R1.epw : R0.epw;
   float klb = 0.f;
-  bias_math<MODE, LINK>(odd ? R1.th : R0.th, epw, lig < 2, acc.part, klb);
+  bias_math<MODE, LINK>(odd ? R1.th : R0.th, epw, lig < 2 && has_bias, acc.part, klb);
   if constexpr (MODE == MODE_TRAIN) {
     const float c0 = cs0 * R0.io, c1 = cs1 * R1.io;
     acc.kl = fmaf(c0, kl0, fmaf(c1, kl1, fmaf(odd ? c1 : c0, klb, acc.kl)));
-  }
-}
-
-// log-likelihood of one (row, sample) and its derivative wrt the prediction
-__device__ __forceinline__ void lik_terms(int lik, float y, float pred, float aabs, float half_log_a, float& ll,
-                                          float& dll, float& aterm) {
-  if (lik == VFM_LIK_NORMAL) {
-    const float diff = y - pred;
-    ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
-    dll = aabs * diff;
-    aterm = 0.5f * diff * diff - 0.5f / aabs;
-  } else {
-    // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
-    const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
-    ll = y * pred - (fmaxf(pred, 0.f) + LN2 * __builtin_amdgcn_logf(1.0f + e1));
-    const float inv = __builtin_amdgcn_rcpf(1.0f + e1);
-    dll = y - ((pred >= 0.f) ? inv : e1 * inv);
-    aterm = 0.f;
   }
 }
 
@@ -278,6 +260,10 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
       const int j = lig + i * LPE;
       if (j < C) st_chunk<VEC>(srow + (size_t)j * VEC, acc.sz[i]);
     }
+  }
+  if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED)) {   // uniform: dimension-sharded mode, the row value
+    if (lig == 0) out.pred[r] = val;                               // over this rank's coordinates; no likelihood
+    return;
   }
   if (a.S > 1) {                      // uniform: one launch per sample, see the header comment
     if (lig == 0) {
@@ -341,6 +327,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = link_f<LINK>(alpha);
   const RngKey key = key_of_sample(a.key, a.sample);   // this launch's sample (a.key: sample 0)
+  const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
   if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZPRE) {     // (ZPRE: the scalars are replicated, w0 is local)
@@ -415,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
         }
         // stage 2: arithmetic of row r from A while B's loads are in flight
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, has_bias, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
         finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yA, acc, tot);
         r = rn;
@@ -436,7 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           if constexpr (MODE == MODE_TRAIN) yA = a.y[rc];
         }
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, has_bias, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
         finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yB, acc, tot);
         r = rn;
@@ -486,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, Bq);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, A, lig, C, cs_of(A.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, has_bias, A, lig, C, cs_of(A.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];
@@ -506,7 +493,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, A);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, Bq, lig, C, cs_of(Bq.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, has_bias, Bq, lig, C, cs_of(Bq.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];

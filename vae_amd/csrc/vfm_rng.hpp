@@ -66,7 +66,8 @@ template <int VEC>
 __device__ __forceinline__ void eps_of_chunk(const RngKey& k, uint32_t e, int j, float (&ep)[VEC], float& nb) {
   float n[8];
   if constexpr (VEC == 4) {
-    normal8b(k, e, (uint32_t)j >> 1, n, nb);
+    const uint32_t jg = (uint32_t)j + k.chunk_off;      // global chunk (chunk_off is even: same parity)
+    normal8b(k, e, jg >> 1, n, nb);
     const bool odd = j & 1;
 #pragma unroll
     for (int t = 0; t < 4; ++t) ep[t] = odd ? n[4 + t] : n[t];

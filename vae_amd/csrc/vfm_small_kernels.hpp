@@ -64,6 +64,48 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partial
   reduce_slots_and_loss(partials, scalars, ll_scale, flags, loss, sh, tot);
 }
 
+// Dimension-sharded mode, after the all-reduce of the row values: pred[r] <- w0 + pred[r], the likelihood
+// terms and grow[r] = dloss/dpred_r, per-workgroup sums into `partials` slots laid out like the forward's
+// (the KL slot of workgroup 0 carries pred[B] = the KL term summed over ranks; NaN there -- ids out of range on
+// some rank -- makes the loss NaN).  Same arithmetic per row as finish_row in vfm_fwd.hpp.
+__global__ __launch_bounds__(BLOCK) void k_lik(const KArgs a, const FwdOut out) {
+  __shared__ float sh_red[6 * 4];
+  const bool softplus = (a.flags & VFM_FLAG_LINK_SOFTPLUS) != 0;
+  const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
+  const float aabs = softplus ? link_f<LINK_SOFTPLUS>(alpha) : link_f<LINK_ABS>(alpha);
+  float e0;
+  if (a.eps_global) {
+    e0 = a.eps_global[0];
+  } else {
+    float n[8], nb;
+    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+    e0 = n[0];
+  }
+  const float w0 = fmaf(softplus ? link_f<LINK_SOFTPLUS>(s0) : link_f<LINK_ABS>(s0), e0, m0);
+  const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
+  float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = blockIdx.x * (int64_t)BLOCK + threadIdx.x; r < a.B; r += (int64_t)gridDim.x * BLOCK) {
+    const float pred = w0 + out.pred[r];
+    const float y = a.y[r];
+    float ll, dll, at;
+    lik_terms(a.lik, y, pred, aabs, half_log_a, ll, dll, at);
+    const float g = -a.ll_scale * dll;
+    out.pred[r] = pred;
+    out.grow[r] = g;
+    tot[0] += ll; tot[2] += g; tot[3] += at;
+  }
+  block_sum<6>(tot, sh_red);
+  if (threadIdx.x == 0) {
+    double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    if (blockIdx.x == 0) {
+      slot[VFM_P_KL] = (double)out.pred[a.B];        // KL term summed over ranks (travels behind the row values)
+      out.partials[7] = (double)gridDim.x;
+    }
+  }
+}
+
 // ws[0] <- sum of ws[1 .. (int)ws[0]]  (per-block partial sums written by a preceding kernel)
 __global__ __launch_bounds__(BLOCK) void k_sum_slots(double* __restrict__ ws) {
   __shared__ double sh[BLOCK / 64];

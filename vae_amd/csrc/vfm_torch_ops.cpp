@@ -33,7 +33,7 @@ float* fptr_mut(const optional<Tensor>& t, const char* name) { return const_cast
 vfm_problem_t problem(const Tensor& x_like, int64_t B, int64_t B_global, int64_t T, int64_t F, int64_t d,
                       int64_t nb_train, int64_t likelihood, int64_t id_bits, int64_t flags,
                       at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step,
-                      int64_t n_samples = 1) {
+                      int64_t n_samples = 1, int64_t coord_off = 0) {
   TORCH_CHECK(F >= 1 && F <= VFM_MAX_FIELDS, "F out of range");
   TORCH_CHECK(n_samples >= 1 && n_samples <= 64, "n_samples out of range [1,64]");
   TORCH_CHECK((int64_t)group_hi.size() == F && (int64_t)group_n.size() == F, "group_hi / group_n need F entries");
@@ -43,6 +43,7 @@ vfm_problem_t problem(const Tensor& x_like, int64_t B, int64_t B_global, int64_t
   p.n_samples = (int32_t)n_samples; p.flags = (int32_t)flags;
   for (int64_t g = 0; g < F; ++g) { p.group_hi[g] = group_hi[g]; p.group_n[g] = group_n[g]; }
   p.seed = (uint64_t)seed; p.step = (uint64_t)step;
+  p.coord_off = (int32_t)coord_off;
   return p;
 }
 
@@ -63,7 +64,7 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
               const optional<Tensor>& eps_global, Tensor pred, Tensor partials,
               const optional<Tensor>& sumz, const optional<Tensor>& grow, at::IntArrayRef group_hi,
               at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
-              int64_t flags, int64_t seed, int64_t step, int64_t n_samples) {
+              int64_t flags, int64_t seed, int64_t step, int64_t n_samples, int64_t coord_off) {
   const Ids id = ids_of(x);
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   dev_tensor(scalars, at::kFloat, "scalars"); dev_tensor(pred, at::kFloat, "pred");
@@ -80,7 +81,7 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
                 eps_global->numel() >= n_samples, "eps tables too small for n_samples");
   c10::hip::HIPGuard guard(x.get_device());
   vfm_problem_t p = problem(x, id.B, B_global, T, id.F, d, nb_train, likelihood, id.id_bits, flags, group_hi,
-                            group_n, seed, step, n_samples);
+                            group_n, seed, step, n_samples, coord_off);
   const double* Wp = (W.has_value() && W->defined()) ? dev_tensor(*W, at::kDouble, "W").data_ptr<double>() : nullptr;
   check(vfm_elbo_fwd_f32(&p, id.ptr, fptr(y, "y"), entity.data_ptr<float>(), bias.data_ptr<float>(),
                          fptr(inv_occ, "inv_occ"), scalars.data_ptr<float>(), Wp, fptr(eps_entity, "eps_entity"),
@@ -134,7 +135,7 @@ BwdCommon bwd_common(at::TensorList index, const Tensor& entity, const Tensor& b
                      int64_t B, int64_t F, int64_t B_global, int64_t nb_train, int64_t likelihood, int64_t flags,
                      at::IntArrayRef group_hi, at::ArrayRef<double> group_n, int64_t seed, int64_t step,
                      int64_t n_samples, const Tensor& sumz, const optional<Tensor>& eps_entity,
-                     const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global) {
+                     const optional<Tensor>& eps_bias, const optional<Tensor>& eps_global, int64_t coord_off = 0) {
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
   TORCH_CHECK(n_samples >= 1 && sumz.numel() >= n_samples * B * d, "sumz too small for n_samples");
@@ -143,7 +144,7 @@ BwdCommon bwd_common(at::TensorList index, const Tensor& entity, const Tensor& b
                 eps_bias->numel() >= n_samples * T && eps_global.has_value() && eps_global->defined() &&
                 eps_global->numel() >= n_samples, "eps tables too small for n_samples");
   return {problem(entity, B, B_global, T, F, d, nb_train, likelihood, 64, flags, group_hi, group_n, seed, step,
-                  n_samples),
+                  n_samples, coord_off),
           index_of(index, T, B, F, d, n_samples)};
 }
 
@@ -153,10 +154,10 @@ void elbo_bwd(at::TensorList index, const Tensor& entity, const Tensor& bias,
               const Tensor& grow, const Tensor& partials, const Tensor& grad_out, Tensor g_entity, Tensor g_bias,
               Tensor g_scalars, int64_t F, at::IntArrayRef group_hi, at::ArrayRef<double> group_n,
               int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed, int64_t step,
-              int64_t n_samples) {
+              int64_t n_samples, int64_t coord_off) {
   const int64_t B = grow.numel();
   BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
-                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global);
+                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global, coord_off);
   TORCH_CHECK(g_entity.sizes() == entity.sizes() && g_bias.sizes() == bias.sizes() && g_scalars.numel() >= 3,
               "gradient shapes");
   c10::hip::HIPGuard guard(entity.get_device());
@@ -182,10 +183,11 @@ void elbo_bwd_adam(at::TensorList index, Tensor entity, Tensor bias, Tensor scal
                    Tensor v_bias, Tensor m_scalars, Tensor v_scalars, int64_t F, at::IntArrayRef group_hi,
                    at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
                    int64_t flags, int64_t seed, int64_t step, double lr, double beta1, double beta2,
-                   double eps_adam, int64_t adam_step, const optional<Tensor>& loss, int64_t n_samples) {
+                   double eps_adam, int64_t adam_step, const optional<Tensor>& loss, int64_t n_samples,
+                   int64_t coord_off) {
   const int64_t B = grow.numel();
   BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
-                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global);
+                           group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global, coord_off);
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel() && m_scalars.numel() >= 3 &&
               v_scalars.numel() >= 3, "Adam moment shapes");
@@ -351,6 +353,24 @@ void adam(Tensor p, const Tensor& g, Tensor m, Tensor v, double lr, double beta1
         "vfm_adam_f32");
 }
 
+void elbo_lik(const Tensor& y, const Tensor& scalars, const optional<Tensor>& eps_global, Tensor pred, Tensor grow,
+              Tensor partials, int64_t nb_train, int64_t B_global, int64_t likelihood, int64_t flags, int64_t seed,
+              int64_t step) {
+  dev_tensor(y, at::kFloat, "y"); dev_tensor(scalars, at::kFloat, "scalars"); dev_tensor(pred, at::kFloat, "pred");
+  dev_tensor(grow, at::kFloat, "grow"); dev_tensor(partials, at::kDouble, "partials");
+  const int64_t B = y.numel();
+  TORCH_CHECK(pred.numel() >= B + 1 && grow.numel() >= B && partials.numel() >= VFM_PARTIALS_LEN && scalars.numel() >= 3,
+              "elbo_lik sizes (pred holds B row values + the KL term)");
+  c10::hip::HIPGuard guard(y.get_device());
+  vfm_problem_t p{};
+  p.B = B; p.B_global = B_global; p.T = 1; p.nb_train = nb_train; p.F = 1; p.d = 4; p.id_bits = 64;
+  p.likelihood = (int32_t)likelihood; p.n_samples = 1; p.flags = (int32_t)flags; p.group_hi[0] = 1; p.group_n[0] = 1;
+  p.seed = (uint64_t)seed; p.step = (uint64_t)step;
+  check(vfm_elbo_lik_f32(&p, y.data_ptr<float>(), scalars.data_ptr<float>(), fptr(eps_global, "eps_global"),
+                         pred.data_ptr<float>(), grow.data_ptr<float>(), partials.data_ptr<double>(), stream_of(y)),
+        "vfm_elbo_lik_f32");
+}
+
 void moments_rescale(Tensor m, Tensor v, double beta1, double beta2, int64_t step, bool to_scaled) {
   dev_tensor(m, at::kFloat, "m"); dev_tensor(v, at::kFloat, "v");
   TORCH_CHECK(m.numel() == v.numel(), "moment sizes");
@@ -369,7 +389,7 @@ TORCH_LIBRARY(vfm_hip, m) {
   m.def("elbo_fwd(Tensor x, Tensor? y, Tensor entity_params, Tensor bias_params, Tensor? inv_occ, Tensor scalars, "
         "Tensor? W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor(a!) pred, Tensor(b!) partials, "
         "Tensor(c!)? sumz, Tensor(d!)? grow, int[] group_hi, float[] group_n, int nb_train, int B_global, "
-        "int likelihood, int flags, int seed, int step, int n_samples=1) -> ()", &elbo_fwd);
+        "int likelihood, int flags, int seed, int step, int n_samples=1, int coord_off=0) -> ()", &elbo_fwd);
   m.def("elbo_finalize(Tensor(a!) partials, Tensor scalars, Tensor(b!) loss, int nb_train, int B_global, int flags, "
         "int n_samples=1) -> ()",
         &elbo_finalize);
@@ -377,14 +397,15 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor scalars, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor sumz, Tensor grow, "
         "Tensor partials, Tensor grad_out, Tensor(a!) g_entity, Tensor(b!) g_bias, Tensor(c!) g_scalars, int F, "
         "int[] group_hi, float[] group_n, int nb_train, int B_global, int likelihood, int flags, int seed, int step, "
-        "int n_samples=1) -> ()",
+        "int n_samples=1, int coord_off=0) -> ()",
         &elbo_bwd);
   m.def("elbo_bwd_adam(Tensor[] index, Tensor(a!) entity_params, Tensor(b!) bias_params, "
         "Tensor(c!) scalars, Tensor inv_occ, Tensor W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, "
         "Tensor sumz, Tensor grow, Tensor partials, Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, "
         "Tensor(g!) v_bias, Tensor(h!) m_scalars, Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, "
         "int nb_train, int B_global, int likelihood, int flags, int seed, int step, float lr, float beta1, "
-        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss, int n_samples=1) -> ()", &elbo_bwd_adam);
+        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss, int n_samples=1, int coord_off=0) -> ()",
+        &elbo_bwd_adam);
   m.def("elbo_bwd_acc(Tensor[] index, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
         "Tensor(c!) sums, int T, int F, int d, int e_lo, int e_hi) -> ()", &elbo_bwd_acc);
   m.def("elbo_apply_adam(Tensor acc, Tensor sums, Tensor(a!) entity_params, Tensor(b!) bias_params, "
@@ -402,6 +423,8 @@ TORCH_LIBRARY(vfm_hip, m) {
   m.def("records_add(Tensor(a!) dst, Tensor idx, Tensor src, int d, bool atomic) -> ()", &records_add);
   m.def("shard_pack(Tensor(a!) small, Tensor loss_local, Tensor kl_ws) -> ()", &shard_pack);
   m.def("shard_loss(Tensor small, Tensor(a!) loss3) -> ()", &shard_loss);
+  m.def("elbo_lik(Tensor y, Tensor scalars, Tensor? eps_global, Tensor(a!) pred, Tensor(b!) grow, Tensor(c!) partials, "
+        "int nb_train, int B_global, int likelihood, int flags, int seed, int step) -> ()", &elbo_lik);
   m.def("moments_rescale(Tensor(a!) m, Tensor(b!) v, float beta1, float beta2, int step, bool to_scaled) -> ()",
         &moments_rescale);
   m.def("adam(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "

@@ -107,7 +107,10 @@ class VFM(nn.Module):
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
         # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
-        # "auto" picks it unless the whole statistics table is tiny (< 4 MB: one small all-reduce wins).
+        # "dims" = the embedding dimension cut over the ranks (vae_amd/dims.py): every rank sees all rows, holds
+        # d / N coordinates, ONE all-reduce of B + 1 floats per step and Adam traffic / N.
+        # "auto": "dims" when d % (8 N) == 0, else "sharded" unless the whole statistics table is tiny
+        # (< 4 MB: one small all-reduce wins); "grads" with n_samples > 1.
         self.exchange = "auto"
         self.exchange_chunks = 4
         self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
@@ -200,6 +203,8 @@ class VFM(nn.Module):
     def training_state_dict(self):
         """Everything needed to resume training bit-for-bit: parameters (state_dict), Adam moments and
         step count, the Philox step counter, the epoch-averaged posterior means of save_weights()."""
+        if getattr(self, "_stale_group", None) is not None:
+            self.sync_params(self._stale_group)       # (collective: every rank calls this together)
         opt = None
         if self._adam_m is not None:
             opt = {"m": self._adam_m.detach().cpu().clone(), "v": self._adam_v.detach().cpu().clone(),
@@ -221,6 +226,8 @@ class VFM(nn.Module):
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
+        if getattr(self, "_dims", None) is not None:
+            self._dims.scatter(self)
         if state.get("snapshots") is not None:
             self._n_saved = int(state["snapshots"]["n"])
             self._mean_flat = state["snapshots"]["mean"].to(self.device).clone()
@@ -257,11 +264,11 @@ class VFM(nn.Module):
             y = torch.as_tensor(y).to(self.device)
             if self.inv_occ is None:
                 raise RuntimeError("call set_training_data() before building training plans")
-        if process_group is not None and self.n_samples > 1 and y is not None:
-            self.exchange = "grads"      # the statistics / sharded exchanges carry one sample
-        if process_group is not None and self.exchange == "auto" and y is not None:
-            table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
-            self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
+        if process_group is not None and y is not None:
+            self._resolve_exchange(process_group)
+        if process_group is not None and self.exchange == "dims" and y is not None:
+            # embedding-dimension-sharded: every rank plans ALL rows of the batch (vae_amd/dims.py)
+            return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=x.shape[0], build_index=build_index)
         if process_group is not None and self.exchange == "sharded" and y is not None:
             from .sharded import ShardedPlan
             return ShardedPlan(self.spec(), x, y, self.inv_occ, B_global if B_global is not None else x.shape[0],
@@ -269,6 +276,19 @@ class VFM(nn.Module):
                                torch.distributed.get_world_size(process_group))
         return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
                              build_index=build_index and y is not None, process_group=process_group)
+
+    def _resolve_exchange(self, process_group):
+        """exchange == "auto" -> the pattern for this model / world size (see __init__)."""
+        if self.n_samples > 1:
+            self.exchange = "grads"      # the statistics / sharded / dims exchanges carry one sample
+        if self.exchange == "auto":
+            from .dims import supported
+            table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
+            if supported(self.d, torch.distributed.get_world_size(process_group), self.n_samples):
+                self.exchange = "dims"       # one all-reduce of B + 1 floats per step; Adam traffic / N
+            else:
+                self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
+        return self.exchange
 
     # ------------------------------------------------------------------ forward surfaces
     def _scalars(self):
@@ -312,8 +332,21 @@ class VFM(nn.Module):
         st = ops.elbo_forward(_single_sample(plan), ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
         return st.pred
 
+    def _dims_state(self, group):
+        from .dims import DimsState
+        if getattr(self, "_dims", None) is None:
+            self._ensure_opt_state()
+            self._dims = DimsState(self, group)
+        return self._dims
+
     def sync_params(self, process_group):
-        """Entity-sharded mode: refresh the parameter rows owned by the other ranks (all-gather)."""
+        """Entity-sharded mode: refresh the parameter rows owned by the other ranks (all-gather).
+        Dimension-sharded mode: assemble the full tables (and Adam moments) from the ranks' slices."""
+        if self.exchange == "dims":
+            if getattr(self, "_dims", None) is not None:
+                self._dims.gather(self)
+            self._stale_group = None
+            return
         from .sharded import sync_params
         sync_params(self, process_group, torch.distributed.get_rank(process_group),
                     torch.distributed.get_world_size(process_group))
@@ -399,6 +432,11 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
+        if process_group is not None and self.exchange == "dims":
+            from .dims import train_step_dims
+            if not adam or out_pred is not None:
+                raise ValueError("the dimension-sharded step always applies Adam and owns its prediction buffer")
+            return train_step_dims(self, plan, lr, process_group, eps=eps, mark=mark)
         if process_group is not None and self.exchange == "sharded" and self.n_samples == 1:
             from .sharded import train_step_sharded
             if not adam:
@@ -514,9 +552,13 @@ class VFM(nn.Module):
         if sort_within_batch:
             Xd, yd = sort_rows_within_batches(Xd, yd, batch_size)
         plans, spans = [], []
+        dims = world > 1 and self._resolve_exchange(process_group) == "dims"
         for lo in range(0, nb_train, batch_size):
             hi = min(lo + batch_size, nb_train)
-            a, b = shard_rows(lo, hi, rank, world)
+            if dims:
+                a, b = lo, hi                 # every rank handles all rows, d / N coordinates (vae_amd/dims.py)
+            else:
+                a, b = shard_rows(lo, hi, rank, world)
             plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group))
             spans.append((a, b))
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
@@ -524,7 +566,10 @@ class VFM(nn.Module):
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
         for epoch in range(n_epochs):
             for i, (plan, (a, b)) in enumerate(zip(plans, spans)):
-                if self.n_samples == 1:
+                if world > 1 and self.exchange == "dims":
+                    loss3, pr = self.train_step(plan, process_group=process_group)
+                    train_pred[a:b] = pr
+                elif self.n_samples == 1:
                     loss3, _ = self.train_step(plan, out_pred=train_pred[a:b], process_group=process_group)
                 else:       # [S,B] predictions: the train metrics use their mean over the samples
                     loss3, pr = self.train_step(plan, process_group=process_group)
@@ -532,13 +577,13 @@ class VFM(nn.Module):
                 losses[i] = loss3[0]
             # ---- end of epoch (vfm-torch.py:378-384)
             if self.output == "reg":
-                if world > 1 and self.exchange == "sharded":
+                if world > 1 and self.exchange in ("sharded", "dims"):
                     self.sync_params(process_group)
                 self.save_weights()
             if epoch % display_every == 0:
                 rec = {"epoch": epoch, "elbo": float(losses.mean())}
                 tp = train_pred
-                if world > 1:       # each rank only wrote its own row blocks (the rest stays 0)
+                if world > 1 and self.exchange != "dims":       # each rank only wrote its own row blocks (the rest stays 0)
                     tp = train_pred.clone()
                     torch.distributed.all_reduce(tp, group=process_group)
                 if self.output == "reg":
@@ -547,7 +592,7 @@ class VFM(nn.Module):
                 else:
                     rec["train_auc"], rec["train_map"] = _auc_map(yd, torch.sigmoid(tp))
                 if X_test is not None:
-                    if world > 1 and self.exchange == "sharded":
+                    if world > 1 and self.exchange in ("sharded", "dims"):
                         self.sync_params(process_group)        # rows owned by other ranks are stale
                     rec["test"] = self.evaluate(X_test, y_test)
                 hist["epoch"].append(epoch)

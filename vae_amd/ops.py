@@ -32,6 +32,8 @@ FLAG_LINK_SOFTPLUS = 16
 FLAG_SCALED_MOMENTS = 32
 FLAG_ROWS_UNTOUCHED = 64
 FLAG_ROWS_TOUCHED = 128
+FLAG_PARTIAL_PRED = 256
+FLAG_NO_BIAS = 512
 MOMENT_PERIOD = 128
 MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
@@ -49,6 +51,7 @@ class Spec:
     likelihood: int      # _lib.LIK_NORMAL / LIK_BERNOULLI
     nb_train: int = 1
     n_samples: int = 1   # N_VARIATIONAL_SAMPLES (vfm-torch.py:19)
+    coord_off: int = 0   # dimension-sharded mode: the tables hold coordinates [coord_off, coord_off + d)
     link: str = "abs"    # LINK (vfm-torch.py:125-126): "abs" (the one in effect) or "softplus"
 
     def __post_init__(self):
@@ -72,6 +75,7 @@ def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, ste
         p.group_hi[g] = int(spec.group_hi[g])
         p.group_n[g] = float(spec.group_n[g])
     p.seed, p.step = seed & (2 ** 64 - 1), step & (2 ** 62 - 1)
+    p.coord_off = int(spec.coord_off)
     return p
 
 
@@ -212,7 +216,7 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
     _lib.ops().elbo_fwd(plan.x, plan.y, entity_params, bias_params, inv_occ if have_y else None, scalars,
                         plan.W if have_y else None, e[0], e[1], e[2], pred, partials, sumz, grow,
                         list(spec.group_hi), list(spec.group_n), spec.nb_train, plan.B_global,
-                        spec.likelihood, p.flags, p.seed & _I63, p.step, S)
+                        spec.likelihood, p.flags, p.seed & _I63, p.step, S, spec.coord_off)
     return FwdState(pred, partials, sumz, grow, p, eps)
 
 
@@ -241,7 +245,7 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
     _lib.ops().elbo_bwd(plan.index_tensors(), entity_params, bias_params, inv_occ, scalars, plan.W,
                         e[0], e[1], e[2], st.sumz, st.grow, st.partials, grad_out, g_entity, g_bias, g_scalars,
                         spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
-                        p.flags, p.seed & _I63, p.step, p.n_samples)
+                        p.flags, p.seed & _I63, p.step, p.n_samples, p.coord_off)
     return g_entity, g_bias, g_scalars
 
 
@@ -266,7 +270,8 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
                              p.flags | (FLAG_SPARSE_ADAM if sparse else 0) |
                              (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
-                             p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples)
+                             p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples,
+                             p.coord_off)
 
 
 def exchange_record_len(d: int) -> int:
@@ -300,6 +305,15 @@ def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bia
                                p.seed & _I63, p.step,
                                lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi, own_mod, own_rank, kl_ws,
                                rec_index[0] if rec_index else None, rec_index[1] if rec_index else None)
+
+
+def elbo_lik(st: FwdState, y, scalars, flags=0):
+    """Dimension-sharded mode, after the all-reduce of st.pred[0..B] (row values + KL term): predictions,
+    grow and a `partials` workspace as a full forward would have left it (in place on st)."""
+    p = st.problem
+    e = st.eps if st.eps is not None else (None, None, None)
+    _lib.ops().elbo_lik(y, scalars, e[2], st.pred, st.grow, st.partials, p.nb_train, p.B_global, p.likelihood,
+                        flags | (p.flags & FLAG_LINK_SOFTPLUS), p.seed & _I63, p.step)
 
 
 def moments_rescale(m, v, step, to_scaled, beta1=0.9, beta2=0.999):
