@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "stats", "grads", "sharded"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "stats", "grads", "sharded", "dims"],
                     help="what ranks exchange per step when N>1 (see DESIGN.md section 6)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the global batch stays at --batch rows and is split over the ranks "
@@ -124,10 +124,28 @@ def main():
     model.set_training_data(X, nb_train=nb_train, nb_occ=occ)
     model.lr = 1.0 / (1 + nb_train // (B * world))       # vfm-torch.py:92
 
+    # dimension-sharded mode: every rank holds ALL rows of the global batch (the ranks' row blocks side by side)
+    Xg = yg = None
+
+    def global_rows():
+        nonlocal Xg, yg
+        if Xg is None:
+            blocks = [synthetic_triples(sizes, nbt * B, seed=1000 + r, output=output, device=dev,
+                                        zipf=args.zipf if args.zipf > 0 else None) for r in range(world)]
+            Xg = torch.stack([b[0] for b in blocks], 1).reshape(nbt, B, world, F).transpose(1, 2).reshape(-1, F)
+            yg = torch.stack([b[1] for b in blocks], 1).reshape(nbt, B, world).transpose(1, 2).reshape(-1)
+            if args.id32:
+                Xg = Xg.to(torch.int32)
+            Xg, yg = Xg.contiguous(), yg.contiguous()
+        return Xg, yg
+
     def build_plans():
         ps, us = [], []
+        dims = world > 1 and model.exchange == "dims"
+        Bp = B * world if dims else B
+        Xs, ys = global_rows() if dims else (X, y)
         for i in range(nbt):
-            xb, yb = X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]
+            xb, yb = Xs[i * Bp:(i + 1) * Bp], ys[i * Bp:(i + 1) * Bp]
             if not args.no_sort:
                 o = torch.argsort(xb[:, -1], stable=True)
                 xb, yb = xb[o].contiguous(), yb[o].contiguous()
@@ -180,10 +198,13 @@ def main():
             model._flat.copy_(init)
             model._adam_m.zero_(); model._adam_v.zero_()
             model._adam_t, model.global_step, model._stale_group, model._moments_scaled = 0, 0, None, False
+            model._dims = None
 
         tune, built = {}, {}
         table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
-        for mode in (("sharded", "stats") if table_bytes >= (4 << 20) else ("stats",)):
+        from vae_amd.dims import supported as dims_supported
+        cands = (("dims",) if dims_supported(d, world) else ()) + (("sharded", "stats") if table_bytes >= (4 << 20) else ("stats",))
+        for mode in cands:
             model.exchange = mode
             try:
                 plans, uniq = build_plans()
@@ -225,7 +246,7 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     loss = float(model._gflat[model._n_flat].item())
-    if world > 1 and model.exchange == "sharded":
+    if world > 1 and model.exchange in ("sharded", "dims"):
         model.sync_params(pg)
     nan_params = int(torch.isnan(model._flat).sum().item())
 
@@ -241,14 +262,21 @@ def main():
         n_params = model._n_flat
         # ALGORITHMIC bytes per launch (fp32 params, ids as given, eps in-kernel):
         idb = 4 if args.id32 else 8
-        bytes_fwd = U * (8 * d + 16) + B * (idb * F + 8)          # touched rows once + ids, y, pred
-        bytes_bwd = bytes_fwd + U * (8 * d + 8)                   # re-read + one write per touched row
+        dims_mode = world > 1 and model.exchange == "dims"
+        if dims_mode:         # per rank: all B*world rows, d / world coordinates
+            d_k, B_k, n_params = d // world, B * world, model._dims.n_flat
+        else:
+            d_k, B_k = d, B
+        bytes_fwd = U * (8 * d_k + 16) + B_k * (idb * F + 8)        # touched rows once + ids, y, pred
+        bytes_bwd = bytes_fwd + U * (8 * d_k + 8)                   # re-read + one write per touched row
         alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
                "allreduce": 4.0 * n_params,
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
                # (scaled moments: the rows a batch does not touch read p, m, v and write p only: 16 B/param)
-               "bwd_adam": B * (idb * F + 8) + U * 16 + 24.0 * n_params -
-                           (8.0 * (model.T - U) * (2 * d + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0),
+               "bwd_adam": B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
+                           (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0),
+               # dimension-sharded mode: the step's only exchange, and the per-row likelihood kernel after it
+               "allreduce_row_values": 4.0 * (B_k + 1), "lik": 16.0 * B_k,
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
                "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
                # all-reduce of the statistics overlapped with the epilogue + dense Adam kernels
@@ -260,6 +288,8 @@ def main():
         names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
+                 "allreduce_row_values": "RCCL all-reduce of the B+1 row values (the dimension-sharded step's exchange)",
+                 "lik": "k_lik (likelihood terms + dloss/dpred of all rows) + k_finalize",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
                  "exchange_apply_adam": "RCCL all-reduce of the statistics, chunk-overlapped with "
                                         "k_bwd<APPLY,ADAM> (epilogue + dense Adam)",
@@ -334,10 +364,14 @@ def main():
                        "exchange_autotune_ms_per_step": tune,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
                                  "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
-                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)"}[model.exchange]
+                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
+                                 "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
+                                         "on d/N coordinates"}[model.exchange]
                                 if world > 1 else "fwd+loss+bwd+dense-adam") if
                                (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
-                       "parallelism": f"row-sharded dp{world}"},
+                       "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
+                                       f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
+                       else f"row-sharded dp{world}"},
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
         }
         print(json.dumps(out))
