@@ -212,14 +212,20 @@ def main():
                 exchange_note = "%s plan failed (%s: %s)" % (mode, type(exc).__name__, str(exc)[:200])
                 print("[bench] " + exchange_note, file=sys.stderr)
                 continue
-            run(3, False)
-            barrier()
-            t0 = time.perf_counter()
-            run(10, False)
-            barrier()
-            tune[mode] = round(max_over_ranks(time.perf_counter() - t0) / 10 * 1e3, 4)
-            built[mode] = (plans, uniq)
+            try:
+                run(3, False)
+                barrier()
+                t0 = time.perf_counter()
+                run(10, False)
+                barrier()
+                tune[mode] = round(max_over_ranks(time.perf_counter() - t0) / 10 * 1e3, 4)
+                built[mode] = (plans, uniq)
+            except Exception as exc:      # a pattern that does not run here is not a candidate
+                exchange_note = "%s step failed (%s: %s)" % (mode, type(exc).__name__, str(exc)[:200])
+                print("[bench] " + exchange_note, file=sys.stderr)
             reset_state()
+        if not tune:
+            raise SystemExit("[bench] no exchange pattern ran: " + str(exchange_note))
         best = min(tune, key=tune.get)
         model.exchange = best
         plans, uniq = built[best]
