@@ -295,7 +295,7 @@ def main():
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "allreduce_row_values": "RCCL all-reduce of the B+1 row values (the dimension-sharded step's exchange)",
-                 "lik": "k_lik (likelihood terms + dloss/dpred of all rows) + k_finalize",
+                 "lik": "k_lik (likelihood terms + dloss/dpred of all rows)",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
                  "exchange_apply_adam": "RCCL all-reduce of the statistics, chunk-overlapped with "
                                         "k_bwd<APPLY,ADAM> (epilogue + dense Adam)",

@@ -299,15 +299,16 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
  * both tables; the only per-step exchange is one all-reduce of B+1 floats):
- *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED (+ coord_off; + VFM_FLAG_NO_BIAS | VFM_FLAG_NO_PRIOR_TERMS on
+ *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_PRIOR_TERMS (+ coord_off; + VFM_FLAG_NO_BIAS on
  *      all ranks but one) -> pred[0..B) = this rank's share of the row values, sumz, KL slots;
- *      vfm_elbo_finalize_f32 -> loss[2] = this rank's share of the KL term; the caller stores it in pred[B];
+ *      vfm_elbo_finalize_f32 (same flags) -> loss[2] = this rank's share of the entity KL term; the caller stores
+ *      it in pred[B];
  *   2. all-reduce (sum) of pred[0..B];
  *   3. vfm_elbo_lik_f32: pred[r] <- w0 + pred[r] (the predictions), grow[r] = dloss/dpred_r, and a `partials`
- *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = pred[B],
- *      so finalise it with VFM_FLAG_NO_PRIOR_TERMS);
- *   4. vfm_elbo_bwd_adam_f32 / vfm_elbo_bwd_f32 on the local coordinates with those partials (the three scalars
- *      are replicated: every rank applies the same update). */
+ *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = pred[B]);
+ *   4. vfm_elbo_bwd_adam_f32 / vfm_elbo_finalize_f32 + vfm_elbo_bwd_f32 on the local coordinates with those
+ *      partials and WITHOUT VFM_FLAG_NO_PRIOR_TERMS: KL(q(w0)) enters the loss and the scalars' gradients once, on
+ *      every rank alike (the three scalars are replicated: every rank applies the same update). */
 int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,
                      float* pred, float* grow, double* partials, void* stream);
 

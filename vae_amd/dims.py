@@ -137,12 +137,13 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     if eps is not None:                      # eps tables are local like the parameter tables
         eps = (eps[0][:, st.off: st.off + st.dl].contiguous(), eps[1], eps[2])
     sumz, grow, vals = st.step_buffers(plan.B, model.device)
-    one = 0 if r == 0 else (ops.FLAG_NO_BIAS | ops.FLAG_NO_PRIOR_TERMS)
+    nobias = 0 if r == 0 else ops.FLAG_NO_BIAS
     mark("start")
-    # 1. this rank's share of every row value + its KL share
+    # 1. this rank's share of every row value + its share of the entity KL term (KL(q(w0)) is added once, by
+    #    every rank identically, when the backward launch forms the loss)
     fw = ops.elbo_forward(lp, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
-                          flags=ops.FLAG_PARTIAL_PRED | one, out_pred=vals, out_sumz=sumz, out_grow=grow,
-                          out_partials=model._partials)
+                          flags=ops.FLAG_PARTIAL_PRED | ops.FLAG_NO_PRIOR_TERMS | nobias, out_pred=vals, out_sumz=sumz,
+                          out_grow=grow, out_partials=model._partials)
     ops.elbo_finalize(fw, scal, out=st.loss_local)
     vals[plan.B: plan.B + 1].copy_(st.loss_local[2:3])
     mark("fwd")
@@ -150,24 +151,20 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     dist.all_reduce(vals, group=st.group)
     mark("allreduce_row_values")
     # 3. predictions, likelihood, dloss/dpred; partials as a full forward would have left them
-    lik = ops.FwdState(vals, st.partials_lik, sumz, grow,
-                       ops._problem(lp.spec, plan.B, plan.B_global, plan.id_bits, model.rng_seed, step,
-                                    ops.FLAG_NO_PRIOR_TERMS), eps)
-    ops.elbo_lik(lik, lp.y, scal)
-    loss3 = model._gflat[model._n_flat: model._n_flat + 3]
-    ops.elbo_finalize(lik, scal, out=loss3)
+    bw = ops.FwdState(vals, st.partials_lik, sumz, grow,
+                      ops._problem(lp.spec, plan.B, plan.B_global, plan.id_bits, model.rng_seed, step, nobias), eps)
+    ops.elbo_lik(bw, lp.y, scal)
     mark("lik")
-    # 4. gradients + dense Adam of the local coordinates (rank 0: also the first-order weights)
+    # 4. loss + gradients + dense Adam of the local coordinates (rank 0: also the first-order weights); the
+    #    three scalars are replicated: every rank applies the same update
     scaled = model.scaled_moments
     if scaled != model._moments_scaled:
         ops.moments_rescale(st.m, st.v, model._adam_t, to_scaled=scaled)
         model._set_moment_form(scaled)
     model._adam_t += 1
-    bw = ops.FwdState(vals, st.partials_lik, sumz, grow,
-                      ops._problem(lp.spec, plan.B, plan.B_global, plan.id_bits, model.rng_seed, step,
-                                   0 if r == 0 else ops.FLAG_NO_BIAS), eps)
+    loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     ops.elbo_backward_adam(lp, bw, ent, bia, scal, model.inv_occ, st.views(st.m), st.views(st.v), lr, model._adam_t,
-                           scaled_moments=scaled)
+                           loss_out=loss3, scaled_moments=scaled)
     mark("bwd_adam")
     model._stale_group = st.group          # the full tables are stale until sync_params()
     return loss3, vals[: plan.B]
