@@ -249,12 +249,13 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
   if (int rc = check_problem(p)) return rc;
   if (!W || (p->B > 0 && (!x || !inv_occ))) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (p->B == 0) {                       // empty shard: W = 0
-    hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);
-    return after_launch("vfm_batch_norms");
-  }
-  hipLaunchKernelGGL(k_norms, dim3((unsigned)p->F), dim3(NORMS_BLOCK), 0, st, x, (int)(p->id_bits == 64), inv_occ,
-                     p->B, (int)p->F, p->T, W);
+  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);      // (all-zero bits: 0.0 and integer 0)
+  if (p->B == 0) return after_launch("vfm_batch_norms");                        // empty shard: W = 0
+  int64_t nbx = (p->B + BLOCK * 8 - 1) / (BLOCK * 8);
+  if (nbx > 1024) nbx = 1024;
+  hipLaunchKernelGGL(k_norms, dim3((unsigned)nbx, (unsigned)p->F), dim3(BLOCK), 0, st, x, (int)(p->id_bits == 64),
+                     inv_occ, p->B, (int)p->F, p->T, reinterpret_cast<unsigned long long*>(W));
+  hipLaunchKernelGGL(k_norms_fix, dim3(1), dim3(64), 0, st, W, (int)p->F);
   return after_launch("vfm_batch_norms");
 }
 

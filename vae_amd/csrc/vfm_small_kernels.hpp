@@ -15,34 +15,21 @@ __global__ void k_inv_occ(const int64_t* __restrict__ occ, float* __restrict__ i
     inv[i] = 1.0f / (float)occ[i];
 }
 
-// W[f] = sum_r inv_occ[x[r,f]]: one workgroup per column f, fp64, fixed summation order (thread-strided
-// partial sums, xor-shuffle tree inside each wave, waves added in order) -- bitwise reproducible, so the
-// KL scale n_g / W_g and everything downstream of it is too.  Once per batch, outside the step.
-constexpr int NORMS_BLOCK = 1024;
-__global__ __launch_bounds__(NORMS_BLOCK) void k_norms(const void* __restrict__ x, int id64,
-                                                       const float* __restrict__ inv_occ, int64_t B, int F,
-                                                       int64_t T, double* __restrict__ W) {
-  __shared__ double sh[NORMS_BLOCK / 64];
-  const int f = blockIdx.x;
+// W[f] = sum_r inv_occ[x[r,f]], bitwise reproducible AND parallel: every workgroup sums its rows of column f
+// in fp64 in a fixed order, converts the partial sum to 2^-31 fixed point and adds it with a 64-bit INTEGER
+// atomic (integer addition is associative, so the order in which workgroups arrive does not matter; 1/occ <= 1
+// and B < 2^31 keep the sum below 2^62; the rounding is <= 2^-32 per workgroup, 1e-10 of W).  k_norms_fix
+// turns the accumulators into doubles in place.  Once per batch, outside the step.
+constexpr double NORMS_SCALE = 2147483648.0;   // 2^31
+__global__ __launch_bounds__(BLOCK) void k_norms(const void* __restrict__ x, int id64,
+                                                 const float* __restrict__ inv_occ, int64_t B, int F,
+                                                 int64_t T, unsigned long long* __restrict__ Wfix) {
+  __shared__ double sh[BLOCK / 64];
+  const int f = blockIdx.y;
   double acc = 0.0;
-  auto id_of = [&](int64_t r) -> int64_t {
+  for (int64_t r = blockIdx.x * (int64_t)BLOCK + threadIdx.x; r < B; r += (int64_t)gridDim.x * BLOCK) {
     const int64_t o = r * F + f;
-    return id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
-  };
-  constexpr int UN = 8;                  // independent id -> 1/occ chains in flight per thread
-  int64_t r = threadIdx.x;
-  for (; r + (UN - 1) * (int64_t)NORMS_BLOCK < B; r += UN * (int64_t)NORMS_BLOCK) {
-    int64_t id[UN];
-    float v[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) id[u] = id_of(r + u * (int64_t)NORMS_BLOCK);
-#pragma unroll
-    for (int u = 0; u < UN; ++u) v[u] = (id[u] >= 0 && id[u] < T) ? inv_occ[id[u]] : 0.f;
-#pragma unroll
-    for (int u = 0; u < UN; ++u) acc += (double)v[u];
-  }
-  for (; r < B; r += NORMS_BLOCK) {
-    const int64_t id = id_of(r);
+    const int64_t id = id64 ? ((const int64_t*)x)[o] : (int64_t)((const int32_t*)x)[o];
     if (id >= 0 && id < T) acc += (double)inv_occ[id];
   }
 #pragma unroll
@@ -51,8 +38,15 @@ __global__ __launch_bounds__(NORMS_BLOCK) void k_norms(const void* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int w = 0; w < NORMS_BLOCK / 64; ++w) t += sh[w];
-    W[f] = t;
+    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
+    atomicAdd(&Wfix[f], (unsigned long long)(long long)__double2ll_rn(t * NORMS_SCALE));
+  }
+}
+
+__global__ void k_norms_fix(double* __restrict__ W, int F) {
+  if ((int)threadIdx.x < F) {
+    const long long v = reinterpret_cast<const long long*>(W)[threadIdx.x];
+    W[threadIdx.x] = (double)v / NORMS_SCALE;
   }
 }
 
