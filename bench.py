@@ -282,7 +282,7 @@ def main():
                "bwd_adam": B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
                            (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0),
                # dimension-sharded mode: the step's only exchange, and the per-row likelihood kernel after it
-               "allreduce_row_values": 4.0 * (B_k + 1), "lik": 16.0 * B_k,
+               "allreduce_row_values": 4.0 * (B_k + 4096), "lik": 16.0 * B_k,
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
                "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
                # all-reduce of the statistics overlapped with the epilogue + dense Adam kernels
@@ -294,7 +294,7 @@ def main():
         names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
-                 "allreduce_row_values": "RCCL all-reduce of the B+1 row values (the dimension-sharded step's exchange)",
+                 "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",
                  "lik": "k_lik (likelihood terms + dloss/dpred of all rows)",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
                  "exchange_apply_adam": "RCCL all-reduce of the statistics, chunk-overlapped with "

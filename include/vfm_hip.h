@@ -71,8 +71,10 @@ extern "C" {
 #define VFM_FLAG_PARTIAL_PRED 256   /* vfm_elbo_fwd_f32 (training, n_samples == 1): stop before the likelihood --
                                      pred[r] receives this call's share  sum_f w_f + 1/2 sum_k[..]  of the row
                                      value over ITS coordinates only (no global bias); sumz and the KL slots are
-                                     written as usual.  The embedding-dimension-sharded multi-rank mode sums the
-                                     shares over ranks and finishes with vfm_elbo_lik_f32.                     */
+                                     written as usual, and `pred` must hold B + VFM_MAX_FWD_BLOCKS floats: the
+                                     tail receives the workgroups' shares of the KL term (zero beyond the grid;
+                                     NaN where an id was out of range).  The embedding-dimension-sharded multi-rank
+                                     mode sums pred over ranks and finishes with vfm_elbo_lik_f32.             */
 #define VFM_FLAG_NO_BIAS 512        /* this call leaves the first-order weights (bias_params) out: no sum_f w_f,
                                      no KL of them, no gradient / Adam update for them (dimension-sharded mode:
                                      rank 0 alone carries them; bias_params and its moments must still point to
@@ -300,12 +302,12 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
  * both tables; the only per-step exchange is one all-reduce of B+1 floats):
  *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_PRIOR_TERMS (+ coord_off; + VFM_FLAG_NO_BIAS on
- *      all ranks but one) -> pred[0..B) = this rank's share of the row values, sumz, KL slots;
- *      vfm_elbo_finalize_f32 (same flags) -> loss[2] = this rank's share of the entity KL term; the caller stores
- *      it in pred[B];
- *   2. all-reduce (sum) of pred[0..B];
+ *      all ranks but one) -> pred[0..B) = this rank's share of the row values, pred[B..B+VFM_MAX_FWD_BLOCKS) = its
+ *      workgroups' shares of the entity KL term; sumz;
+ *   2. all-reduce (sum) of pred[0 .. B + VFM_MAX_FWD_BLOCKS);
  *   3. vfm_elbo_lik_f32: pred[r] <- w0 + pred[r] (the predictions), grow[r] = dloss/dpred_r, and a `partials`
- *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = pred[B]);
+ *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = the sum
+ *      of the tail, in a fixed order);
  *   4. vfm_elbo_bwd_adam_f32 / vfm_elbo_finalize_f32 + vfm_elbo_bwd_f32 on the local coordinates with those
  *      partials and WITHOUT VFM_FLAG_NO_PRIOR_TERMS: KL(q(w0)) enters the loss and the scalars' gradients once, on
  *      every rank alike (the three scalars are replicated: every rank applies the same update). */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
 OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
 
 ABI_VERSION = 2
+MAX_FWD_BLOCKS = 4096
 MAX_FIELDS = 64
 N_PARTIALS = 8
 MAX_FWD_BLOCKS = 4096

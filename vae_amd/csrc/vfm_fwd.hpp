@@ -514,6 +514,13 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED)) {
+      // dimension-sharded mode: this workgroup's share of the KL term travels behind the row values
+      // (pred[B + b]; NaN when an id was out of range); workgroup 0 clears the unused tail
+      out.pred[a.B + blockIdx.x] = (tot[4] != 0.f) ? __builtin_nanf("") : tot[1];
+    }
     if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
   }
+  if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED) && blockIdx.x == 0)
+    for (int b = gridDim.x + tid; b < VFM_MAX_FWD_BLOCKS; b += BLOCK) out.pred[a.B + b] = 0.f;
 }

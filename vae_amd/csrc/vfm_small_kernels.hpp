@@ -60,10 +60,11 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partial
 
 // Dimension-sharded mode, after the all-reduce of the row values: pred[r] <- w0 + pred[r], the likelihood
 // terms and grow[r] = dloss/dpred_r, per-workgroup sums into `partials` slots laid out like the forward's
-// (the KL slot of workgroup 0 carries pred[B] = the KL term summed over ranks; NaN there -- ids out of range on
-// some rank -- makes the loss NaN).  Same arithmetic per row as finish_row in vfm_fwd.hpp.
+// (the KL slot of workgroup 0 = the sum of pred[B .. B + VFM_MAX_FWD_BLOCKS), the forward workgroups' KL shares
+// summed over ranks; NaN there -- ids out of range on some rank -- makes the loss NaN).  Same arithmetic per row as finish_row in vfm_fwd.hpp.
 __global__ __launch_bounds__(BLOCK) void k_lik(const KArgs a, const FwdOut out) {
   __shared__ float sh_red[6 * 4];
+  __shared__ double sh_kl[BLOCK / 64];
   const bool softplus = (a.flags & VFM_FLAG_LINK_SOFTPLUS) != 0;
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = softplus ? link_f<LINK_SOFTPLUS>(alpha) : link_f<LINK_ABS>(alpha);
@@ -93,9 +94,19 @@ __global__ __launch_bounds__(BLOCK) void k_lik(const KArgs a, const FwdOut out) 
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
-    if (blockIdx.x == 0) {
-      slot[VFM_P_KL] = (double)out.pred[a.B];        // KL term summed over ranks (travels behind the row values)
-      out.partials[7] = (double)gridDim.x;
+    if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
+  }
+  if (blockIdx.x == 0) {     // the KL term: the forward workgroups' shares, summed over ranks by the all-reduce
+    double kl = 0.0;         // (fixed order: reproducible)
+    for (int b = threadIdx.x; b < VFM_MAX_FWD_BLOCKS; b += BLOCK) kl += (double)out.pred[a.B + b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) kl += __shfl_xor(kl, m, 64);
+    if ((threadIdx.x & 63) == 0) sh_kl[threadIdx.x >> 6] = kl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < BLOCK / 64; ++w) t += sh_kl[w];
+      out.partials[VFM_N_PARTIALS * 1 + VFM_P_KL] = t;
     }
   }
 }

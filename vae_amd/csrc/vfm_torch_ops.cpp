@@ -73,6 +73,8 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
               entity.size(1) % 2 == 0, "table shapes");
   TORCH_CHECK(n_samples >= 1 && pred.numel() >= n_samples * id.B && partials.numel() >= VFM_PARTIALS_LEN &&
               scalars.numel() >= 3, "output sizes");
+  if (flags & VFM_FLAG_PARTIAL_PRED)
+    TORCH_CHECK(pred.numel() >= id.B + VFM_MAX_FWD_BLOCKS, "VFM_FLAG_PARTIAL_PRED: pred needs B + VFM_MAX_FWD_BLOCKS floats");
   const int64_t T = entity.size(0), d = entity.size(1) / 2;
   if (sumz.has_value() && sumz->defined()) TORCH_CHECK(sumz->numel() >= n_samples * id.B * d, "sumz too small");
   if (eps_entity.has_value() && eps_entity->defined())
@@ -359,8 +361,8 @@ void elbo_lik(const Tensor& y, const Tensor& scalars, const optional<Tensor>& ep
   dev_tensor(y, at::kFloat, "y"); dev_tensor(scalars, at::kFloat, "scalars"); dev_tensor(pred, at::kFloat, "pred");
   dev_tensor(grow, at::kFloat, "grow"); dev_tensor(partials, at::kDouble, "partials");
   const int64_t B = y.numel();
-  TORCH_CHECK(pred.numel() >= B + 1 && grow.numel() >= B && partials.numel() >= VFM_PARTIALS_LEN && scalars.numel() >= 3,
-              "elbo_lik sizes (pred holds B row values + the KL term)");
+  TORCH_CHECK(pred.numel() >= B + VFM_MAX_FWD_BLOCKS && grow.numel() >= B && partials.numel() >= VFM_PARTIALS_LEN &&
+              scalars.numel() >= 3, "elbo_lik sizes (pred holds B row values + VFM_MAX_FWD_BLOCKS KL shares)");
   c10::hip::HIPGuard guard(y.get_device());
   vfm_problem_t p{};
   p.B = B; p.B_global = B_global; p.T = 1; p.nb_train = nb_train; p.F = 1; p.d = 4; p.id_bits = 64;

@@ -6,8 +6,8 @@ This mode cuts the MODEL instead: rank r of N holds the coordinates [r*d/N, (r+1
 of every entity row, sees ALL rows of the batch, and everything per coordinate -- sampling, KL, gradients,
 Adam -- is local.  The only quantity that couples coordinates is the FM row value
     sum_f w_f + 1/2 sum_k [ (sum_f z_fk)^2 - sum_f z_fk^2 ]            (vfm-torch.py:244-245)
-a sum over k, so the ONE exchange of a step is an all-reduce of B + 1 floats (each rank's share of every row
-value + its share of the KL term): 3.2 MB at N = 8, B = 800 K.  Per rank and step:
+a sum over k, so the ONE exchange of a step is an all-reduce of B + 4096 floats (each rank's share of every row
+value + its forward workgroups' shares of the KL term): 3.2 MB at N = 8, B = 800 K.  Per rank and step:
 
     1. forward on the local coordinates, VFM_FLAG_PARTIAL_PRED          -> shares, sumz slice, KL share   [k_fwd]
     2. all-reduce of the shares                                                                           [RCCL]
@@ -31,7 +31,7 @@ import dataclasses
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 def _round4(n):
@@ -62,7 +62,6 @@ class DimsState:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.partials_lik = torch.zeros_like(model._partials)
-        self.loss_local = torch.zeros(4, dtype=torch.float32, device=dev)
         self._bufs = {}
         self.scatter(model)
 
@@ -105,7 +104,7 @@ class DimsState:
         if b is None:
             b = (torch.empty(B, self.dl, dtype=torch.float32, device=dev),       # sumz slice
                  torch.empty(B, dtype=torch.float32, device=dev),                # grow
-                 torch.empty(B + 1, dtype=torch.float32, device=dev))            # row values + KL term
+                 torch.zeros(B + _lib.MAX_FWD_BLOCKS, dtype=torch.float32, device=dev))   # row values + KL shares
             if len(self._bufs) > 4:
                 self._bufs.clear()
             self._bufs[B] = b
@@ -139,13 +138,11 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     sumz, grow, vals = st.step_buffers(plan.B, model.device)
     nobias = 0 if r == 0 else ops.FLAG_NO_BIAS
     mark("start")
-    # 1. this rank's share of every row value + its share of the entity KL term (KL(q(w0)) is added once, by
-    #    every rank identically, when the backward launch forms the loss)
-    fw = ops.elbo_forward(lp, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
-                          flags=ops.FLAG_PARTIAL_PRED | ops.FLAG_NO_PRIOR_TERMS | nobias, out_pred=vals, out_sumz=sumz,
-                          out_grow=grow, out_partials=model._partials)
-    ops.elbo_finalize(fw, scal, out=st.loss_local)
-    vals[plan.B: plan.B + 1].copy_(st.loss_local[2:3])
+    # 1. this rank's share of every row value; its forward workgroups' shares of the entity KL term land behind
+    #    them in `vals` (KL(q(w0)) is added once, by every rank identically, when the backward forms the loss)
+    ops.elbo_forward(lp, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
+                     flags=ops.FLAG_PARTIAL_PRED | ops.FLAG_NO_PRIOR_TERMS | nobias, out_pred=vals, out_sumz=sumz,
+                     out_grow=grow, out_partials=model._partials)
     mark("fwd")
     # 2. the exchange of the step
     dist.all_reduce(vals, group=st.group)
