@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Whole entity-sharded step (Python + launches + collectives on a 1-rank gloo group) at cfg3 on one GPU:
-shows the host-side cost of the step next to the kernel time (tools/shard_probe.py)."""
+"""Whole multi-rank step (Python + launches + collectives on a 1-rank gloo group) at cfg3 on one GPU: shows the
+host-side cost of the step next to the kernel time (tools/shard_probe.py).  EXCHANGE=sharded|stats|grads, or
+EXCHANGE=dims DIMS_N=8: rank 0's work of the embedding-dimension-sharded step at the N-rank shape (all N*B rows,
+d/N coordinates; the all-reduce replaced by the identity)."""
 import os
 import sys
 import time
@@ -31,11 +33,17 @@ if os.environ.get("LOCAL_COLLECTIVES", "1") == "1":
 
     dist.all_to_all_single = _a2a
     dist.all_reduce = _ar
+DIMS_N = int(os.environ.get("DIMS_N", "0"))
+if DIMS_N > 1:          # pretend to be rank 0 of N
+    dist.get_world_size = lambda group=None: DIMS_N
+    dist.get_rank = lambda group=None: 0
 dev = torch.device("cuda")
 sizes, d, B, nb_train = [138493, 26744], 128, 100000, 16000210
 torch.manual_seed(42)
 m = VFM(field_sizes=sizes, embedding_size=d, device=dev, rng_seed=3)
 m.exchange = os.environ.get("EXCHANGE", "sharded")
+if DIMS_N > 1:
+    B *= DIMS_N
 X, y = synthetic_triples(sizes, 4 * B, seed=1, device=dev)
 occ = torch.clamp(torch.bincount(X.reshape(-1), minlength=sum(sizes)) * 40, min=1)
 m.set_training_data(X, nb_train=nb_train, nb_occ=occ)
