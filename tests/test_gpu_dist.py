@@ -269,3 +269,49 @@ def test_fit_dimension_sharded_matches_single_rank(tmp_path):
     assert np.array_equal(np.load(tmp_path / "df_params_0.npy"), np.load(tmp_path / "df_params_1.npy"))
     assert rel_err(np.load(tmp_path / "df_params_0.npy"), m._flat.cpu().numpy()) < 1e-3
     assert rel_err(np.load(tmp_path / "df_rmse_0.npy"), np.array([t["rmse_of_mean"] for t in h["test"]])) < 1e-3
+
+
+def _dims_general_worker(rank, world, port, out_dir, output):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, X, y = _general_model(output)
+    m.exchange = "dims"
+    plan = m.plan(X, y, process_group=dist.group.WORLD)
+    losses = []
+    for step in range(3):
+        loss3, _ = m.train_step(plan, lr=0.03, process_group=dist.group.WORLD)
+        losses.append(loss3.cpu().numpy().copy())
+    m.sync_params(dist.group.WORLD)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"dg_params_{rank}.npy"), m._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"dg_loss_{rank}.npy"), np.array(losses))
+    dist.destroy_process_group()
+
+
+def _general_model(output):
+    """Three fields (the general-F kernels), d = 32, softplus link, skewed ids (heavy lists)."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    sizes = [40, 30, 50]
+    X, y = synthetic_triples(sizes, 3000, seed=8, output=output, zipf=1.2)
+    torch.manual_seed(2)
+    m = VFM(field_sizes=sizes, embedding_size=32, output=output, device="cuda:0", rng_seed=6, link="softplus")
+    m.set_training_data(X, nb_train=3000)
+    return m, X, y
+
+
+@pytest.mark.parametrize("output", ["reg", "class"])
+def test_dimension_sharded_general_fields(output, tmp_path):
+    world = 2
+    mp.spawn(_dims_general_worker, args=(world, _free_port(), str(tmp_path), output), nprocs=world, join=True)
+    m, X, y = _general_model(output)
+    plan = m.plan(X, y)
+    ref = []
+    for step in range(3):
+        loss3, _ = m.train_step(plan, lr=0.03)
+        ref.append(loss3.cpu().numpy().copy())
+    p0, p1 = np.load(tmp_path / "dg_params_0.npy"), np.load(tmp_path / "dg_params_1.npy")
+    assert np.array_equal(p0, p1)
+    assert rel_err(p0, m._flat.cpu().numpy()) < 5e-5
+    assert rel_err(np.load(tmp_path / "dg_loss_0.npy"), np.array(ref)) < 1e-5
