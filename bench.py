@@ -37,6 +37,8 @@ WORKLOADS = {
     "ml20m_d64": ([138493, 26744], 64, 200000, 16000210, "reg"),
     "ml20m_d32": ([138493, 26744], 32, 400000, 16000210, "reg"),
     "ml20m_d16": ([138493, 26744], 16, 800000, 16000210, "reg"),
+    # ... and at cfg5 with N = 8: 16,384 rows of 32 fields, 32 of 256 coordinates
+    "criteo_d32": ([31250] * 32, 32, 16384, 1 << 22, "class"),
 }
 
 
