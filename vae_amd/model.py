@@ -170,9 +170,18 @@ class VFM(nn.Module):
         self.global_bias_scale.data = f[self._off_scal + 2: self._off_scal + 3]
 
     def _views(self, flat):
-        return (flat[: self._n_ent].view(self.T, 2 * self.d),
-                flat[self._off_bias: self._off_bias + self._n_bias].view(self.T, 2),
-                flat[self._off_scal: self._off_scal + 3])
+        """(entity [T,2d], bias [T,2], scalars [3]) views of a flat buffer; cached per buffer (the step path
+        asks for the same few persistent buffers every step)."""
+        cache = self.__dict__.setdefault("_view_cache", {})
+        hit = cache.get(id(flat))
+        if hit is None or hit[0] is not flat:
+            if len(cache) > 16:
+                cache.clear()
+            hit = (flat, (flat[: self._n_ent].view(self.T, 2 * self.d),
+                          flat[self._off_bias: self._off_bias + self._n_bias].view(self.T, 2),
+                          flat[self._off_scal: self._off_scal + 3]))
+            cache[id(flat)] = hit
+        return hit[1]
 
     def _apply(self, fn, *a, **k):
         # keep the parameters tied to the flat buffer across .to()/.cuda(); the kernels are fp32 only
