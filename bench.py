@@ -258,7 +258,57 @@ def main():
         model.sync_params(pg)
     nan_params = int(torch.isnan(model._flat).sum().item())
 
-    # ---- per-kernel durations from the HIP events recorded inside the timed region
+    # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
+    kern, roof = kernel_report(events, model, args, world, B, d, F, U)
+    copy_gbs = stream_copy_rate(dev)
+    if roof is not None:
+        roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
+        roof["frac_of_box_stream_copy"] = round(roof["achieved"] / copy_gbs, 4)
+
+    # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sizes, d, B, nb_train, output, plans[0], occ, args.cpu_seconds)
+
+    if rank == 0:
+        value = args.steps * B * world / dt
+        out = {
+            "metric": "rating-triples/sec (ELBO step) at d=%d" % d,
+            "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
+                       "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
+                       "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
+                       "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
+                       "likelihood": output, "unique_entities_per_batch": round(U, 1),
+                       "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
+                       "adam_moments": "scaled form (untouched rows do not write m, v)" if (
+                           model.scaled_moments and world == 1 and not args.unfused) else "plain",
+                       "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
+                       "exchange_autotune_ms_per_step": tune,
+                       "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
+                                 "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
+                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
+                                 "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
+                                         "on d/N coordinates"}[model.exchange]
+                                if world > 1 else "fwd+loss+bwd+dense-adam") if
+                               (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
+                       "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
+                                       f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
+                       else f"row-sharded dp{world}"},
+            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def kernel_report(events, model, args, world, B, d, F, U):
+    """Per-kernel averages of the HIP events recorded inside the timed region, each with its ALGORITHMIC bytes
+     and the resulting GB/s, and the `roofline` object of the kernel that takes most time."""
     kern = {}
     roof = None
     if events:
@@ -328,9 +378,13 @@ def main():
                 "avg_us": kern[dom]["avg_us"], "alg_bytes": kern[dom]["alg_bytes"],
                 "elbo_fwd_kernel": {"achieved": kern["fwd"]["achieved_GBs"], "frac": kern["fwd"]["frac_hbm_peak"],
                                     "avg_us": kern["fwd"]["avg_us"], "alg_bytes": kern["fwd"]["alg_bytes"]}}
+    return kern, roof
 
-    # ---- this box's streaming rate (device-to-device copy of 1 GiB), an honest denominator next to the
-    # 8 TB/s spec peak
+
+def stream_copy_rate(dev):
+    """This box's streaming rate (device-to-device copy of 1 GiB): an honest denominator next to the 8 TB/s
+    spec peak."""
+    import torch
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     dst = torch.empty_like(src)
     dst.copy_(src)
@@ -342,49 +396,7 @@ def main():
     torch.cuda.synchronize()
     copy_gbs = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
-    if roof is not None:
-        roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
-        roof["frac_of_box_stream_copy"] = round(roof["achieved"] / copy_gbs, 4)
-
-    # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sizes, d, B, nb_train, output, plans[0], occ, args.cpu_seconds)
-
-    if rank == 0:
-        value = args.steps * B * world / dt
-        out = {
-            "metric": "rating-triples/sec (ELBO step) at d=%d" % d,
-            "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
-                       "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
-                       "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
-                       "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
-                       "likelihood": output, "unique_entities_per_batch": round(U, 1),
-                       "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
-                       "adam_moments": "scaled form (untouched rows do not write m, v)" if (
-                           model.scaled_moments and world == 1 and not args.unfused) else "plain",
-                       "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
-                       "exchange_autotune_ms_per_step": tune,
-                       "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
-                                 "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
-                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
-                                 "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
-                                         "on d/N coordinates"}[model.exchange]
-                                if world > 1 else "fwd+loss+bwd+dense-adam") if
-                               (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
-                       "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
-                                       f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
-                       else f"row-sharded dp{world}"},
-            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
-        }
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    return copy_gbs
 
 
 def cpu_baseline(sizes, d, B, nb_train, output, plan, occ, budget_s):
