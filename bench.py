@@ -65,9 +65,6 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--sync-each-step", action="store_true", help="debug: host sync after every step")
     ap.add_argument("--unfused", action="store_true", help="separate backward and Adam kernels (as N>1 does)")
-    ap.add_argument("--overlap-untouched", action="store_true",
-                    help="A/B: Adam of the rows the batch does not touch as its own launch on a side stream, "
-                         "beside the forward (measured slower; see DESIGN.md)")
     ap.add_argument("--plain-moments", action="store_true",
                     help="A/B: keep the Adam moments in the plain form (no VFM_FLAG_SCALED_MOMENTS)")
     args = ap.parse_args()
@@ -110,7 +107,6 @@ def main():
     model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
     model.exchange = args.exchange
     model.scaled_moments = not args.plain_moments
-    model.overlap_untouched = args.overlap_untouched
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)

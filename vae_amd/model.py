@@ -96,19 +96,13 @@ class VFM(nn.Module):
         # fused single-rank step: keep the Adam moments in the scaled form (VFM_FLAG_SCALED_MOMENTS: rows the
         # batch does not touch do not write their moments back; same dense Adam up to fp32 rounding)
         self.scaled_moments = True
-        # OPTIONAL (off): update the rows the batch does not touch (pure Adam decay, 41 % of the table at
-        # ML-20M shape) in a separate launch on a side stream, concurrently with the forward kernel.  Results
-        # are unchanged; measured SLOWER at cfg3 (0.246-0.261 vs 0.224 ms/step: the forward already fills the
-        # CUs, so the side launch only runs in its tail and both kernels then scan the table) -- DESIGN.md 4
-        self.overlap_untouched = False
-        self._side_stream = None
         self._moments_scaled = False       # which form _adam_m / _adam_v are in right now
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
         # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
         # "dims" = the embedding dimension cut over the ranks (vae_amd/dims.py): every rank sees all rows, holds
-        # d / N coordinates, ONE all-reduce of B + 1 floats per step and Adam traffic / N.
+        # d / N coordinates, ONE all-reduce of B + 4096 floats per step and Adam traffic / N.
         # "auto": "dims" when d % (8 N) == 0, else "sharded" unless the whole statistics table is tiny
         # (< 4 MB: one small all-reduce wins); "grads" with n_samples > 1.
         self.exchange = "auto"
@@ -465,23 +459,10 @@ class VFM(nn.Module):
         if fused is None:
             fused = self.fuse_adam
         fused = fused and adam and process_group is None
-        split = fused and self.overlap_untouched and not self.sparse_adam and plan.B > 0
         if fused:
             scaled = self.scaled_moments and not self.sparse_adam
             self._set_moment_form(scaled)
             self._adam_t += 1
-        if split:
-            # rows not in the batch: Adam decay on the side stream, beside the forward (disjoint rows)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            cur = torch.cuda.current_stream(self.device)
-            self._side_stream.wait_stream(cur)
-            st0 = ops.FwdState(pred, self._partials, sumz, grow,
-                               ops._problem(plan.spec, plan.B, plan.B_global, plan.id_bits, self.rng_seed, step, flags), eps)
-            with torch.cuda.stream(self._side_stream):
-                ops.elbo_backward_adam(plan, st0, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                       self._views(self._adam_v), lr, self._adam_t, scaled_moments=scaled,
-                                       rows="untouched")
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
                               train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
@@ -490,9 +471,7 @@ class VFM(nn.Module):
             # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
                                    self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                   sparse=self.sparse_adam, scaled_moments=scaled, rows="touched" if split else None)
-            if split:
-                torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+                                   sparse=self.sparse_adam, scaled_moments=scaled)
             mark("bwd_adam")
             return loss3, st.pred
         stats = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
