@@ -154,14 +154,14 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     mark("lik")
     # 4. loss + gradients + dense Adam of the local coordinates (rank 0: also the first-order weights); the
     #    three scalars are replicated: every rank applies the same update
-    scaled = model.scaled_moments
+    scaled = model.scaled_moments and not model.sparse_adam
     if scaled != model._moments_scaled:
         ops.moments_rescale(st.m, st.v, model._adam_t, to_scaled=scaled)
         model._set_moment_form(scaled)
     model._adam_t += 1
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     ops.elbo_backward_adam(lp, bw, ent, bia, scal, model.inv_occ, st.views(st.m), st.views(st.v), lr, model._adam_t,
-                           loss_out=loss3, scaled_moments=scaled)
+                           loss_out=loss3, sparse=model.sparse_adam, scaled_moments=scaled)
     mark("bwd_adam")
     model._stale_group = st.group          # the full tables are stale until sync_params()
     return loss3, vals[: plan.B]
