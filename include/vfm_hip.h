@@ -300,7 +300,7 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta2, float eps, int64_t step, void* stream);
 
 /* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
- * both tables; the only per-step exchange is one all-reduce of B+1 floats):
+ * both tables; the only per-step exchange is one all-reduce of B + VFM_MAX_FWD_BLOCKS floats):
  *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_PRIOR_TERMS (+ coord_off; + VFM_FLAG_NO_BIAS on
  *      all ranks but one) -> pred[0..B) = this rank's share of the row values, pred[B..B+VFM_MAX_FWD_BLOCKS) = its
  *      workgroups' shares of the entity KL term; sumz;

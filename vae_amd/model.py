@@ -288,7 +288,7 @@ class VFM(nn.Module):
             from .dims import supported
             table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
             if supported(self.d, torch.distributed.get_world_size(process_group), self.n_samples):
-                self.exchange = "dims"       # one all-reduce of B + 1 floats per step; Adam traffic / N
+                self.exchange = "dims"       # one all-reduce of B + 4096 floats per step; Adam traffic / N
             else:
                 self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
         return self.exchange
