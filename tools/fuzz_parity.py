@@ -67,9 +67,10 @@ def main():
                 "g_sc": max(abs(g_sc[i].item() - r[k][0]) / max(abs(r[k][0]), 1e-3)
                             for i, k in enumerate(("g_alpha", "g_global_bias_mean", "g_global_bias_scale")))}
         # F = 1: the FM interaction vanishes identically, so the embedding gradient is the KL part alone and the
-        # kernel's  A - z * sum(g)  is pure cancellation noise (1 ulp of z times sum g) on top of it: only a loose
-        # check is meaningful there
+        # kernel's  A - z * sum(g)  (A = sum_r g_r z, accumulated in fp32 over the rows) is pure cancellation noise
+        # on top of it: only a loose check is meaningful there
         tol = {k: 2e-4 for k in errs}
+        tol["g_sc"] = 5e-4         # (B = 1: the alpha term (y-pred)^2/2 - 1/(2 alpha) cancels too)
         if F == 1:
             tol["g_ent"] = 0.2
         bad = {k: v for k, v in errs.items() if not (v < tol[k])}
