@@ -73,6 +73,33 @@ def main():
         tol["g_sc"] = 5e-4         # (B = 1: the alpha term (y-pred)^2/2 - 1/(2 alpha) cancels too)
         if F == 1:
             tol["g_ent"] = 0.2
+        # fused backward + dense Adam (plain and scaled moment forms) vs the gradients above + the flat Adam kernel
+        pr = [ent.clone(), bia.clone(), scal.clone()]
+        for p_, g_ in zip(pr, (g_ent, g_bias, g_sc)):
+            n4 = (p_.numel() + 3) // 4 * 4
+            buf = [torch.zeros(n4, device=dev) for _ in range(4)]
+            buf[0][: p_.numel()] = p_.reshape(-1); buf[1][: p_.numel()] = g_.reshape(-1)
+            ops.adam_step(buf[0], buf[1], buf[2], buf[3], 0.01, 1)
+            p_.copy_(buf[0][: p_.numel()].reshape(p_.shape))
+        for scaled in (False, True):
+            e2, b2, s2 = ent.clone(), bia.clone(), scal.clone()
+            mv = [(torch.zeros_like(e2), torch.zeros_like(b2), torch.zeros(3, device=dev)) for _ in range(2)]
+            st2 = ops.elbo_forward(plan, e2, b2, s2, inv_occ, seed=seed, step=step)
+            ops.elbo_backward_adam(plan, st2, e2, b2, s2, inv_occ, mv[0], mv[1], 0.01, 1, scaled_moments=scaled,
+                                   loss_out=torch.zeros(3, device=dev))       # (also reduces the forward's slots)
+            key = "adam_scaled" if scaled else "adam_plain"
+            sc_ok = slice(1, 3) if output == "class" else slice(0, 3)       # alpha: no gradient under Bernoulli
+            errs[key] = max(rel(e2.cpu().numpy(), pr[0].cpu().numpy()), rel(b2.cpu().numpy(), pr[1].cpu().numpy()),
+                            rel(s2[sc_ok].cpu().numpy(), pr[2][sc_ok].cpu().numpy()))
+            tol[key] = 2e-6 if F > 1 else 0.05     # (F = 1: Adam normalises that cancellation noise to +-lr)
+            worst.setdefault(key, 0.0)
+            if os.environ.get("FUZZ_DEBUG") and errs[key] > 1e-4:
+                for nm, got, want, gg in (("ent", e2, pr[0], g_ent), ("bias", b2, pr[1], g_bias), ("scal", s2, pr[2], g_sc)):
+                    dlt = (got - want).abs().reshape(-1)
+                    i = int(dlt.argmax())
+                    print("   ", key, nm, "max diff", float(dlt[i]), "at", i, "fused", float(got.reshape(-1)[i]),
+                          "unfused", float(want.reshape(-1)[i]), "grad", float(gg.reshape(-1)[i]),
+                          "init", float((ent, bia, scal)[("ent", "bias", "scal").index(nm)].reshape(-1)[i]))
         bad = {k: v for k, v in errs.items() if not (v < tol[k])}
         for k, v in errs.items():
             worst[k] = max(worst[k], v if np.isfinite(v) else 1e9)
