@@ -98,6 +98,9 @@ extern "C" {
 #define VFM_P_ALPHA 3   /* sum_r [(y-pred)^2/2 - 1/(2|alpha|)]                          */
 #define VFM_P_BADID 4   /* number of ids outside [0,T) met (they are clamped to 0)      */
 #define VFM_P_GE0 5     /* n_samples > 1: sum_s eps0^s * sum_r dloss/dpred[s,r]         */
+#define VFM_P_REDUCED 6 /* 1.0 once the slots were reduced into [0..5] (vfm_elbo_finalize_f32, or the fused
+                           backward given `loss`); 0.0 after a forward.  A backward call that needs the sums
+                           and finds 0.0 here produces NaN scalar gradients instead of using stale sums */
 #define VFM_N_PARTIALS 8
 /* `partials` is a caller-owned fp64 workspace of VFM_PARTIALS_LEN entries: [0..7] the sums
  * above (valid after vfm_elbo_finalize_f32; [7] = number of forward blocks), followed by one

@@ -91,6 +91,7 @@ def test_grad_out_scaling_and_dense_zero_rows():
     c = Case("ml100k_reg_d20")
     ops, spec, plan, ent, bia, scal, inv_occ, eps = _setup(c, dev)
     st = ops.elbo_forward(plan, ent, bia, scal, inv_occ, eps=eps)
+    ops.elbo_finalize(st, scal)
     g1 = ops.elbo_backward(plan, st, ent, bia, scal, inv_occ, torch.ones(1, device=dev))
     g3 = ops.elbo_backward(plan, st, ent, bia, scal, inv_occ, torch.full((1,), 3.0, device=dev),
                            g_entity=torch.full_like(ent, 7.0), g_bias=torch.full_like(bia, 7.0))
@@ -100,3 +101,19 @@ def test_grad_out_scaling_and_dense_zero_rows():
     untouched[torch.tensor(c.uniq, device=dev)] = False
     assert untouched.any()
     assert (g3[0][untouched] == 0).all() and (g3[1][untouched] == 0).all()
+
+
+def test_backward_without_reduced_sums_is_loud():
+    """The backward needs the forward's slot sums: skipping vfm_elbo_finalize_f32 (and not asking the fused backward
+    to do it) yields NaN scalar gradients / scalars, never silently stale sums."""
+    dev = _dev()
+    c = Case("quirk_reg_d8")
+    ops, spec, plan, ent, bia, scal, inv_occ, eps = _setup(c, dev)
+    st = ops.elbo_forward(plan, ent, bia, scal, inv_occ, eps=eps)
+    assert st.partials[6].item() == 0.0
+    g = ops.elbo_backward(plan, st, ent, bia, scal, inv_occ, torch.ones(1, device=dev))
+    assert torch.isnan(g[2][1:]).all()                         # global_bias_mean / scale gradients
+    ops.elbo_finalize(st, scal)
+    assert st.partials[6].item() == 1.0
+    g = ops.elbo_backward(plan, st, ent, bia, scal, inv_occ, torch.ones(1, device=dev))
+    assert torch.isfinite(g[2]).all()

@@ -78,12 +78,17 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
   if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_lo == 0) {
-    b.sums[0] = (float)b.partials[VFM_P_G];       // this rank's row sums, to be summed over ranks
-    b.sums[1] = (float)b.partials[VFM_P_ALPHA];
+    // (a caller that skipped vfm_elbo_finalize_f32 gets NaN, not stale sums)
+    const bool reduced = b.partials[VFM_P_REDUCED] == 1.0;
+    b.sums[0] = reduced ? (float)b.partials[VFM_P_G] : __builtin_nanf("");   // this rank's row sums, to be summed over ranks
+    b.sums[1] = reduced ? (float)b.partials[VFM_P_ALPHA] : __builtin_nanf("");
   }
   if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T && a.row_filter != 1) {   // (last chunk of a chunked run)
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
-    const float sum_g = (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
+    // (no fold and the forward's slots never reduced -- vfm_elbo_finalize_f32 skipped --: NaN, not stale sums)
+    const bool stale = STAGE == STAGE_FULL && !fold && b.partials[VFM_P_REDUCED] != 1.0;
+    const float sum_g = stale ? __builtin_nanf("")
+                              : (STAGE == STAGE_APPLY) ? b.sums[0] : (float)(fold ? fin[VFM_P_G] : b.partials[VFM_P_G]);
     const float sum_a = (STAGE == STAGE_APPLY) ? b.sums[1]
                                                : (float)(fold ? fin[VFM_P_ALPHA] : b.partials[VFM_P_ALPHA]);
     float e0 = 0.f;

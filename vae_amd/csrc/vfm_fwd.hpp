@@ -519,7 +519,10 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
       // (pred[B + b]; NaN when an id was out of range); workgroup 0 clears the unused tail
       out.pred[a.B + blockIdx.x] = (tot[4] != 0.f) ? __builtin_nanf("") : tot[1];
     }
-    if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
+    if (blockIdx.x == 0) {
+      out.partials[7] = (double)gridDim.x;
+      out.partials[VFM_P_REDUCED] = 0.0;       // the sums [0..5] are stale until the slots are reduced
+    }
   }
   if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED) && blockIdx.x == 0)
     for (int b = gridDim.x + tid; b < VFM_MAX_FWD_BLOCKS; b += BLOCK) out.pred[a.B + b] = 0.f;

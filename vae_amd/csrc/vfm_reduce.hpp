@@ -31,6 +31,7 @@ __device__ __forceinline__ void reduce_slots_and_loss(double* __restrict__ parti
   if (threadIdx.x != 0) return;
 #pragma unroll
   for (int i = 0; i < 6; ++i) partials[i] = tot[i];
+  partials[VFM_P_REDUCED] = 1.0;
   const double m0 = scalars[1], s0 = scalars[2];
   // sigma_0 = link(s0): |s0| or softplus(s0)
   const double sg0 = (flags & VFM_FLAG_LINK_SOFTPLUS) ? fmax(s0, 0.0) + log1p(exp(-fabs(s0))) : fabs(s0);

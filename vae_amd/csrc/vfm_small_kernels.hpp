@@ -94,7 +94,10 @@ __global__ __launch_bounds__(BLOCK) void k_lik(const KArgs a, const FwdOut out) 
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
-    if (blockIdx.x == 0) out.partials[7] = (double)gridDim.x;
+    if (blockIdx.x == 0) {
+      out.partials[7] = (double)gridDim.x;
+      out.partials[VFM_P_REDUCED] = 0.0;
+    }
   }
   if (blockIdx.x == 0) {     // the KL term: the forward workgroups' shares, summed over ranks by the all-reduce
     double kl = 0.0;         // (fixed order: reproducible)
