@@ -270,7 +270,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
                             float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
                             const int32_t* rec_pos, void* stream);
-/* rec_ptr / rec_pos (both or neither): GATHER form for the entity-sharded mode -- `acc` is the raw
+/* rec_ptr / rec_pos (both or neither; rec_pos may be NULL when no record exists at all): GATHER form for the entity-sharded mode -- `acc` is the raw
  * receive buffer of the statistics all-to-all and the records of local entity li are those at positions
  * rec_pos[rec_ptr[li] .. rec_ptr[li+1]) (one per rank that had the entity in its rows); the kernel sums
  * them itself, so no dense table, no vfm_records_add_f32 pass and no atomics are needed. */

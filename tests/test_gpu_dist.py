@@ -315,3 +315,43 @@ def test_dimension_sharded_general_fields(output, tmp_path):
     assert np.array_equal(p0, p1)
     assert rel_err(p0, m._flat.cpu().numpy()) < 5e-5
     assert rel_err(np.load(tmp_path / "dg_loss_0.npy"), np.array(ref)) < 1e-5
+
+
+def _tiny_model():
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([9, 7], 2, seed=11)
+    torch.manual_seed(4)
+    m = VFM(9, 7, 8, device="cuda:0", rng_seed=2)
+    m.set_training_data(X, nb_train=10)
+    return m, X, y
+
+
+def _tiny_sharded_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import shard_rows
+    m, X, y = _tiny_model()
+    m.exchange = "sharded"
+    a, b = shard_rows(0, 2, rank, world)            # 2 rows over 3 ranks: one rank has no rows, owners without requests
+    plan = m.plan(X[a:b], y[a:b], B_global=2, process_group=dist.group.WORLD)
+    for _ in range(2):
+        loss3, _ = m.train_step(plan, lr=0.03, process_group=dist.group.WORLD)
+    m.sync_params(dist.group.WORLD)
+    np.save(os.path.join(out_dir, f"ts_params_{rank}.npy"), m._flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"ts_loss_{rank}.npy"), loss3.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_entity_sharded_more_ranks_than_rows(tmp_path):
+    """Two rows over three ranks (found by tools/fuzz_multirank.py): an empty row shard, owners nobody asks
+    anything of -- the entity-sharded step still equals the single-process one."""
+    mp.spawn(_tiny_sharded_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    m, X, y = _tiny_model()
+    plan = m.plan(X, y)
+    for _ in range(2):
+        loss3, _ = m.train_step(plan, lr=0.03)
+    assert rel_err(np.load(tmp_path / "ts_params_0.npy"), m._flat.cpu().numpy()) < 1e-5
+    assert rel_err(np.load(tmp_path / "ts_loss_0.npy"), loss3.cpu().numpy()) < 1e-5
+    assert np.array_equal(np.load(tmp_path / "ts_params_0.npy")[: m._off_scal], np.load(tmp_path / "ts_params_2.npy")[: m._off_scal])

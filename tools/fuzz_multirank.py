@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised check of the embedding-dimension-sharded step against the single-process step, several ranks
-sharing one GPU over gloo:  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1
-tools/fuzz_dims.py [n_configs] [seed]"""
+"""Randomised check of the multi-rank steps against the single-process step, several ranks sharing one GPU over
+gloo:  [EXCHANGE=dims|sharded|stats|grads] python -m torch.distributed.run --nproc-per-node 2
+--master-addr 127.0.0.1 tools/fuzz_multirank.py [n_configs] [seed]      (default: the dimension-sharded step)"""
 import os
 import sys
 
@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 from vae_amd.model import VFM
 from vae_amd.data import synthetic_triples
+from vae_amd.dist import shard_rows
 
 
 def rel(a, b):
@@ -42,21 +43,26 @@ def main():
             return m
 
         m = fresh()
-        m.exchange = "dims"
-        plan = m.plan(X, y, process_group=dist.group.WORLD)
+        m.exchange = os.environ.get("EXCHANGE", "dims")
+        if m.exchange == "dims":
+            plan = m.plan(X, y, process_group=dist.group.WORLD)          # every rank: all rows
+        else:
+            a, b = shard_rows(0, B, rank, world)                         # row blocks
+            plan = m.plan(X[a:b], y[a:b], B_global=B, process_group=dist.group.WORLD)
         losses = [m.train_step(plan, lr=0.03, process_group=dist.group.WORLD)[0].clone() for _ in range(2)]
-        m.sync_params(dist.group.WORLD)
+        if m.exchange in ("dims", "sharded"):
+            m.sync_params(dist.group.WORLD)
         if rank == 0:
             r = fresh()
             rp = r.plan(X, y)
-            ref = [r.train_step(rp, lr=0.03)[0].clone() for _ in range(2)]
+            ref = [r.train_step(rp, lr=0.03, fused=m.exchange != "grads")[0].clone() for _ in range(2)]
             e = max(rel(torch.stack(losses), torch.stack(ref)), rel(m._flat, r._flat))
             worst = max(worst, e)
             if not e < 1e-4:
                 print("MISMATCH", dict(F=F, d=d, B=B, sizes=sizes, output=output, link=link, zipf=zipf), e, flush=True)
         dist.barrier()
     if rank == 0:
-        print("world", world, "configs", n, "worst relative error", "%.3g" % worst)
+        print(os.environ.get("EXCHANGE", "dims"), "world", world, "configs", n, "worst relative error", "%.3g" % worst)
     dist.destroy_process_group()
 
 
