@@ -73,6 +73,19 @@ def main():
         tol["g_sc"] = 5e-4         # (B = 1: the alpha term (y-pred)^2/2 - 1/(2 alpha) cancels too)
         if F == 1:
             tol["g_ent"] = 0.2
+        # prediction-only launches: the same eps stream gives the training forward's predictions; eps = 0 gives
+        # the posterior-mean predictions (vfm-torch.py:248-259)
+        pplan = ops.BatchPlan(spec, plan.x, None, None)
+        pp = ops.elbo_forward(pplan, ent, bia, scal, None, seed=seed, step=step, train=False).pred
+        errs["predict"] = rel(pp.cpu().numpy(), st.pred.cpu().numpy())
+        import dataclasses
+        p1 = ops.BatchPlan(dataclasses.replace(spec, n_samples=1), plan.x, None, None)
+        p0 = ops.elbo_forward(p1, ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO).pred
+        z = O.rowwise_elbo(P, x, y.astype(np.float64), nb_occ, np.array(hi), np.array(gn), nb_train, np.zeros(1),
+                           np.zeros(T), np.zeros((T, d)), output, link=link, want_grads=False)
+        errs["predict_mean"] = rel(p0.cpu().numpy(), z["pred"])
+        tol["predict"], tol["predict_mean"] = 1e-6, 1e-4
+        worst.setdefault("predict", 0.0); worst.setdefault("predict_mean", 0.0)
         # fused backward + dense Adam (plain and scaled moment forms) vs the gradients above + the flat Adam kernel
         pr = [ent.clone(), bia.clone(), scal.clone()]
         for p_, g_ in zip(pr, (g_ent, g_bias, g_sc)):
@@ -89,9 +102,12 @@ def main():
                                    loss_out=torch.zeros(3, device=dev))       # (also reduces the forward's slots)
             key = "adam_scaled" if scaled else "adam_plain"
             sc_ok = slice(1, 3) if output == "class" else slice(0, 3)       # alpha: no gradient under Bernoulli
-            errs[key] = max(rel(e2.cpu().numpy(), pr[0].cpu().numpy()), rel(b2.cpu().numpy(), pr[1].cpu().numpy()),
-                            rel(s2[sc_ok].cpu().numpy(), pr[2][sc_ok].cpu().numpy()))
-            tol[key] = 2e-6 if F > 1 else 0.05     # (F = 1: Adam normalises that cancellation noise to +-lr)
+            # Adam's first step is -lr * sign(g): a gradient entry that is pure rounding noise (|g| ~ 1e-9 of the row's
+            # scale) may land on either side, so the check is the FRACTION of entries that differ, not the maximum
+            def frac(u, w):
+                return float(((u - w).abs() > 1e-6 * w.abs().max()).float().mean())
+            errs[key] = max(frac(e2, pr[0]), frac(b2, pr[1]), frac(s2[sc_ok], pr[2][sc_ok]))
+            tol[key] = 1e-4 if F > 1 else 0.5      # (F = 1: the whole embedding gradient is cancellation noise)
             worst.setdefault(key, 0.0)
             if os.environ.get("FUZZ_DEBUG") and errs[key] > 1e-4:
                 for nm, got, want, gg in (("ent", e2, pr[0], g_ent), ("bias", b2, pr[1], g_bias), ("scal", s2, pr[2], g_sc)):
@@ -100,6 +116,11 @@ def main():
                     print("   ", key, nm, "max diff", float(dlt[i]), "at", i, "fused", float(got.reshape(-1)[i]),
                           "unfused", float(want.reshape(-1)[i]), "grad", float(gg.reshape(-1)[i]),
                           "init", float((ent, bia, scal)[("ent", "bias", "scal").index(nm)].reshape(-1)[i]))
+                    if nm == "ent":
+                        row = i // (2 * d)
+                        print("        row", row, "col", i % (2 * d), "occurrences in batch", int((x == row).sum()),
+                              "m", float(mv[0][0].reshape(-1)[i]), "v", float(mv[1][0].reshape(-1)[i]),
+                              "row grad unfused absmax", float(g_ent[row].abs().max()))
         bad = {k: v for k, v in errs.items() if not (v < tol[k])}
         for k, v in errs.items():
             worst[k] = max(worst[k], v if np.isfinite(v) else 1e9)
