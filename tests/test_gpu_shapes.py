@@ -257,3 +257,63 @@ def test_randomised_configurations_against_oracle():
         O.adam_step(pe, r["g_entity_params"], np.zeros_like(pe), np.zeros_like(pe), 1, 0.01)
         assert rel_err(ent.cpu().numpy(), pe) < (1e-5 if F > 1 else 1e-2), tag   # (Adam normalises: sign noise at F == 1)
         assert abs(l3[0].item() - r["loss"]) / abs(r["loss"]) < 2e-5, tag
+
+
+def test_tables_beyond_4GiB_index_like_small_ones():
+    """A 6.4 GB entity table (12.5 M rows x 128 floats; with gradients / eps ~20 GB of HBM): the same batch
+    through the big table and through a compact table holding only the touched rows gives the same loss,
+    predictions and gradient rows -- byte offsets beyond 2^32 are exercised on every path (forward, backward,
+    fused Adam), untouched rows get exact zeros."""
+    from vae_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    N, M, d, B = 9_000_000, 3_500_000, 64, 40_000
+    T = N + M
+    g = torch.Generator(device="cpu").manual_seed(5)
+    users = torch.randint(0, N, (B,), generator=g)
+    users[: B // 2] = torch.randint(N - 200_000, N, (B // 2,), generator=g)      # many rows far beyond 4 GiB
+    items = N + 1 + torch.randint(0, M - 1, (B,), generator=g)                   # (id == N, the quirk id, unused)
+    x = torch.stack([users, items], 1).to(dev)
+    y = torch.randint(1, 6, (B,), generator=g).float().to(dev)
+    uniq = torch.unique(x)
+    U = int(uniq.numel())
+    nu = int((uniq < N).sum())
+    xc = torch.searchsorted(uniq, x)
+    ent = torch.randn(T, 2 * d, device=dev) * 0.3
+    bia = torch.randn(T, 2, device=dev)
+    scal = torch.tensor([0.8, 0.1, -0.9], device=dev)
+    ee = torch.randn(T, d, device=dev)
+    eb = torch.randn(T, device=dev)
+    eg = torch.randn(1, device=dev)
+    occ = torch.randint(1, 50, (T,), device=dev)
+    lik = _lib.LIK_NORMAL
+    big = ops.Spec(T=T, F=2, d=d, group_hi=(N + 1, T), group_n=(float(N), float(M)), likelihood=lik, nb_train=10 * B)
+    small = ops.Spec(T=U, F=2, d=d, group_hi=(nu, U), group_n=(float(N), float(M)), likelihood=lik, nb_train=10 * B)
+    res = []
+    for spec, xs, sel in ((big, x, None), (small, xc, uniq)):
+        pick = (lambda t: t) if sel is None else (lambda t: t[sel].contiguous())
+        e_, b_ = pick(ent), pick(bia)
+        inv = ops.inv_occ_from_counts(pick(occ))
+        plan = ops.BatchPlan(spec, xs.contiguous(), y, inv)
+        eps = (pick(ee), pick(eb), eg)
+        st = ops.elbo_forward(plan, e_, b_, scal, inv, eps=eps)
+        loss3 = ops.elbo_finalize(st, scal)
+        ge, gb, gs = ops.elbo_backward(plan, st, e_, b_, scal, inv, torch.ones(1, device=dev))
+        # fused Adam on copies of the touched rows' tables is checked through the parameters after one step
+        e2, b2, s2 = e_.clone(), b_.clone(), scal.clone()
+        mv = [(torch.zeros_like(e2), torch.zeros_like(b2), torch.zeros(3, device=dev)) for _ in range(2)]
+        st2 = ops.elbo_forward(plan, e2, b2, s2, inv, eps=eps)
+        ops.elbo_backward_adam(plan, st2, e2, b2, s2, inv, mv[0], mv[1], 0.01, 1, loss_out=torch.zeros(3, device=dev))
+        res.append((loss3.clone(), st.pred.clone(), ge, gb, gs.clone(), e2, b2))
+        del st, st2, mv
+    (lb, pb, geb, gbb, gsb, e2b, b2b), (ls, ps, ges, gbs, gss, e2s, b2s) = res
+    assert torch.allclose(lb, ls, rtol=1e-6)
+    assert torch.allclose(pb, ps, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(geb[uniq], ges, rtol=1e-5, atol=1e-5 * float(ges.abs().max()))
+    assert torch.allclose(gbb[uniq], gbs, rtol=1e-5, atol=1e-5 * float(gbs.abs().max()))
+    assert torch.allclose(gsb, gss, rtol=1e-5)
+    untouched = torch.ones(T, dtype=torch.bool, device=dev)
+    untouched[uniq] = False
+    assert not geb[untouched].any() and not gbb[untouched].any()
+    # (Adam's first step is -lr * sign(g): entries whose gradient is rounding noise may differ -- compare the bulk)
+    assert float(((e2b[uniq] - e2s).abs() > 1e-6).float().mean()) < 1e-4
+    assert torch.equal(e2b[untouched], ent[untouched])
