@@ -203,7 +203,7 @@ def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_
         mean = pred
     else:
         ll = y * pred - np.logaddexp(0.0, pred)
-        mean = 1.0 / (1.0 + np.exp(-pred))
+        mean = 0.5 * (1.0 + np.tanh(0.5 * pred))          # sigmoid, without overflow for large |pred|
         dll = y - mean
 
     kl_w = 0.5 * (sg_w ** 2 + mu_w ** 2 - 1.0) - np.log(sg_w)

@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda:0")
     worst = {"loss": 0.0, "pred": 0.0, "g_ent": 0.0, "g_bias": 0.0, "g_sc": 0.0}
     for it in range(n):
-        F = int(g.choice([1, 2, 2, 2, 3, 5, 9]))
+        F = int(g.choice([1, 2, 2, 2, 3, 5, 9, 33, 64]))
         d = int(g.choice([1, 3, 4, 5, 8, 12, 16, 20, 31, 32, 48, 64, 100, 128, 192, 256]))
         B = int(g.choice([1, 2, 7, 64, 257, 1000, 4097]))
         sizes = [int(g.integers(1, 60)) for _ in range(F)]
