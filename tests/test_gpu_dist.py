@@ -400,3 +400,53 @@ def test_dimension_sharded_checkpoint_resume_is_bit_exact(tmp_path):
     for r in range(2):
         ok, t, gs = np.load(tmp_path / f"dr_ok_{r}.npy")
         assert ok == 1 and t == 5 and gs == 5
+
+
+def _switch_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    from vae_amd.dist import shard_rows
+    X, y = synthetic_triples([70, 50], 600, seed=12)
+    pg = dist.group.WORLD
+    torch.manual_seed(3)
+    m = VFM(70, 50, 32, device="cuda:0", rng_seed=21)
+    m.set_training_data(X, nb_train=600)
+    m.lr = 0.04
+    a, b = shard_rows(0, 600, rank, world)
+    for mode in ("sharded", "dims", "stats", "dims", "sharded", "grads"):      # two steps each
+        m.exchange = mode
+        plan = (m.plan(X, y, process_group=pg) if mode == "dims"
+                else m.plan(X[a:b], y[a:b], B_global=600, process_group=pg))
+        for _ in range(2):
+            loss3, _ = m.train_step(plan, process_group=pg)
+    if m._stale_group is not None:
+        m.sync_params(pg)
+    m._set_moment_form(False)
+    np.save(os.path.join(out_dir, f"sw_{rank}.npy"), torch.cat([m._flat, m._adam_m, m._adam_v]).cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_switching_exchange_modes_mid_training(tmp_path):
+    """Changing VFM.exchange between steps (sharded -> dims -> stats -> dims -> sharded -> grads) keeps training the
+    same model: parameters AND Adam moments are gathered when the mode that left them stale is left."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    mp.spawn(_switch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    X, y = synthetic_triples([70, 50], 600, seed=12)
+    torch.manual_seed(3)
+    m = VFM(70, 50, 32, device="cuda:0", rng_seed=21)
+    m.set_training_data(X, nb_train=600)
+    m.lr = 0.04
+    plan = m.plan(X, y)
+    for _ in range(12):
+        m.train_step(plan)
+    m._set_moment_form(False)
+    want = torch.cat([m._flat, m._adam_m, m._adam_v]).cpu().numpy()
+    g0, g1 = np.load(tmp_path / "sw_0.npy"), np.load(tmp_path / "sw_1.npy")
+    n = m._n_flat
+    assert rel_err(g0[:n], want[:n]) < 1e-4 and rel_err(g1[:n], want[:n]) < 1e-4
+    assert rel_err(g0[n:2 * n], want[n:2 * n]) < 1e-3 and rel_err(g0[2 * n:], want[2 * n:]) < 1e-3
+    assert np.allclose(g0, g1, rtol=1e-5, atol=1e-6 * np.abs(g0).max())

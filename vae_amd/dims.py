@@ -163,5 +163,5 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     ops.elbo_backward_adam(lp, bw, ent, bia, scal, model.inv_occ, st.views(st.m), st.views(st.v), lr, model._adam_t,
                            loss_out=loss3, sparse=model.sparse_adam, scaled_moments=scaled)
     mark("bwd_adam")
-    model._stale_group = st.group          # the full tables are stale until sync_params()
+    model._stale_group, model._stale_kind = st.group, "dims"      # the full tables are stale until sync_params()
     return loss3, vals[: plan.B]

@@ -345,14 +345,16 @@ class VFM(nn.Module):
     def sync_params(self, process_group):
         """Entity-sharded mode: refresh the parameter rows owned by the other ranks (all-gather).
         Dimension-sharded mode: assemble the full tables (and Adam moments) from the ranks' slices."""
-        if self.exchange == "dims":
+        kind = getattr(self, "_stale_kind", None) or self.exchange      # what made the full tables stale
+        if kind == "dims":
             if getattr(self, "_dims", None) is not None:
                 self._dims.gather(self)
-            self._stale_group = None
+            self._stale_group = self._stale_kind = None
             return
         from .sharded import sync_params
         sync_params(self, process_group, torch.distributed.get_rank(process_group),
                     torch.distributed.get_world_size(process_group))
+        self._stale_kind = None
 
     @torch.no_grad()
     def save_weights(self):
@@ -435,6 +437,11 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
+        # a step in another mode than the one that left the full tables stale: bring them up to date first
+        if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_kind", None) not in (
+                None, self.exchange if process_group is not None else "single"):
+            self.sync_params(self._stale_group)
+            self._dims = None
         if process_group is not None and self.exchange == "dims":
             from .dims import train_step_dims
             if not adam or out_pred is not None:

@@ -184,7 +184,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     _lib.ops().shard_loss(small, loss3)
-    model._stale_group = plan.group      # rows owned by other ranks are stale until sync_params()
+    model._stale_group, model._stale_kind = plan.group, "sharded"   # rows owned by other ranks are stale until sync_params()
     return loss3, pred
 
 
@@ -196,18 +196,21 @@ class _OwnPlan:
 
 
 def sync_params(model, group, rank: int, world: int):
-    """Refresh the rows this rank does not own (all-gather of the owned rows).  Plumbing only:
-    strided copies + one collective."""
+    """Refresh the rows this rank does not own (all-gather of the owned rows) -- parameters and, when they
+    exist, the Adam moments, so that a checkpoint taken on any rank is complete.  Plumbing only: strided
+    copies + collectives."""
     T = model.T
-    ent, bia, _ = model._views(model._flat)
-    for tab in (ent, bia):
-        mx = owned_rows(T, 0, world)
-        mine = torch.zeros(mx, tab.shape[1], dtype=tab.dtype, device=tab.device)
-        own = tab[rank::world]
-        mine[: own.shape[0]] = own
-        out = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(out, mine, group=group)
-        for s in range(world):
-            n = owned_rows(T, s, world)
-            tab[s::world] = out[s][:n]
+    flats = [model._flat] + ([model._adam_m, model._adam_v] if model._adam_m is not None else [])
+    for flat in flats:
+        ent, bia, _ = model._views(flat)
+        for tab in (ent, bia):
+            mx = owned_rows(T, 0, world)
+            mine = torch.zeros(mx, tab.shape[1], dtype=tab.dtype, device=tab.device)
+            own = tab[rank::world]
+            mine[: own.shape[0]] = own
+            out = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(out, mine, group=group)
+            for s in range(world):
+                n = owned_rows(T, s, world)
+                tab[s::world] = out[s][:n]
     model._stale_group = None
