@@ -196,7 +196,7 @@ def main():
             model._flat.copy_(init)
             model._adam_m.zero_(); model._adam_v.zero_()
             model._adam_t, model.global_step, model._stale_group, model._moments_scaled = 0, 0, None, False
-            model._dims = None
+            model._dims = model._stale_kind = None
 
         tune, built = {}, {}
         table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)

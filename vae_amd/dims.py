@@ -81,11 +81,12 @@ class DimsState:
             e, b, s = self.views(mine)
             e.copy_(self._cols(ent)); b.copy_(bia); s.copy_(scal)
 
-    def gather(self, model):
-        """Assemble the full tables (parameters and Adam moments) on every rank: all-gather of the entity
-        slices, first-order weights from rank 0, scalars as they are (replicated)."""
+    def gather(self, model, moments: bool = True):
+        """Assemble the full tables (parameters and, unless `moments` is False, the Adam moments) on every rank:
+        all-gather of the entity slices, first-order weights from rank 0, scalars as they are (replicated)."""
         d, dl = self.d, self.dl
-        for mine, full in ((self.flat, model._flat), (self.m, model._adam_m), (self.v, model._adam_v)):
+        pairs = [(self.flat, model._flat)] + ([(self.m, model._adam_m), (self.v, model._adam_v)] if moments else [])
+        for mine, full in pairs:
             ent, bia, scal = model._views(full)
             e, b, s = self.views(mine)
             parts = [torch.empty_like(e) for _ in range(self.world)]
@@ -163,5 +164,5 @@ def train_step_dims(model, plan: ops.BatchPlan, lr: float, group, eps=None, mark
     ops.elbo_backward_adam(lp, bw, ent, bia, scal, model.inv_occ, st.views(st.m), st.views(st.v), lr, model._adam_t,
                            loss_out=loss3, sparse=model.sparse_adam, scaled_moments=scaled)
     mark("bwd_adam")
-    model._stale_group, model._stale_kind = st.group, "dims"      # the full tables are stale until sync_params()
+    model._mark_stale(st.group, "dims")            # the full tables are stale until sync_params()
     return loss3, vals[: plan.B]

@@ -315,8 +315,7 @@ class VFM(nn.Module):
         a fresh posterior sample; last/mean logits are the deterministic predictions from the last /
         epoch-averaged posterior means once `save_weights()` has run (None before).  The KL branch
         is not evaluated on inference inputs (kl_term is None)."""
-        if getattr(self, "_stale_group", None) is not None:
-            self.sync_params(self._stale_group)      # entity-sharded training: collective, every rank calls it
+        self._fresh_params()      # sharded training modes: collective, every rank calls it
         plan = self.plan(x, None) if not isinstance(x, ops.BatchPlan) else x
         ent, bia, scal = self._views(self._flat)
         step = self.global_step
@@ -342,24 +341,36 @@ class VFM(nn.Module):
             self._dims = DimsState(self, group)
         return self._dims
 
-    def sync_params(self, process_group):
-        """Entity-sharded mode: refresh the parameter rows owned by the other ranks (all-gather).
-        Dimension-sharded mode: assemble the full tables (and Adam moments) from the ranks' slices."""
+    def sync_params(self, process_group, moments: bool = True):
+        """Entity-sharded mode: refresh the rows owned by the other ranks (all-gather).  Dimension-sharded mode:
+        assemble the full tables from the ranks' slices.  `moments=False` gathers the parameters only (enough for
+        predict / save_weights; the tables then still count as stale for checkpoints and mode switches)."""
         kind = getattr(self, "_stale_kind", None) or self.exchange      # what made the full tables stale
         if kind == "dims":
             if getattr(self, "_dims", None) is not None:
-                self._dims.gather(self)
+                self._dims.gather(self, moments=moments)
+        else:
+            from .sharded import sync_params
+            sync_params(self, process_group, torch.distributed.get_rank(process_group),
+                        torch.distributed.get_world_size(process_group), moments=moments)
+        self._stale_params = False
+        if moments:
+            self._stale_moments = False
             self._stale_group = self._stale_kind = None
-            return
-        from .sharded import sync_params
-        sync_params(self, process_group, torch.distributed.get_rank(process_group),
-                    torch.distributed.get_world_size(process_group))
-        self._stale_kind = None
+
+    def _mark_stale(self, group, kind):
+        """A multi-rank step that trains slices / owned rows leaves the full buffers of this rank stale."""
+        self._stale_group, self._stale_kind = group, kind
+        self._stale_params = self._stale_moments = True
+
+    def _fresh_params(self):
+        """Collective (every rank together): gather the parameters if a sharded mode left them stale."""
+        if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_params", True):
+            self.sync_params(self._stale_group, moments=False)
 
     @torch.no_grad()
     def save_weights(self):
-        if getattr(self, "_stale_group", None) is not None:
-            self.sync_params(self._stale_group)
+        self._fresh_params()
         self._save_weights()
 
     @torch.no_grad()
@@ -572,9 +583,7 @@ class VFM(nn.Module):
                 losses[i] = loss3[0]
             # ---- end of epoch (vfm-torch.py:378-384)
             if self.output == "reg":
-                if world > 1 and self.exchange in ("sharded", "dims"):
-                    self.sync_params(process_group)
-                self.save_weights()
+                self.save_weights()          # (sharded modes: gathers the parameters first)
             if epoch % display_every == 0:
                 rec = {"epoch": epoch, "elbo": float(losses.mean())}
                 tp = train_pred
@@ -587,8 +596,6 @@ class VFM(nn.Module):
                 else:
                     rec["train_auc"], rec["train_map"] = _auc_map(yd, torch.sigmoid(tp))
                 if X_test is not None:
-                    if world > 1 and self.exchange in ("sharded", "dims"):
-                        self.sync_params(process_group)        # rows owned by other ranks are stale
                     rec["test"] = self.evaluate(X_test, y_test)
                 hist["epoch"].append(epoch)
                 hist["elbo"].append(rec["elbo"])

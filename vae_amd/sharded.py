@@ -184,7 +184,7 @@ def train_step_sharded(model, plan: ShardedPlan, lr: float, eps=None, out_pred=N
     mark("apply_adam")
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     _lib.ops().shard_loss(small, loss3)
-    model._stale_group, model._stale_kind = plan.group, "sharded"   # rows owned by other ranks are stale until sync_params()
+    model._mark_stale(plan.group, "sharded")      # rows owned by other ranks are stale until sync_params()
     return loss3, pred
 
 
@@ -195,12 +195,12 @@ class _OwnPlan:
         self.spec, self.W = spec, W
 
 
-def sync_params(model, group, rank: int, world: int):
+def sync_params(model, group, rank: int, world: int, moments: bool = True):
     """Refresh the rows this rank does not own (all-gather of the owned rows) -- parameters and, when they
     exist, the Adam moments, so that a checkpoint taken on any rank is complete.  Plumbing only: strided
     copies + collectives."""
     T = model.T
-    flats = [model._flat] + ([model._adam_m, model._adam_v] if model._adam_m is not None else [])
+    flats = [model._flat] + ([model._adam_m, model._adam_v] if (moments and model._adam_m is not None) else [])
     for flat in flats:
         ent, bia, _ = model._views(flat)
         for tab in (ent, bia):
@@ -213,4 +213,3 @@ def sync_params(model, group, rank: int, world: int):
             for s in range(world):
                 n = owned_rows(T, s, world)
                 tab[s::world] = out[s][:n]
-    model._stale_group = None
