@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: random (F, d, B, T, likelihood, link, S, id width, skew) configurations,
 kernels (Philox eps dumped and fed to the oracle) vs the fp64 row-wise oracle -- loss, predictions, every gradient.
-usage: tools/fuzz_parity.py [n_configs] [seed]      (test infrastructure: imports oracle/)"""
+usage: python tests/fuzz_parity.py [n_configs] [seed]      (test infrastructure: checks against oracle/; not
+collected by pytest -- the fixed-seed cases of test_gpu_*.py are the suite)"""
 import os
 import sys
 
