@@ -61,10 +61,14 @@ def main():
                          "(SURVEY cfg4); default is weak scaling, --batch rows per rank")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--sync-each-step", action="store_true", help="debug: host sync after every step")
     ap.add_argument("--unfused", action="store_true", help="separate backward and Adam kernels (as N>1 does)")
+    ap.add_argument("--fwd-eps", default="philox", choices=["philox", "table"],
+                    help="A/B: eps of the forward / backward from tables (one fixed draw, as the parity tests feed "
+                         "the reference's recorded draws) instead of the in-kernel Philox stream")
+    ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
     ap.add_argument("--plain-moments", action="store_true",
                     help="A/B: keep the Adam moments in the plain form (no VFM_FLAG_SCALED_MOMENTS)")
     args = ap.parse_args()
@@ -91,6 +95,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
+
+    # what the collective library itself reports: N ranks, and a 1-element all-reduce that must give N
+    comm_check = None
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one, group=pg)
+        comm_check = {"backend": backend, "world_size": dist.get_world_size(pg), "allreduce_of_ones": float(one.item())}
+        assert comm_check["world_size"] == world and comm_check["allreduce_of_ones"] == float(world), comm_check
 
     from vae_amd.model import VFM
     from vae_amd.data import synthetic_triples
@@ -137,8 +149,14 @@ def main():
             Xg, yg = Xg.contiguous(), yg.contiguous()
         return Xg, yg
 
+    plan_build = {}
+
     def build_plans():
-        ps, us = [], []
+        """The per-batch work OUTSIDE the timed step: batch normalisers W (k_norms), the inverted index
+        (vfm_build_index: radix sort) and its one readback.  The reference pays torch.unique x3 inside every
+        step (vfm-torch.py:190-192); here a plan is built once per batch and reused every epoch (the loader
+        does not shuffle, :121-122), so its cost is reported separately and amortised over the 50 epochs."""
+        ps, us, batches = [], [], []
         dims = world > 1 and model.exchange == "dims"
         Bp = B * world if dims else B
         Xs, ys = global_rows() if dims else (X, y)
@@ -147,13 +165,23 @@ def main():
             if not args.no_sort:
                 o = torch.argsort(xb[:, -1], stable=True)
                 xb, yb = xb[o].contiguous(), yb[o].contiguous()
-            p = model.plan(xb, yb, B_global=B * world, process_group=pg)
-            ps.append(p)
+            batches.append((xb, yb))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for xb, yb in batches:
+            ps.append(model.plan(xb, yb, B_global=B * world, process_group=pg))
+        torch.cuda.synchronize()
+        plan_build[model.exchange if world > 1 else "single"] = (time.perf_counter() - t0) / nbt * 1e3
+        for p in ps:
             us.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
         return ps, us
 
     events = []
     plans = uniq = None
+    eps_tables = None
+    if args.fwd_eps == "table":
+        from vae_amd import ops as _ops
+        eps_tables = _ops.philox_eps(model.spec(), seed=1, step=1, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,7 +208,7 @@ def main():
                     ev[name] = e
             else:
                 mark = None
-            model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused)
+            model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables)
             if args.sync_each_step:
                 torch.cuda.synchronize()
 
@@ -201,7 +229,10 @@ def main():
         tune, built = {}, {}
         table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
         from vae_amd.dims import supported as dims_supported
-        cands = (("dims",) if dims_supported(d, world) else ()) + (("sharded", "stats") if table_bytes >= (4 << 20) else ("stats",))
+        # "grads" is the north star's literal pattern (row-sharded batch + ONE all-reduce of [gradients | loss]);
+        # every candidate's time is reported in config.exchange_autotune_ms_per_step
+        cands = ("grads", "stats") + (("sharded",) if table_bytes >= (4 << 20) else ()) + (
+            ("dims",) if dims_supported(d, world) else ())
         for mode in cands:
             model.exchange = mode
             try:
@@ -261,6 +292,40 @@ def main():
         roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
         roof["frac_of_box_stream_copy"] = round(roof["achieved"] / copy_gbs, 4)
 
+    # ---- regions of SURVEY 8(d): F = forward only, K = forward + loss + backward kernels (no optimizer), S = the
+    # full step.  The timed step fuses the backward with Adam, so K comes from a short run of the UNFUSED step
+    # (separate k_bwd writing the dense gradient, then k_adam) after the timed region.
+    regions = None
+    if world == 1 and kern and not args.unfused and not args.no_regions:
+        ev_main = events
+        events = []
+        for s_ in range(5):
+            model.train_step(plans[s_ % nbt], fused=False, eps=eps_tables)
+        nreg = min(40, max(10, args.steps))
+        for s_ in range(nreg):
+            ev = {}
+            events.append(ev)
+
+            def mark(name, ev=ev):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev[name] = e
+            model.train_step(plans[s_ % nbt], fused=False, mark=mark, eps=eps_tables)
+        torch.cuda.synchronize()
+        order = list(events[0].keys())
+        acc = {k: 0.0 for k in order[1:]}
+        for ev in events:
+            for a_, b_ in zip(order[:-1], order[1:]):
+                acc[b_] += ev[a_].elapsed_time(ev[b_])
+        un = {k: v / len(events) * 1e3 for k, v in acc.items()}
+        regions = {"F_us": kern["fwd"]["avg_us"], "K_us": round(un["fwd"] + un["finalize"] + un["bwd"], 2),
+                   "S_us": round(dt / args.steps * 1e6, 2),
+                   "K_triples_per_s": round(B / ((un["fwd"] + un["finalize"] + un["bwd"]) * 1e-6), 1),
+                   "unfused_step_us": {k: round(v, 2) for k, v in un.items()},
+                   "note": "F and S from the timed region; K = k_fwd + k_finalize + k_bwd (dense gradient written) of "
+                           "%d unfused steps run after it" % nreg}
+        events = ev_main
+
     # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -277,7 +342,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
                        "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
-                       "ids": "int32" if args.id32 else "int64", "eps": "philox-in-kernel",
+                       "ids": "int32" if args.id32 else "int64",
+                       "eps": "philox-in-kernel" if eps_tables is None else "tables (fixed draw, A/B)",
                        "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
@@ -295,7 +361,11 @@ def main():
                        "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
                                        f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
                        else f"row-sharded dp{world}"},
-            "roofline": roof, "kernels": kern, "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
+            "roofline": roof, "kernels": kern, "regions": regions,
+            "plan_build_ms_per_batch": {k: round(v, 4) for k, v in plan_build.items()},
+            "plan_build_amortised_us_per_step_at_50_epochs": {k: round(v * 1e3 / 50, 3) for k, v in plan_build.items()},
+            "comm_check": comm_check,
+            "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
         }
         print(json.dumps(out))
     if world > 1:
@@ -339,7 +409,10 @@ def kernel_report(events, model, args, world, B, d, F, U):
                "sample_a2a": U * (8 * d + 8) + 2 * 4.0 * U * (d + 4), "acc_a2a": B * F * (4 * d + 8) + 2 * 4.0 * U * (d + 4),
                "apply_adam": 24.0 * n_params / max(world, 1) + 4.0 * U * (d + 4)}
         alg["allreduce"] = 4.0 * n_params
-        names = {"fwd": "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
+        fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and not dims_mode and \
+            os.environ.get("VFM_FWD_KERNEL", "2") != "1"
+        names = {"fwd": "k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "
+                        "once per run)" if fwd2 else "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",
@@ -396,32 +469,57 @@ def stream_copy_rate(dev):
 
 
 def cpu_baseline(sizes, d, B, nb_train, output, plan, occ, budget_s):
-    """Time the oracle's reference-shaped step (same op graph as vfm-torch.py:189-324,359,368-370)
-    on the host cores: one warm-up step, then steps until ~budget_s seconds are used."""
+    """Time the oracle's reference-shaped step (same op graph as vfm-torch.py:189-324,359,368-370) on the host
+    cores.  torch's intra-op threading does not scale to all logical CPUs of the node for this op mix, so the
+    thread count is swept (one warm-up + two steps each) and the best count is then timed for the rest of the
+    budget: the reported value is the best the host does, with the count stated."""
     import torch
     from oracle import vfm_oracle as O
     if len(sizes) != 2:
         return None
     N, M = sizes
-    torch.manual_seed(42)
-    P = O.make_params(N + M, d)
-    opt = torch.optim.Adam(list(P.values()), lr=1.0 / (1 + nb_train // B))
     x = plan.x.to(torch.int64).cpu()
     y = plan.y.cpu()
     occ_c = occ.cpu()
-    O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)       # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 50:
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
+
+    def fresh():
+        torch.manual_seed(42)
+        P = O.make_params(N + M, d)
+        return P, torch.optim.Adam(list(P.values()), lr=1.0 / (1 + nb_train // B))
+
+    def time_steps(P, opt, n_max, budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= n_max:
+                return n, el
+
+    keep = torch.get_num_threads()
+    sweep = {}
+    for nt in sorted({t for t in (8, 16, 32, 64, ncpu // 2, ncpu) if 1 <= t <= ncpu}):
+        if time.perf_counter() - t_start > 0.6 * budget_s and sweep:
             break
-    return {"value": round(n * B / el, 1), "unit": "triples/s", "cores": torch.get_num_threads(),
+        torch.set_num_threads(nt)
+        P, opt = fresh()
+        O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)       # warm-up
+        n, el = time_steps(P, opt, 2, 1e9)
+        sweep[nt] = round(n * B / el, 1)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    P, opt = fresh()
+    O.reference_shaped_step(P, opt, x, y, occ_c, N, M, nb_train, output)           # warm-up
+    n, el = time_steps(P, opt, 50, max(2.0, budget_s - (time.perf_counter() - t_start)))
+    torch.set_num_threads(keep)
+    return {"value": round(n * B / el, 1), "unit": "triples/s", "cores": best,
             "kind": "port", "ms_per_step": round(el / n * 1e3, 2),
+            "thread_sweep_triples_per_s": {str(k): v for k, v in sweep.items()},
             "sample": f"{n} full steps (fwd+loss+bwd+Adam) of the same batch shape B={B}, d={d}, "
-                      f"T={N + M} with the torch-CPU reference-shaped restatement "
-                      f"(oracle/vfm_oracle.py), after 1 warm-up step; host has {os.cpu_count()} logical CPUs"}
+                      f"T={N + M} with the torch-CPU reference-shaped restatement (oracle/vfm_oracle.py) on the "
+                      f"best thread count of a sweep (1 warm-up + 2 steps per count); host has {ncpu} logical CPUs"}
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define VFM_ABI_VERSION 2
+#define VFM_ABI_VERSION 3
 #define VFM_MAX_FIELDS 64
 
 #define VFM_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported size)   */
@@ -148,12 +148,15 @@ typedef struct vfm_problem {
 
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
  *   occ_ptr [T+1] offsets into occ_rows [B*F] (row numbers sorted by entity id, stable).
- * Long lists (skewed data: a popular item can own 10% of the rows) would serialise on one lane group,
- * so entities with more than VFM_HEAVY_LIST occurrences (any threshold >= VFM_HEAVY_MIN works: the
- * kernels look an entity up in `heavy_ids` whenever its list is longer than VFM_HEAVY_MIN) are also
- * listed in `heavy_ids` (sorted) and their lists cut in work items `heavy_items` [n_items,4] =
- * (slot in heavy_ids, begin, end, 0) of about that many occurrences; every backward call first reduces them into the scratch table
- * `heavy_acc` [n_samples, n_heavy, 4 + round4(d)] (overwritten per call).  n_heavy == 0: all three may be NULL. */
+ * Long lists (skewed data: a popular item can own 10% of the rows; small tables: every entity in dozens of
+ * rows) would serialise on one lane group, so entities with more occurrences than the index's heavy-list
+ * length (any length >= VFM_HEAVY_MIN works: the kernels look an entity up in `heavy_ids` whenever its list is
+ * longer than VFM_HEAVY_MIN) are also listed in `heavy_ids` (sorted) and their lists cut in work items
+ * `heavy_items` [n_items,4] = (slot in heavy_ids, begin, end, 0) of at most that many occurrences, in list
+ * order (vfm_build_index makes all of this).  Every backward call first reduces the work items (one lane
+ * group each, plain stores) and then adds each entity's items in order -- no atomics, a fixed summation order --
+ * in the scratch table `heavy_acc` [n_samples, n_heavy + n_items, 4 + round4(d)] (overwritten per call).
+ * n_heavy == 0: all three may be NULL. */
 #define VFM_HEAVY_LIST 64
 #define VFM_HEAVY_MIN 8
 typedef struct vfm_index {
@@ -168,6 +171,23 @@ typedef struct vfm_index {
 
 int vfm_abi_version(void);
 const char* vfm_last_error(void);
+
+/* Builds the inverted index of one batch on the GPU (what the reference gets from torch.unique(x,
+ * return_inverse, return_counts), vfm-torch.py:190-192, restated as entity -> rows): a stable radix sort
+ * of the B*F (entity id, position) pairs -- an entity's rows keep their row order, so every sum the
+ * backward forms over them has a fixed order.  Launch-only, no atomics between workgroups.
+ *   x         [B,F] ids (id_bits 32 or 64)
+ *   ws        workspace of vfm_index_workspace_bytes(B, F, T) bytes (16-byte aligned), scratch
+ *   occ_ptr   [T+1], occ_rows [B*F]                       (vfm_index_t)
+ *   heavy_list  entities with MORE occurrences than this get an entry in heavy_ids (id order) and
+ *             ceil(count / heavy_list) work items (slot, begin, end, 0) in heavy_items [cap_items,4];
+ *             capacities that always suffice: cap_heavy = B*F / heavy_list + 1, cap_items = 2*B*F / heavy_list + 2
+ *   counts    [4] int32, DEVICE: (ids outside [0,T) met -- they are indexed as id 0, like the forward
+ *             clamps them --, n_heavy, n_items, 0): the caller reads them back once to fill vfm_index_t */
+int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
+int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
+                    int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
+                    int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream);
 
 /* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
  * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */

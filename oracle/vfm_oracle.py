@@ -119,6 +119,30 @@ def reference_shaped_step(P, opt, x, y, nb_occ, N, M, nb_train, output="reg", ep
     return loss.detach(), lik.mean.detach()
 
 
+class SavedWeights:
+    """`CF.save_weights` (vfm-torch.py:179-185): snapshots of the posterior MEANS (global bias,
+    first-order weights, embeddings) appended once per epoch, and their mean over the snapshots."""
+
+    def __init__(self):
+        self.g, self.b, self.e = [], [], []
+
+    def save(self, P):
+        d = P["entity_params"].shape[1] // 2
+        self.g.append(P["global_bias_mean"].detach().numpy().copy())
+        self.b.append(P["bias_params"][:, 0].detach().numpy().copy())
+        self.e.append(P["entity_params"][:, :d].detach().numpy().copy())
+
+    def logits(self, x):
+        """(last_logits, mean_logits) of rows x [B,2] (vfm-torch.py:248-259): deterministic
+        predictions from the last snapshot and from the mean of all snapshots."""
+        x = np.asarray(x)
+        out = []
+        for g, b, e in ((self.g[-1], self.b[-1], self.e[-1]),
+                        (np.array(self.g).mean(axis=0), np.array(self.b).mean(axis=0), np.array(self.e).mean(axis=0))):
+            out.append(g + b[x].sum(axis=1).squeeze() + e[x].prod(axis=1).sum(axis=1))
+        return out[0], out[1]
+
+
 # --------------------------------------------------------------------------
 # (b) row-wise float64 restatement (what the HIP kernels compute)
 # --------------------------------------------------------------------------

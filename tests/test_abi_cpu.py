@@ -32,14 +32,42 @@ def test_problem_struct_layout_matches_header(tmp_path):
     from vae_amd._lib import Problem
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_problem_t), offsetof(vfm_problem_t, F),'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_problem_t), offsetof(vfm_problem_t, F),'
                    'offsetof(vfm_problem_t, group_hi), offsetof(vfm_problem_t, group_n), offsetof(vfm_problem_t, seed),'
-                   'offsetof(vfm_problem_t, e_lo));return 0;}\n')
+                   'offsetof(vfm_problem_t, e_lo), offsetof(vfm_problem_t, flags), offsetof(vfm_problem_t, n_samples),'
+                   'offsetof(vfm_problem_t, coord_off));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert got == [C.sizeof(Problem), Problem.F.offset, Problem.group_hi.offset, Problem.group_n.offset,
-                   Problem.seed.offset, Problem.e_lo.offset]
+                   Problem.seed.offset, Problem.e_lo.offset, Problem.flags.offset, Problem.n_samples.offset,
+                   Problem.coord_off.offset]
+
+
+def test_problem_mirror_has_every_header_field_and_rejects_unknown_names():
+    """Every member of vfm_problem_t is a ctypes field of the same name (ctypes would otherwise keep an
+    assignment as a plain Python attribute and pass 0 to the library), and a flag set through the mirror
+    reaches the library."""
+    from vae_amd import _lib, ops
+    hdr = open(os.path.join(ROOT, "include", "vfm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct vfm_problem {"): hdr.index("} vfm_problem_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    members = []
+    for decl in re.findall(r"\b(?:u?int(?:32|64)_t|double)\s+([^;]+);", body):
+        members += [re.sub(r"\[.*\]", "", m).strip() for m in decl.split(",")]
+    assert members == [n for n, _ in _lib.Problem._fields_]
+    p = _lib.Problem()
+    with pytest.raises(AttributeError):
+        p.flagz = 3
+    # everything ops._problem sets is a real field, and a non-zero flag is seen by the C side
+    spec = ops.Spec(T=10, F=2, d=8, group_hi=(5, 10), group_n=(5.0, 5.0), likelihood=0, n_samples=2)
+    q = ops._problem(spec, 4, 4, 64, flags=ops.FLAG_PARTIAL_PRED)
+    assert q.flags == ops.FLAG_PARTIAL_PRED and q.n_samples == 2
+    lib = _lib.load()
+    assert lib.vfm_elbo_fwd_f32(C.byref(q), *([None] * 15)) == -2      # rejected BECAUSE of the flag (S > 1)
+    assert b"VFM_FLAG_PARTIAL_PRED" in lib.vfm_last_error()
+    q.flags = 0
+    assert lib.vfm_elbo_fwd_f32(C.byref(q), *([None] * 15)) == -1      # same call without it: NULL pointers
 
 
 def test_bad_arguments_return_errors_not_crashes():

@@ -53,6 +53,7 @@ def _worker(rank, world, port, name, out_dir, exchange="stats"):
 
 
 @pytest.mark.parametrize("name,exchange", [("ml100k_reg_d20", "stats"), ("ml100k_reg_d20", "grads"),
+                                           ("ml20m_reg_d128", "stats"), ("ml20m_reg_d128", "grads"),   # cfg4's shape (d = 128, ML-20M ids)
                                            ("softplus_reg_d8", "stats"),
                                            ("multi_reg_d8_s3", "auto"),             # S > 1: falls back to "grads"
                                            ("softplus_multi_class_d8_s2", "auto")])
@@ -248,9 +249,10 @@ def _dims_fit_worker(rank, world, port, out_dir):
     X, y = synthetic_triples([60, 50], 3000, seed=4)
     torch.manual_seed(1)
     m = VFM(60, 50, 16, device="cuda:0", rng_seed=5)
+    m.exchange = "dims"                        # opt-in ("auto" = the row-sharded "stats" exchange)
     h = m.fit(X[:2400], y[:2400], n_epochs=3, batch_size=1000, X_test=X[2400:], y_test=y[2400:], verbose=False,
               process_group=dist.group.WORLD)
-    assert m.exchange == "dims"                # "auto" picks it: 16 % (8 * 2) == 0
+    assert m.exchange == "dims"
     np.save(os.path.join(out_dir, f"df_elbo_{rank}.npy"), np.array(h["elbo"]))
     np.save(os.path.join(out_dir, f"df_rmse_{rank}.npy"), np.array([t["rmse_of_mean"] for t in h["test"]]))
     np.save(os.path.join(out_dir, f"df_params_{rank}.npy"), m._flat.cpu().numpy())

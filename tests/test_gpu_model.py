@@ -112,6 +112,88 @@ def test_trajectory_train_step_and_torch_adam():
             assert rel_err(got, z["pT_" + k]) < 2e-3, (mode, k)
 
 
+@pytest.mark.parametrize("name", ["eval_reg_d16", "eval_class_d16_s2"])
+def test_eval_block_vs_reference(name):
+    """The end-of-epoch block of vfm-torch.py:378-417 against the reference's own run (tools/make_golden.py):
+    train with the recorded draws, `save_weights()` per epoch ('reg'), then `model(X_test)` -- the sampled
+    prediction with the recorded test-time draws, `last_logits` / `mean_logits` (the EPS_ZERO launches on the
+    last / epoch-averaged posterior means, :248-259) and the four predictors of `predict()` (:402-417)."""
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    from vae_amd.model import VFM
+    N, M, d, output = int(z["N"]), int(z["M"]), int(z["d"]), str(z["output"])
+    S = int(z["n_samples"]) if "n_samples" in z.files else 1
+    nb, B, lr = int(z["nb_train"]), int(z["batch"]), float(z["lr"])
+    X, Y, xt = torch.tensor(z["x"]), torch.tensor(z["y"]), torch.tensor(z["x_test"])
+    torch.manual_seed(42)
+    m = VFM(N, M, d, output=output, device=dev, n_samples=S)
+    for k in PARAM_KEYS:
+        assert np.array_equal(dict(m.state_dict())[k if "params" not in k else k + ".weight"].cpu().numpy(), z["p0_" + k])
+    m.set_training_data(X, nb_train=nb)
+    T = N + M
+
+    def tables(prefix):
+        lead = () if S == 1 else (S,)
+        ev, ew = torch.zeros(*lead, T, d), torch.zeros(*lead, T)
+        u = torch.tensor(z[prefix + "_uniq"])
+        ev[..., u, :] = torch.tensor(z[prefix + "_eps_v"])
+        ew[..., u] = torch.tensor(z[prefix + "_eps_w"])
+        return ev.to(dev), ew.to(dev), torch.tensor(z[prefix + "_eps0"]).to(dev)
+
+    step, all_preds = 0, []
+    for epoch in range(int(z["n_epochs"])):
+        for lo in range(0, nb, B):
+            loss3, _ = m.train_step(m.plan(X[lo:lo + B], Y[lo:lo + B]), lr=lr, eps=tables(f"s{step}"))
+            assert abs(loss3[0].item() - z["losses"][step]) / abs(z["losses"][step]) < 1e-4, step
+            step += 1
+        if output == "reg":
+            m.save_weights()                                     # vfm-torch.py:380
+        lik, last, mean, kl = m.forward(xt, eps=tables(f"e{epoch}"))
+        want = z[f"e{epoch}_pred"]
+        assert kl is None
+        assert rel_err(lik.mean.cpu().numpy().reshape(want.shape), want) < 2e-3, epoch
+        if output == "reg":
+            assert rel_err(last.cpu().numpy(), z[f"e{epoch}_last_logits"]) < 2e-3
+            assert rel_err(mean.cpu().numpy(), z[f"e{epoch}_mean_logits"]) < 2e-3
+            out = m.predict(xt, eps=tables(f"e{epoch}"))         # :402-417
+            y_pred = np.clip(want, 1, 5)
+            all_preds.append(y_pred)
+            assert rel_err(out["y_pred"].cpu().numpy(), y_pred) < 2e-3
+            assert rel_err(out["mean_pred"].cpu().numpy(), np.mean(all_preds, axis=0)) < 2e-3
+            assert rel_err(out["y_pred_of_last"].cpu().numpy(), z[f"e{epoch}_last_logits"]) < 2e-3   # (not clipped, :402-417)
+            assert rel_err(out["y_pred_of_mean"].cpu().numpy(), np.clip(z[f"e{epoch}_mean_logits"], 1, 5)) < 2e-3
+        else:
+            assert last is None and mean is None                 # the reference saves weights for 'reg' only
+            out = m.predict(xt, eps=tables(f"e{epoch}"))
+            assert rel_err(out["y_pred"].cpu().numpy(), want.mean(axis=0)) < 2e-3
+
+
+def test_predict_samples_moments_vs_oracle():
+    """predict_samples (posterior-predictive mean + logit variance over fresh Philox draws) against the fp64
+    oracle fed with the SAME draws (dumped per step by vfm_philox_eps_f32)."""
+    from oracle import vfm_oracle as O
+    from vae_amd import ops
+    dev = torch.device("cuda:0")
+    for name, n in (("ml100k_reg_d20", 6), ("fraction_class_d5", 5)):
+        c = Case(name)
+        m = _model_from_case(c, dev)
+        xq = torch.tensor(c.x[:300])
+        step0 = m.global_step
+        got = m.predict_samples(xq, n_samples=n)
+        P = c.params()
+        logits = []
+        for k in range(n):
+            ee, eb, eg = ops.philox_eps(m.spec(), seed=m.rng_seed, step=step0 + k, device=dev)
+            r = O.rowwise_elbo(P, c.x[:300], np.zeros(300), c.nb_occ, c.group_hi, c.group_n, c.nb_train,
+                               eg.cpu().numpy(), eb.cpu().numpy(), ee.cpu().numpy(), c.output, want_grads=False)
+            logits.append(r["pred"])
+        L = np.array(logits)
+        assert rel_err(got["logits_mean"].cpu().numpy(), L.mean(axis=0)) < 1e-4
+        assert rel_err(got["logits_var"].cpu().numpy(), L.var(axis=0, ddof=1)) < 1e-3
+        want_mean = L.mean(axis=0) if c.output == "reg" else (1 / (1 + np.exp(-L))).mean(axis=0)
+        assert rel_err(got["mean"].cpu().numpy(), want_mean) < 1e-4
+
+
 def test_fit_predict_fraction_runs_and_learns(tmp_path):
     """cfg 1 plumbing: the shipped toy data (copied fixture of data/fraction/data.csv), d=5, Bernoulli."""
     from vae_amd.model import VFM

@@ -193,3 +193,42 @@ def test_trajectory_fixture_reference_shaped(name):
             step += 1
     for k in PARAM_KEYS:
         assert rel_err(P[k].detach().numpy(), z["pT_" + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["eval_reg_d16", "eval_class_d16_s2"])
+def test_eval_block_fixture_reference_shaped(name):
+    """The evaluation block (vfm-torch.py:378-406) replayed with the reference-shaped restatement: after each
+    epoch `save_weights` (:179-185, 'reg' only) and the forward over the test rows (:402) reproduce the
+    reference's sampled predictions and its last / mean logits (:248-259)."""
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N, M, output = int(z["N"]), int(z["M"]), str(z["output"])
+    S = int(z["n_samples"]) if "n_samples" in z.files else 1
+    P = {k: torch.tensor(z["p0_" + k], requires_grad=True) for k in PARAM_KEYS}
+    opt = torch.optim.Adam(list(P.values()), lr=float(z["lr"]))
+    X, Y, occ = torch.tensor(z["x"]), torch.tensor(z["y"]), torch.tensor(z["nb_occ"])
+    xt = torch.tensor(z["x_test"])
+    nb, B = int(z["nb_train"]), int(z["batch"])
+    saved = O.SavedWeights()
+    step = 0
+    for epoch in range(int(z["n_epochs"])):
+        for lo in range(0, nb, B):
+            eps = (z[f"s{step}_eps0"], z[f"s{step}_eps_w"], z[f"s{step}_eps_v"])
+            loss, _ = O.reference_shaped_step(P, opt, X[lo:lo + B], Y[lo:lo + B], occ, N, M, nb, output, eps,
+                                              n_samples=S)
+            assert abs(loss.item() - z["losses"][step]) / abs(z["losses"][step]) < 1e-5
+            step += 1
+        if output == "reg":
+            saved.save(P)
+        eps = (z[f"e{epoch}_eps0"], z[f"e{epoch}_eps_w"], z[f"e{epoch}_eps_v"])
+        with torch.no_grad():
+            lik, _ = O.reference_shaped_forward(P, xt, occ, N, M, output, eps, n_samples=S)
+        want = z[f"e{epoch}_pred"]
+        assert rel_err(lik.mean.numpy().reshape(want.shape), want) < 1e-4
+        if output == "reg":
+            last, mean = saved.logits(z["x_test"])
+            assert rel_err(last, z[f"e{epoch}_last_logits"]) < 1e-4
+            assert rel_err(mean, z[f"e{epoch}_mean_logits"]) < 1e-4
+        else:
+            assert f"e{epoch}_last_logits" not in z.files      # the reference saves weights for 'reg' only (:378-380)

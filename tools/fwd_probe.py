@@ -13,6 +13,9 @@ model = VFM(field_sizes=sizes, embedding_size=d, device=dev, rng_seed=1234)
 X, y = synthetic_triples(sizes, 4 * B, seed=1000, device=dev)
 occ = torch.clamp(torch.bincount(X.reshape(-1), minlength=sum(sizes)), min=1)
 model.set_training_data(X, nb_train=nb_train, nb_occ=occ)
+if os.environ.get("PSORT", "1") == "1":       # rows of each batch ordered by item id, as VFM.fit / bench.py do
+    from vae_amd.model import sort_rows_within_batches
+    X, y = sort_rows_within_batches(X, y, B)
 plans = [model.plan(X[i*B:(i+1)*B], y[i*B:(i+1)*B]) for i in range(4)]
 pplans = [model.plan(X[i*B:(i+1)*B], None) for i in range(4)]
 ent, bia, scal = model._views(model._flat)
@@ -31,4 +34,4 @@ res["predict_zero"] = timeit(lambda i: ops.elbo_forward(pplans[i % 4], ent, bia,
 res["predict_philox"] = timeit(lambda i: ops.elbo_forward(pplans[i % 4], ent, bia, scal, None, train=False, seed=1, step=i, out_pred=pred, out_partials=part))
 res["train_philox"] = timeit(lambda i: ops.elbo_forward(plans[i % 4], ent, bia, scal, model.inv_occ, seed=1, step=i, out_pred=pred, out_partials=part, out_sumz=sumz, out_grow=grow))
 res["train_table"] = timeit(lambda i: ops.elbo_forward(plans[i % 4], ent, bia, scal, model.inv_occ, eps=(ee, eb, eg), out_pred=pred, out_partials=part, out_sumz=sumz, out_grow=grow))
-print(os.environ.get("VFM_FWD_BLOCKS_PER_CU", "dflt"), "B", B, {k: round(v, 1) for k, v in res.items()}, flush=True)
+print("kernel", os.environ.get("VFM_FWD_KERNEL", "2"), "norng", os.environ.get("VFM_FWD_AB_NORNG", "0"), "sorted", os.environ.get("PSORT", "1"), "B", B, {k: round(v, 1) for k, v in res.items()}, flush=True)

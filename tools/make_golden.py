@@ -181,8 +181,11 @@ def single_case(ns, CF, name, N, M, d, x, y, nb_train, nb_occ, output,
 
 
 def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
-                    seed=42, eps_seed=11, n_samples=1, link="abs"):
-    """The loop of vfm-torch.py:347-370 for a few steps (incl. a short last batch)."""
+                    seed=42, eps_seed=11, n_samples=1, link="abs", X_test=None):
+    """The loop of vfm-torch.py:347-370 for a few steps (incl. a short last batch).  With `X_test`:
+    also the end-of-epoch block (:378-406) -- `save_weights()` for 'reg' (:380, :179-185) and the
+    forward over the whole test set (:402), whose draws, sampled prediction and last / mean logits
+    (:248-262) are recorded per epoch as e{epoch}_*."""
     if not wanted(name):
         return
     X = torch.as_tensor(X, dtype=torch.int64)
@@ -223,6 +226,26 @@ def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
                                     else lik.mean.detach().numpy().reshape(S, -1))
             losses.append(float(loss))
             step += 1
+        if X_test is not None:
+            if output == "reg":
+                model.save_weights()                        # vfm-torch.py:380
+            xt = torch.as_tensor(X_test, dtype=torch.int64)
+            with EpsRecorder() as r:
+                lik, last, mean, _ = model(xt)              # vfm-torch.py:402
+            e0, ew, ev = r.draws
+            uniq = torch.unique(xt)
+            rec[f"e{epoch}_uniq"] = uniq.numpy()
+            rec[f"e{epoch}_eps0"] = e0.numpy().reshape(-1)
+            rec[f"e{epoch}_eps_w"] = ew.numpy().reshape(-1) if S == 1 else ew.numpy().reshape(S, -1)
+            rec[f"e{epoch}_eps_v"] = (ev.numpy().reshape(len(uniq), -1) if S == 1
+                                      else ev.numpy().reshape(S, len(uniq), -1))
+            rec[f"e{epoch}_pred"] = (lik.mean.detach().numpy().reshape(-1) if S == 1
+                                     else lik.mean.detach().numpy().reshape(S, -1))
+            if last is not None:                            # numpy arrays (:248-259)
+                rec[f"e{epoch}_last_logits"] = np.asarray(last, dtype=np.float32).reshape(-1)
+                rec[f"e{epoch}_mean_logits"] = np.asarray(mean, dtype=np.float32).reshape(-1)
+    if X_test is not None:
+        rec["x_test"] = np.asarray(X_test, dtype=np.int64)
     rec["n_steps"] = step
     rec["losses"] = np.array(losses, dtype=np.float64)
     for k, v in param_dict(model).items():
@@ -314,6 +337,15 @@ def main():
     Y = g.integers(1, 6, nb).astype(np.float32)
     trajectory_case(ns, CF, "traj_reg_d16", N, M, d, X, Y, 1000, "reg")
     trajectory_case(ns, CF, "traj_softplus_s2_reg_d16", N, M, d, X, Y, 1000, "reg", n_samples=2, link="softplus")
+
+    # (6) the evaluation block (vfm-torch.py:378-406): 3 epochs x 3 batches + save_weights() + model(X_test)
+    g = np.random.default_rng(5)
+    nb, nt = 2200, 300
+    X = np.stack([g.integers(0, N, nb + nt), N + g.integers(0, M, nb + nt)], 1)
+    Y = g.integers(1, 6, nb + nt).astype(np.float32)
+    trajectory_case(ns, CF, "eval_reg_d16", N, M, d, X[:nb], Y[:nb], 800, "reg", n_epochs=3, X_test=X[nb:])
+    trajectory_case(ns, CF, "eval_class_d16_s2", N, M, d, X[:nb], (Y[:nb] >= 3).astype(np.float32), 800, "class",
+                    n_epochs=2, n_samples=2, X_test=X[nb:])
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
 OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_FWD_BLOCKS = 4096
 MAX_FIELDS = 64
 N_PARTIALS = 8
@@ -30,7 +30,7 @@ EXPORTS = (
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
-    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32",
+    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index",
 )
 
 
@@ -39,12 +39,22 @@ class Problem(C.Structure):
     _fields_ = [
         ("B", C.c_int64), ("B_global", C.c_int64), ("T", C.c_int64), ("nb_train", C.c_int64),
         ("F", C.c_int32), ("d", C.c_int32), ("likelihood", C.c_int32), ("id_bits", C.c_int32),
-        ("n_samples", C.c_int32), ("reserved", C.c_int32),
+        ("n_samples", C.c_int32), ("flags", C.c_int32),
         ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
         ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
         ("own_mod", C.c_int32), ("own_rank", C.c_int32),
         ("coord_off", C.c_int32), ("reserved0", C.c_int32),
     ]
+
+    def __setattr__(self, name, value):
+        # ctypes accepts ANY attribute name and silently keeps it as a Python attribute: a misspelt or
+        # missing field would leave the struct member 0 without an error
+        if name not in type(self)._names:
+            raise AttributeError(f"vfm_problem_t has no field {name!r}")
+        super().__setattr__(name, value)
+
+
+Problem._names = frozenset(n for n, _ in Problem._fields_)
 
 
 class Index(C.Structure):
@@ -99,10 +109,13 @@ def load():
     lib.vfm_shard_loss_f32.argtypes = [vp, vp, vp]
     lib.vfm_elbo_lik_f32.argtypes = [PP, vp, vp, vp, vp, vp, vp, vp]
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
+    lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
+    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":
             fn.restype = C.c_int
+    lib.vfm_index_workspace_bytes.restype = i64
     if lib.vfm_abi_version() != ABI_VERSION:
         raise VfmLibraryError(f"ABI mismatch: library {lib.vfm_abi_version()}, package {ABI_VERSION}")
     _lib = lib

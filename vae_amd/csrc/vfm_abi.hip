@@ -144,8 +144,25 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   return a;
 }
 
+// Which forward kernel: two fields, one variational sample, d % 4 == 0 and d <= 512 run as a stream of
+// sampling tasks (k_fwd2: an id repeated in consecutive rows of the second column is sampled once per run);
+// everything else -- general F, S > 1, the multi-rank forms that feed the kernel slots / partial row values --
+// runs k_fwd.  VFM_FWD_KERNEL=1 forces k_fwd (A/B runs, tests of both kernels).
+bool use_fwd2(const vfm_problem_t* p, int eps) {
+  if (p->F != 2 || p->n_samples != 1 || (p->d & 3) != 0 || p->d > 512) return false;
+  if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS)) return false;
+  if (eps == EPS_ZPRE) return false;
+  return env_int("VFM_FWD_KERNEL", 2) != 1;
+}
+
 int dispatch_fwd(const vfm_problem_t* p, const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,
                  hipStream_t st) {
+  if (use_fwd2(p, eps)) {
+    // VFM_FWD_AB_NORNG=1 (profiling only, wrong results): eps = 0 in the training forward, i.e. the kernel
+    // without its Philox / Box-Muller arithmetic
+    if (mode == MODE_TRAIN && eps == EPS_PHILOX && env_int("VFM_FWD_AB_NORNG", 0) == 1) eps = EPS_ZERO;
+    return softplus(p) ? launch_fwd2_softplus(eps, mode, a, o, st) : launch_fwd2_abs(eps, mode, a, o, st);
+  }
   return softplus(p) ? launch_fwd_softplus(s, eps, mode, ff, a, o, st) : launch_fwd_abs(s, eps, mode, ff, a, o, st);
 }
 int dispatch_bwd(const vfm_problem_t* p, const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,
@@ -154,27 +171,31 @@ int dispatch_bwd(const vfm_problem_t* p, const Shape& s, int eps, int adam, KArg
 }
 
 template <int LPE, int CPL, int VEC>
-int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, float* heavy_acc, int d,
+int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, float* hacc, int d,
                    hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
+  const size_t xs = 4 + (((size_t)d + 3) & ~(size_t)3);
+  float* item_acc = hacc + xs * (size_t)idx->n_heavy;            // item records sit behind the entity records
   int64_t nb = ((int64_t)idx->n_items + GPB - 1) / GPB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
-                     (int)idx->n_items, idx->occ_rows, sumz, grow, heavy_acc, d);
+                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d);
+  nb = ((int64_t)idx->n_heavy + GPB - 1) / GPB;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL((k_heavy_sum<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
+                     (int)idx->n_items, (int)idx->n_heavy, item_acc, hacc, d);
   return 0;
 }
 
 // pre-reduce the long occurrence lists (if the index has any) and point the main kernel at the result
 int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz, const float* grow,
               hipStream_t st, BwdArgs* b) {
-  b->heavy_ids = nullptr; b->heavy_acc = nullptr; b->n_heavy = 0;
+  b->heavy_ids = nullptr; b->heavy_acc = nullptr; b->n_heavy = 0; b->heavy_stride = 0;
   if (idx->n_heavy <= 0 || idx->n_items <= 0) return 0;
   if (!idx->heavy_ids || !idx->heavy_items || !idx->heavy_acc)
     return fail(VFM_E_INVALID, "index: heavy_ids / heavy_items / heavy_acc missing");
   const size_t xs = 4 + (((size_t)p->d + 3) & ~(size_t)3);
-  const size_t per_sample = xs * (size_t)idx->n_heavy;       // heavy_acc: one block of records per sample
-  hipError_t e = hipMemsetAsync(idx->heavy_acc, 0, sizeof(float) * per_sample * (size_t)p->n_samples, st);
-  if (e != hipSuccess) return fail_hip(e, "heavy_acc memset");
+  const size_t per_sample = xs * ((size_t)idx->n_heavy + (size_t)idx->n_items);   // records of one sample
   Shape s;
   pick_shape(p->d, &s);
   for (int sm = 0; sm < p->n_samples; ++sm) {
@@ -186,6 +207,7 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
 #undef X
   }
   b->heavy_ids = idx->heavy_ids; b->heavy_acc = idx->heavy_acc; b->n_heavy = idx->n_heavy;
+  b->heavy_stride = idx->n_heavy + idx->n_items;
   return 0;
 }
 
@@ -325,7 +347,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias,
-            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
@@ -365,7 +387,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                       eps_bias, eps_global);
   a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, nullptr};
+            nullptr, nullptr, nullptr, 0, 0, nullptr};
   if (!untouched_only)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -388,11 +410,14 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
-            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, nullptr};
+            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr};
   // (the pre-reduction covers whole lists, so with several entity chunks it runs with the first one)
   if (p->e_lo == 0)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
-  if (p->e_lo != 0 && idx->n_heavy > 0) { b.heavy_ids = idx->heavy_ids; b.heavy_acc = idx->heavy_acc; b.n_heavy = idx->n_heavy; }
+  if (p->e_lo != 0 && idx->n_heavy > 0) {
+    b.heavy_ids = idx->heavy_ids; b.heavy_acc = idx->heavy_acc; b.n_heavy = idx->n_heavy;
+    b.heavy_stride = idx->n_heavy + idx->n_items;
+  }
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
   Shape s;
@@ -421,7 +446,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   if (rec_pos != nullptr && rec_ptr == nullptr)      // (rec_pos may be NULL when rec_ptr lists no record at all)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_pos without rec_ptr");
   BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, kl_ws};
+            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};

@@ -2,6 +2,7 @@
 // units of libvfm_hip.so:
 //   vfm_abi.hip  C ABI (include/vfm_hip.h), argument checks, small / Adam / shard glue kernels, k_heavy
 //   vfm_fwd.hip  k_fwd instances + dispatch            (compiled once per link function, -DVFM_LINK=0|1)
+//   vfm_fwd2.hip k_fwd2 instances + dispatch           (two fields, task-stream form; once per link function)
 //   vfm_bwd.hip  k_bwd, k_sample instances + dispatch  (compiled once per link function)
 // Splitting keeps every kernel family in its own object (built in parallel by vae_amd/build.py); a
 // kernel is always launched from the unit that defines it, so no relocatable device code is needed.
@@ -75,8 +76,9 @@ struct BwdArgs {
   float* sums;   // [2]    (sum_r grow_r over all rows, alpha term)
   // entities whose occurrence list is longer than VFM_HEAVY_LIST: pre-reduced by k_heavy
   const int32_t* heavy_ids;   // [n_heavy] sorted
-  const float* heavy_acc;     // [S, n_heavy, 4 + round4(d)] records (sum grow, count, 0, 0 | A_e) per sample
+  const float* heavy_acc;     // per sample: n_heavy entity records (sum grow, count, 0, 0 | A_e) [+ the work items' records]
   int32_t n_heavy;
+  int32_t heavy_stride;       // records per sample in heavy_acc (n_heavy + n_items)
   double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
 };
 
@@ -109,6 +111,7 @@ VFM_INTERNAL int env_int(const char* name, int dflt);
 #define VFM_DECLARE_LAUNCHERS(SUFFIX)                                                                          \
   VFM_INTERNAL int launch_fwd_##SUFFIX(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,   \
                                        hipStream_t st);                                                        \
+  VFM_INTERNAL int launch_fwd2_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
   VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
                                        const AdamArgs& ad, hipStream_t st);                                    \
   VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \

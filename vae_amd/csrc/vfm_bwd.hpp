@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         for (int t = 0; t < VEC; ++t) { g1s[i].v[t] = 0.f; g2s[i].v[t] = 0.f; }
       for (int sm = 0; sm < a.S; ++sm) {
         if (sm > 0)
-          walk(b.sumz + (size_t)sm * (size_t)a.B * d, b.heavy_acc + (size_t)sm * (size_t)b.n_heavy * xs, A, gs);
+          walk(b.sumz + (size_t)sm * (size_t)a.B * d, b.heavy_acc + (size_t)sm * (size_t)b.heavy_stride * xs, A, gs);
         const RngKey ks = key_of_sample(a.key, sm);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {

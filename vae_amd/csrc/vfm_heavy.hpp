@@ -2,16 +2,20 @@
 // Included inside `namespace vfm { namespace {` of vfm_abi.hip.
 #pragma once
 
-// Skewed batches (a popular item can own 10^4 of the 10^5 rows): an occurrence list longer than
-// VFM_HEAVY_LIST is cut in chunks of that length (work items built with the index), each walked by
-// its own lane group here and added -- a few float atomics per chunk -- into the entity's record of a
-// small scratch table; the main kernel then reads that record instead of walking the list.  Without
-// it one lane group serialises the whole list (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
+// Long occurrence lists (skewed batches: a popular item can own 10^4 of the 10^5 rows; small tables: every
+// entity of an ML-100K-shape table sits in ~60 rows of a batch): a list longer than the index's heavy-list
+// length is cut in work items of at most that length (built with the index, vfm_index.hip).  k_heavy walks
+// every work item with its own lane group and STORES the partial record (sum grow, count, 0, 0 | A) of the
+// item; k_heavy_sum then adds the items of each heavy entity IN ITEM ORDER into the entity's record, which
+// the main kernel reads instead of walking the list.  No atomics: the sums have a fixed order, so the step
+// stays bitwise reproducible on skewed data too.  Without the split one lane group serialises the whole
+// list (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
+// Layout of the scratch table per sample: [n_heavy entity records | n_items item records].
 template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ items, int n_items,
                                                  const int32_t* __restrict__ occ_rows,
                                                  const float* __restrict__ sumz, const float* __restrict__ grow,
-                                                 float* __restrict__ heavy_acc, int d) {
+                                                 float* __restrict__ item_acc, int d) {
   constexpr int GPB = BLOCK / LPE;
   const int lig = threadIdx.x % LPE;
   const int C = (d + VEC - 1) / VEC;
@@ -47,16 +51,57 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
         }
       }
     }
-    float* rec = heavy_acc + (size_t)slot * xs;
+    (void)slot;
+    float* rec = item_acc + (size_t)it * xs;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       const int j = lig + i * LPE;
-      if (j < C) {
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) atomicAdd(rec + 4 + (size_t)j * VEC + t, A[i].v[t]);
-      }
+      if (j < C) st_chunk<VEC>(rec + 4 + (size_t)j * VEC, A[i]);
     }
-    if (lig == 0) { atomicAdd(rec, gs); atomicAdd(rec + 1, (float)(end - beg)); }
+    if (lig == 0) *reinterpret_cast<float4*>(rec) = make_float4(gs, (float)(end - beg), 0.f, 0.f);
   }
 }
 
+// heavy entity `slot`: sum of its work items' records (the items of a slot are consecutive and in list order)
+template <int LPE, int CPL, int VEC>
+__global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__ items, int n_items, int n_heavy,
+                                                     const float* __restrict__ item_acc,
+                                                     float* __restrict__ heavy_acc, int d) {
+  constexpr int GPB = BLOCK / LPE;
+  const int lig = threadIdx.x % LPE;
+  const int C = (d + VEC - 1) / VEC;
+  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
+  for (int slot = blockIdx.x * GPB + threadIdx.x / LPE; slot < n_heavy; slot += gridDim.x * GPB) {
+    int lo = 0, hi = n_items;                 // first item of this slot
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (items[4 * mid] < slot) lo = mid + 1; else hi = mid;
+    }
+    Chunk<VEC> A[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
+    float gs = 0.f, cnt = 0.f;
+    for (int it = lo; it < n_items && items[4 * it] == slot; ++it) {
+      const float* rec = item_acc + (size_t)it * xs;
+      gs += rec[0]; cnt += rec[1];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        if (j < C) {
+          const Chunk<VEC> t4 = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) A[i].v[t] += t4.v[t];
+        }
+      }
+    }
+    float* out = heavy_acc + (size_t)slot * xs;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int j = lig + i * LPE;
+      if (j < C) st_chunk<VEC>(out + 4 + (size_t)j * VEC, A[i]);
+    }
+    if (lig == 0) *reinterpret_cast<float4*>(out) = make_float4(gs, cnt, 0.f, 0.f);
+  }
+}

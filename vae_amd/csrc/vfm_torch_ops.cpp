@@ -120,7 +120,7 @@ vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int6
   if (index.size() == 5 && index[2].numel() > 0) {
     dev_tensor(index[2], at::kInt, "heavy_ids"); dev_tensor(index[3], at::kInt, "heavy_items");
     dev_tensor(index[4], at::kFloat, "heavy_acc");
-    TORCH_CHECK(index[3].numel() % 4 == 0 && index[4].numel() >= n_samples * index[2].numel() * rec_len(d),
+    TORCH_CHECK(index[3].numel() % 4 == 0 && index[4].numel() >= n_samples * (index[2].numel() + index[3].numel() / 4) * rec_len(d),
                 "heavy index sizes");
     ix.heavy_ids = index[2].data_ptr<int32_t>(); ix.heavy_items = index[3].data_ptr<int32_t>();
     ix.heavy_acc = index[4].data_ptr<float>();

@@ -103,8 +103,10 @@ class VFM(nn.Module):
         # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
         # "dims" = the embedding dimension cut over the ranks (vae_amd/dims.py): every rank sees all rows, holds
         # d / N coordinates, ONE all-reduce of B + 4096 floats per step and Adam traffic / N.
-        # "auto": "dims" when d % (8 N) == 0, else "sharded" unless the whole statistics table is tiny
-        # (< 4 MB: one small all-reduce wins); "grads" with n_samples > 1.
+        # "auto" = the row-sharded batch + one all-reduce the north star names: "stats" (the all-reduce
+        # carries the gradient's sufficient statistics, half the bytes of the gradient), "grads" with
+        # n_samples > 1.  "sharded" and "dims" are opt-in (bench.py --exchange auto times all of them):
+        # neither has been measured on a multi-GPU node yet.
         self.exchange = "auto"
         self.exchange_chunks = 4
         self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
@@ -285,12 +287,7 @@ class VFM(nn.Module):
         if self.n_samples > 1:
             self.exchange = "grads"      # the statistics / sharded / dims exchanges carry one sample
         if self.exchange == "auto":
-            from .dims import supported
-            table_bytes = 4 * self.T * ops.exchange_record_len(self.d)
-            if supported(self.d, torch.distributed.get_world_size(process_group), self.n_samples):
-                self.exchange = "dims"       # one all-reduce of B + 4096 floats per step; Adam traffic / N
-            else:
-                self.exchange = "sharded" if table_bytes >= (4 << 20) else "stats"
+            self.exchange = "stats"          # row-sharded batch, ONE (chunk-overlapped) all-reduce per step
         return self.exchange
 
     # ------------------------------------------------------------------ forward surfaces
@@ -300,6 +297,7 @@ class VFM(nn.Module):
     def elbo(self, x=None, y=None, plan: Optional[ops.BatchPlan] = None, eps=None):
         """Differentiable ELBO loss of one batch: `-log_prob(y).mean()*nb_train + kl`
         (vfm-torch.py:353-359).  Returns (loss[1], pred[B], detail[3] = loss, nll, kl)."""
+        self._fresh_params()      # sharded training modes: collective, every rank calls it
         if plan is None:
             plan = self.plan(x, y)
         step = self.global_step
@@ -610,13 +608,14 @@ class VFM(nn.Module):
         return hist
 
     @torch.no_grad()
-    def predict(self, X):
+    def predict(self, X, eps=None):
         """The four predictors of the evaluation block (vfm-torch.py:402-417):
         y_pred (fresh posterior sample), mean_pred (average of y_pred over the calls so far --
         "Test RMSE all"), y_pred_of_last / y_pred_of_mean (deterministic, from the last /
         epoch-averaged posterior means; None until save_weights() has run).  'reg' outputs are
-        clipped to [1, 5] like the reference (:405-406); 'class' outputs are probabilities."""
-        lik, last, mean, _ = self.forward(X)
+        clipped to [1, 5] like the reference (:405-406); 'class' outputs are probabilities.
+        `eps`: eps tables for the sampled prediction (tests replay the reference's draws); default Philox."""
+        lik, last, mean, _ = self.forward(X, eps=eps)
         y_pred = lik.mean.mean(0)          # (S = 1: the sample itself; S > 1: mean over the S samples)
         if self.output == "reg":
             y_pred = y_pred.clamp(1, 5)
@@ -637,7 +636,9 @@ class VFM(nn.Module):
         """Posterior-predictive mean and variance of the prediction over `n_samples` fresh posterior
         samples (the quantity the paper's preference-elicitation use case consumes: mean + logit
         variance, cf. vfm.py:1024-1057).  Each sample is one forward launch with its own Philox step.
-        Returns dict(mean, var, logits_mean, logits_var); 'reg': mean == logits_mean."""
+        Returns dict(mean, var, logits_mean, logits_var); 'reg': mean == logits_mean.
+        Collective after a step of a sharded training mode (the parameters are gathered first)."""
+        self._fresh_params()
         plan = self.plan(X, None)
         ent, bia, scal = self._views(self._flat)
         n = 0

@@ -120,13 +120,10 @@ class BatchPlan:
             self.y = y.to(torch.float32).contiguous()
             if self.y.shape != (self.B,):
                 raise ValueError("y must be [B]")
-        if validate and self.B > 0:
-            lo, hi = int(x.min()), int(x.max())
-            if lo < 0 or hi >= spec.T:     # nn.Embedding would raise IndexError (vfm-torch.py:207)
-                raise IndexError(f"entity id out of range [0,{spec.T}): min {lo}, max {hi}")
         self.W = None
         self.occ_ptr = self.occ_rows = None
         self.heavy = None
+        self._checked = False
         dev = x.device
         lib = _lib.load()
         if inv_occ is not None and y is not None:
@@ -138,37 +135,46 @@ class BatchPlan:
                 from .dist import sum_normalisers
                 sum_normalisers(self.W, process_group)
         if build_index and y is not None:
-            self.build_index()
+            self.build_index(validate=validate)        # (its one readback carries the id check too)
+        elif validate and self.B > 0:
+            # nn.Embedding would raise IndexError (vfm-torch.py:207): one readback
+            if bool(((x < 0) | (x >= spec.T)).any()):
+                raise IndexError(f"entity id out of range [0,{spec.T}): min {int(x.min())}, max {int(x.max())}")
+            self._checked = True
 
-    def build_index(self):
-        """Inverted index entity -> batch rows (counting sort by id; torch device ops: this is
-        plumbing done once per batch, outside the per-step path)."""
-        flat = self.x.reshape(-1).to(torch.int64)
-        order = torch.argsort(flat, stable=True)
-        self.occ_rows = (order // self.spec.F).to(torch.int32).contiguous()
-        counts = torch.bincount(flat, minlength=self.spec.T)
-        occ_ptr = torch.zeros(self.spec.T + 1, dtype=torch.int64, device=self.x.device)
-        torch.cumsum(counts, 0, out=occ_ptr[1:])
-        self.occ_ptr = occ_ptr.to(torch.int32).contiguous()
+    def build_index(self, validate: bool = False):
+        """Inverted index entity -> batch rows: `vfm_build_index` (a stable radix sort in HIP, csrc/vfm_index.hip;
+        what the reference gets from torch.unique, vfm-torch.py:190-192).  Launch-only except for ONE small
+        readback at the end: (ids out of range, number of heavy lists, number of their work items)."""
+        spec, dev = self.spec, self.x.device
+        lib = _lib.load()
+        n, L = self.B * spec.F, _lib.HEAVY_LIST
+        nbytes = int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T))
+        if nbytes < 0:
+            raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
+        ws = torch.empty(nbytes // 4 + 4, dtype=torch.int32, device=dev)
+        occ_ptr = torch.empty(spec.T + 1, dtype=torch.int32, device=dev)
+        occ_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        cap_h, cap_i = n // L + 1, 2 * n // L + 2
+        hid = torch.empty(cap_h, dtype=torch.int32, device=dev)
+        items = torch.empty(cap_i, 4, dtype=torch.int32, device=dev)
+        counts = torch.empty(4, dtype=torch.int32, device=dev)
+        check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
+                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(counts),
+                                  current_stream_ptr(dev)), "vfm_build_index")
+        n_bad, n_heavy, n_items, _ = (int(v) for v in counts.tolist())     # the plan build's one readback
+        if validate and n_bad and not self._checked:
+            # nn.Embedding would raise IndexError (vfm-torch.py:207)
+            raise IndexError(f"entity id out of range [0,{spec.T}): min {int(self.x.min())}, max {int(self.x.max())}")
+        self._checked = True
+        self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
         # long lists (skewed data): cut in work items of at most HEAVY_LIST occurrences, pre-reduced by
         # their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
-        L = _lib.HEAVY_LIST
-        heavy = torch.nonzero(counts > L).reshape(-1)
         self.heavy = None
-        if heavy.numel() > 0:
-            cnt = counts[heavy]
-            beg = occ_ptr[heavy]
-            nchunk = (cnt + L - 1) // L
-            slot = torch.repeat_interleave(torch.arange(heavy.numel(), device=flat.device), nchunk)
-            first = torch.cumsum(nchunk, 0) - nchunk
-            k = torch.arange(slot.numel(), device=flat.device) - first[slot]
-            ib = beg[slot] + k * L
-            ie = torch.minimum(ib + L, (beg + cnt)[slot])
-            items = torch.stack([slot, ib, ie, torch.zeros_like(slot)], 1).to(torch.int32).contiguous()
-            rec = 4 + (self.spec.d + 3) // 4 * 4
-            self.heavy = (heavy.to(torch.int32).contiguous(), items,
-                          torch.zeros(self.spec.n_samples * heavy.numel() * rec, dtype=torch.float32,
-                                      device=flat.device))
+        if n_heavy > 0:
+            rec = 4 + (spec.d + 3) // 4 * 4
+            self.heavy = (hid[:n_heavy], items[:n_items],
+                          torch.zeros(spec.n_samples * n_heavy * rec, dtype=torch.float32, device=dev))
 
     def index_tensors(self):
         """What the backward-family ops take as `index`."""
