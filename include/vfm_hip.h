@@ -343,6 +343,37 @@ int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalar
 int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float beta2, int64_t step, int32_t to_scaled,
                             void* stream);
 
+/* ELBO variants of the reference's sibling scripts, as one general (any F, d <= 1024, single rank, |.| link,
+ * one sample) forward / backward pair -- same access pattern as the fused kernels, a different epilogue; not
+ * tuned (csrc/vfm_variants.hip):
+ *   objective VFM_OBJ_SAMPLED      the sampled ELBO of vfm-torch.py:189-324,359
+ *             VFM_OBJ_CLOSED_FORM  the closed-form expected log-likelihood of vfm-tomasrch.py:369-451 (no
+ *                                  sampling; Normal likelihood): per row 1/2 log|alpha| - |alpha|/2 ((y - y_bar)^2 + T_n)
+ *   priors    NULL = N(0,1) (vfm-torch.py:162-164), else the LEARNABLE GROUP PRIORS of vfm-tomasrch.py:206-290,
+ *             flat [mean0, scale0 | mean_w[G] | scale_w[G] | mean_v[G,d] | scale_v[G,d]] (G = F groups =
+ *             columns; sigma = |scale|); g_priors receives their gradient in the same layout
+ *   values    NULL = entity ids only, else [B,F] feature values (sparse features with values != 1,
+ *             vfm.py:483-509): pred = w0 + sum_f v_f w_f + 1/2 sum_k[(sum_f v_f z_fk)^2 - sum_f v_f^2 z_fk^2]
+ * vfm_variant_fwd_f32: pred [B] (the sampled prediction, or y_bar), `state` [B, d] (sampled) / [B, 3d] (closed
+ *   form) and grow [B] for the backward, partials workspace as vfm_elbo_fwd_f32; with `loss` (3 floats) also the
+ *   loss triple (loss, likelihood term, KL term incl. the global bias' KL to ITS prior).  y == NULL: prediction only.
+ * vfm_variant_bwd_f32: dense gradients of both tables, the three scalars and (with priors) the priors;
+ *   occ_pos_ws = B*F int32 of scratch.  Prior gradients are summed with float atomics (order-dependent in
+ *   the last bits). */
+#define VFM_OBJ_SAMPLED 0
+#define VFM_OBJ_CLOSED_FORM 1
+int vfm_variant_fwd_f32(const vfm_problem_t* p, int32_t objective, const void* x, const float* values, const float* y,
+                        const float* entity_params, const float* bias_params, const float* inv_occ,
+                        const float* scalars, const double* W, const float* priors, const float* eps_entity,
+                        const float* eps_bias, const float* eps_global, float* pred, double* partials, float* state,
+                        float* grow, float* loss, void* stream);
+int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_index_t* idx, int32_t* occ_pos_ws,
+                        const void* x, const float* values, const float* entity_params, const float* bias_params,
+                        const float* inv_occ, const float* scalars, const double* W, const float* priors,
+                        const float* eps_entity, const float* eps_bias, const float* eps_global, const float* state,
+                        const float* grow, const double* partials, const float* grad_out, float* g_entity,
+                        float* g_bias, float* g_scalars, float* g_priors, void* stream);
+
 /* Debug / test helper: write the eps the kernels would generate from (seed, step) into
  * tables (eps_entity [S,T,d], eps_bias [S,T], eps_global [S]; S = n_samples). */
 int vfm_philox_eps_f32(const vfm_problem_t* p, float* eps_entity, float* eps_bias,

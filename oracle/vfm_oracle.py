@@ -273,6 +273,77 @@ def rowwise_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, eps0, eps_w, eps_
     return out
 
 
+def variant_elbo(P, x, y, nb_occ, group_hi, group_n, nb_train, objective="sampled", priors=None, values=None,
+                 eps=None, output="reg"):
+    """The ELBO variants of SURVEY 8(f)4 in one torch-fp64 restatement (general F, row-wise sums, autograd):
+
+    objective "sampled": vfm-torch.py:189-324,359 (eps = (eps0[1], eps_w[T], eps_v[T,d]) by entity id);
+    objective "closed_form": the expected log-likelihood of vfm-tomasrch.py:369-451 and the loss of :569-588 --
+        y_bar = m0 + sum_f v_f mu_w + sum_{f<g} v_f v_g <mu_f, mu_g>,
+        T_n = s0^2 + sum_f v_f^2 s_w^2 + sum_{f<g} v_f^2 v_g^2 sum_k (mu_f^2 s_g^2 + mu_g^2 s_f^2 + s_f^2 s_g^2),
+        loss = -nb_train/B sum_n [1/2 log|alpha| - |alpha|/2 ((y_n - y_bar_n)^2 + T_n)] + KL terms;
+    priors: None = N(0,1), else dict(global=(mean[1], scale[1]), bias=(mean[G], scale[G]), entity=(mean[G,d], scale[G,d]))
+        -- the learnable group priors of vfm-tomasrch.py:206-290 (sigma = |scale|), group of an id = first g with
+        id < group_hi[g];
+    values: None or [B,F] feature values (vfm.py:483-509: x.w + 1/2 sum((x.V)^2 - x^2.V^2); x^2 is squared here --
+        the reference's `x2 = x` carries a FIXME that it only holds for 0/1 values).
+    P / priors entries may be tensors with requires_grad: returns dict(loss, pred, kl, nll)."""
+    f8 = torch.float64
+    T = lambda v: torch.as_tensor(v).to(f8) if not torch.is_tensor(v) else v.to(f8)
+    x = torch.as_tensor(np.asarray(x), dtype=torch.int64)
+    B, F = x.shape
+    y = T(y)
+    ent, bia = T(P["entity_params"]), T(P["bias_params"])
+    d = ent.shape[1] // 2
+    alpha, m0, s0 = T(P["alpha"]).reshape(()), T(P["global_bias_mean"]).reshape(()), T(P["global_bias_scale"]).reshape(())
+    a, sg0 = alpha.abs(), s0.abs()
+    v = torch.ones(B, F, dtype=f8) if values is None else T(values)
+    grp = torch.as_tensor(np.searchsorted(np.asarray(group_hi), x.numpy(), side="right"))     # [B,F]
+    G = len(group_n)
+    mu_w, s_w = bia[x][..., 0], bia[x][..., 1]
+    mu_v, s_v = ent[x][..., :d], ent[x][..., d:]
+    if objective == "sampled":
+        e0, ew, ev = (T(e) for e in eps)
+        w0 = m0 + sg0 * e0.reshape(())
+        w = mu_w + s_w.abs() * ew[x]
+        z = mu_v + s_v.abs() * ev[x]
+    else:
+        w0, w, z = m0, mu_w, mu_v
+    vz = v[..., None] * z
+    pred = w0 + (v * w).sum(1) + 0.5 * ((vz.sum(1) ** 2).sum(1) - (vz ** 2).sum((1, 2)))
+    if objective == "sampled":
+        if output == "reg":
+            ll = -0.5 * a * (y - pred) ** 2 + 0.5 * torch.log(a) - LOG_SQRT_2PI
+        else:
+            ll = y * pred - torch.nn.functional.softplus(pred)
+    else:
+        am, bs = (v[..., None] ** 2) * mu_v ** 2, (v[..., None] ** 2) * s_v ** 2
+        q = am + bs
+        t2 = 0.5 * ((q.sum(1) ** 2 - am.sum(1) ** 2).sum(1) - (q ** 2 - am ** 2).sum((1, 2)))
+        Tn = s0 ** 2 + (v ** 2 * s_w ** 2).sum(1) + t2
+        ll = 0.5 * torch.log(a) - 0.5 * a * ((y - pred) ** 2 + Tn)
+    if priors is None:
+        pg = (torch.zeros((), dtype=f8), torch.ones((), dtype=f8))
+        pw = (torch.zeros(G, dtype=f8), torch.ones(G, dtype=f8))
+        pv = (torch.zeros(G, d, dtype=f8), torch.ones(G, d, dtype=f8))
+    else:
+        pg = tuple(T(t).reshape(()) for t in priors["global"])
+        pw = tuple(T(t).reshape(G) for t in priors["bias"])
+        pv = tuple(T(t).reshape(G, d) for t in priors["entity"])
+
+    def kl(mu, sg, pm, ps):
+        ps = ps.abs()
+        return torch.log(ps / sg) + (sg ** 2 + (mu - pm) ** 2) / (2 * ps ** 2) - 0.5
+    kl_e = kl(mu_w, s_w.abs(), pw[0][grp], pw[1][grp]) + kl(mu_v, s_v.abs(), pv[0][grp], pv[1][grp]).sum(2)   # [B,F]
+    io = 1.0 / T(np.asarray(nb_occ))[x]
+    W = io.sum(0)                                          # per column
+    cs = T(np.asarray(group_n)) / W
+    klr = (kl_e * io * cs[grp]).sum()
+    kl0 = kl(m0, sg0, pg[0], pg[1])
+    nll = -(nb_train / B) * ll.sum()
+    return {"loss": nll + kl0 + klr, "pred": pred, "nll": nll, "kl": kl0 + klr, "kl0": kl0, "partial_loss": ll.sum()}
+
+
 def pairwise_second_order(z):
     """Explicit sum_{f<g} <z_f, z_g> for z [B,F,d] -- the identity the FM trick
     1/2((sum z)^2 - sum z^2) must satisfy (vfm.py:491-493, vfm-tomasrch.py:379-393)."""

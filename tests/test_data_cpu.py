@@ -109,3 +109,48 @@ def test_load_ratings_frame_reindexes_and_splits():
     X = np.concatenate([Xtr, Xte])
     assert X[:, 0].min() == 0 and X[:, 0].max() == 3 and X[:, 1].min() == 4 and X[:, 1].max() == 8
     assert sorted(np.concatenate([ytr, yte]).tolist()) == sorted(df["rating"].astype(np.float32).tolist())
+
+
+def test_loaders_against_the_reference_fixtures(tmp_path):
+    """tests/golden/loader/ was produced by running the reference's own prepare.prepare_data / load_data
+    (tools/make_loader_golden.py) on the committed raw files: the same raw files through vae_amd.data must give
+    byte-identical data.csv / libFM exports and identical load_data results."""
+    import shutil
+    G = os.path.join(ROOT, "tests", "golden", "loader")
+    d = tmp_path / "toy"
+    d.mkdir()
+    shutil.copy(os.path.join(G, "raw_data.csv"), d / "data.csv")
+    for f in ("trainval.csv", "test.csv"):
+        shutil.copy(os.path.join(G, f), d / f)
+    exp = np.load(os.path.join(G, "expected_load_data.npz"))
+    # load_data on the raw file: the `shifted_item` fallback (prepare.py:20-21)
+    N, M, Xtr, Xte, ytr, yte, i = D.load_data("toy", "reg", root=tmp_path)
+    assert (N, M) == (int(exp["raw_N"]), int(exp["raw_M"]))
+    assert np.array_equal(Xtr, exp["raw_X_train"]) and np.array_equal(Xte, exp["raw_X_test"])
+    assert np.array_equal(ytr, exp["raw_y_train"])
+    # prepare_data: re-indexing, shifted_item, outcome, libFM exports (prepare.py:39-64)
+    D.prepare_data("toy", False, root=tmp_path)
+    assert open(d / "data.csv").read() == open(os.path.join(G, "expected_data.csv")).read()
+    for name in ("trainval", "test"):
+        assert open(d / f"toy.{name}_libfm").read() == open(os.path.join(G, f"expected.{name}_libfm")).read()
+    for ot in ("reg", "class"):
+        N, M, Xtr, Xte, ytr, yte, i = D.load_data("toy", ot, root=tmp_path)
+        assert (N, M) == (int(exp[f"{ot}_N"]), int(exp[f"{ot}_M"]))
+        assert np.array_equal(Xtr, exp[f"{ot}_X_train"]) and np.array_equal(Xte, exp[f"{ot}_X_test"])
+        assert np.array_equal(ytr, exp[f"{ot}_y_train"]) and np.array_equal(yte, exp[f"{ot}_y_test"])
+        assert i["trainval"] == exp[f"{ot}_i_trainval"].tolist() and i["test"] == exp[f"{ot}_i_test"].tolist()
+    # the libFM export read back (the `movie100` branch, vfm-torch.py:31-57)
+    n2, m2, Ltr, Lte, ly, _ = D.load_libfm(d / "toy.trainval_libfm", d / "toy.test_libfm")
+    assert np.array_equal(Ltr, exp["reg_X_train"]) and np.array_equal(ly, exp["reg_y_train"])
+
+
+def test_read_config_yml_and_fallback(tmp_path):
+    """config.yml (nb_users / nb_items) as the TF sibling reads it (vfm.py:97-104), else 1 + the largest id."""
+    pd.DataFrame({"user": [0, 2, 5], "item": [1, 1, 3], "outcome": [1, 0, 1]}).to_csv(tmp_path / "data.csv", index=False)
+    assert D.read_config(tmp_path) == (6, 4)
+    (tmp_path / "config.yml").write_text("nb_users: 10\nnb_items: 7\n")
+    assert D.read_config(tmp_path) == (10, 7)
+    N, M, Xtr, Xte, ytr, yte = D.load_fraction(str(tmp_path), test_size=0.0)
+    assert (N, M) == (10, 7) and Xtr[:, 1].min() >= 10             # items shifted by the configured N
+    frac = os.path.join(ROOT, "tests", "golden", "fraction")
+    assert D.read_config(frac) == (536, 20)                        # the shipped toy set has no config.yml

@@ -47,13 +47,14 @@ def test_index_equals_stable_sort(B, sizes, zipf, dtype):
                     likelihood=_lib.LIK_NORMAL)
     inv_occ = torch.ones(T, dtype=torch.float32, device=dev)
     plan = ops.BatchPlan(spec, X, y, inv_occ)
-    ptr_want, rows_want, heavy_want, items_want = _ref(X.cpu().numpy(), T, F, _lib.HEAVY_LIST)
+    assert plan.heavy_list == _lib.heavy_list_for(B * F, T) and 8 <= plan.heavy_list <= 64
+    ptr_want, rows_want, heavy_want, items_want = _ref(X.cpu().numpy(), T, F, plan.heavy_list)
     assert np.array_equal(plan.occ_ptr.cpu().numpy(), ptr_want)
     assert np.array_equal(plan.occ_rows.cpu().numpy(), rows_want)
     if len(heavy_want):
         assert np.array_equal(plan.heavy[0].cpu().numpy(), heavy_want)
         assert np.array_equal(plan.heavy[1].cpu().numpy(), items_want)
-        assert plan.heavy[2].numel() == len(heavy_want) * (4 + 8)
+        assert plan.heavy[2].numel() == (len(heavy_want) + len(items_want)) * (4 + 8)
     else:
         assert plan.heavy is None
     # W (vfm_batch_norms) with inv_occ = 1 is the row count of every column

@@ -232,3 +232,69 @@ def test_eval_block_fixture_reference_shaped(name):
             assert rel_err(mean, z[f"e{epoch}_mean_logits"]) < 1e-4
         else:
             assert f"e{epoch}_last_logits" not in z.files      # the reference saves weights for 'reg' only (:378-380)
+
+
+def _cf_case(name):
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sizes = [int(v) for v in z["group_sizes"]]
+    G, d = len(sizes), int(z["d"])
+    leaf = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    P = {"alpha": leaf(z["p_alpha"]), "global_bias_mean": leaf(z["p_mean_global_bias"]),
+         "global_bias_scale": leaf(z["p_scale_global_bias"]), "bias_params": leaf(z["p_bias_params"]),
+         "entity_params": leaf(z["p_entity_params"])}
+    pri = {"global": (leaf(z["p_mean_global_bias_prior"]), leaf(z["p_scale_global_bias_prior"])),
+           "bias": (leaf(np.concatenate([z[f"p_mean_group_bias_prior_{i}"] for i in range(G)])),
+                    leaf(np.concatenate([z[f"p_scale_group_bias_prior_{i}"] for i in range(G)]))),
+           "entity": (leaf(np.stack([z[f"p_mean_group_entity_prior_{i}"] for i in range(G)])),
+                      leaf(np.stack([z[f"p_scale_group_entity_prior_{i}"] for i in range(G)])))}
+    return z, sizes, G, d, P, pri
+
+
+@pytest.mark.parametrize("name", ["cf_reg_d8_g2", "cf_reg_d12_g3"])
+def test_closed_form_variant_vs_reference(name):
+    """The sibling script's objective -- closed-form expected log-likelihood (vfm-tomasrch.py:369-451), learnable
+    group priors (:206-290), loss of :569-588 -- restated row-wise (O.variant_elbo) against the reference's own
+    class run by tools/make_golden.py: loss, y_bar and the gradient of EVERY parameter, priors included."""
+    z, sizes, G, d, P, pri = _cf_case(name)
+    r = O.variant_elbo(P, z["x"], z["y"], z["nb_occ"], np.cumsum(sizes), np.array(sizes, np.float64), int(z["nb_train"]),
+                       objective="closed_form", priors=pri)
+    assert abs(r["loss"].item() - z["loss"][0]) / abs(z["loss"][0]) < 1e-5
+    if G == 2:      # (`likelihood.mean` of the reference multiplies ALL groups' embeddings, :342-347: it is the
+        assert rel_err(r["pred"].detach().numpy(), z["y_bar"]) < 1e-5     # pairwise y_bar of :369-393 only for G = 2)
+    assert abs(r["partial_loss"].item() - z["partial_loss"][0]) / abs(z["partial_loss"][0]) < 1e-5
+    assert abs(r["kl0"].item() - z["kl0"][0]) < 1e-5 * max(1.0, abs(z["kl0"][0]))
+    r["loss"].backward()
+    for key, t in (("alpha", P["alpha"]), ("mean_global_bias", P["global_bias_mean"]),
+                   ("scale_global_bias", P["global_bias_scale"]), ("bias_params", P["bias_params"]),
+                   ("entity_params", P["entity_params"]), ("mean_global_bias_prior", pri["global"][0]),
+                   ("scale_global_bias_prior", pri["global"][1])):
+        assert rel_err(t.grad.numpy(), z["g_" + key]) < 2e-4, key
+    for i in range(G):
+        assert rel_err(pri["bias"][0].grad.numpy()[i:i + 1], z[f"g_mean_group_bias_prior_{i}"]) < 2e-4
+        assert rel_err(pri["bias"][1].grad.numpy()[i:i + 1], z[f"g_scale_group_bias_prior_{i}"]) < 2e-4
+        assert rel_err(pri["entity"][0].grad.numpy()[i], z[f"g_mean_group_entity_prior_{i}"]) < 2e-4
+        assert rel_err(pri["entity"][1].grad.numpy()[i], z[f"g_scale_group_entity_prior_{i}"]) < 2e-4
+
+
+def test_variant_oracle_reduces_to_the_main_path():
+    """variant_elbo with N(0,1) priors, unit values and the sampled objective IS the main path: equal to
+    rowwise_elbo (which the vfm-torch.py goldens pin); and feature values: v = 2 on one field equals doubling that
+    field's first-order weight and embedding."""
+    c = Case("quirk_reg_d8")
+    P = c.params(np.float64)
+    e0, ew, ev = c.eps("f64")
+    want = O.rowwise_elbo(P, c.x, c.y.astype(np.float64), c.nb_occ, c.group_hi, c.group_n, c.nb_train, e0, ew, ev, "reg")
+    got = O.variant_elbo(P, c.x, c.y, c.nb_occ, c.group_hi, c.group_n, c.nb_train, "sampled", eps=(e0, ew, ev))
+    assert abs(got["loss"].item() - want["loss"]) / abs(want["loss"]) < 1e-10
+    assert rel_err(got["pred"].numpy(), want["pred"]) < 1e-10
+    vals = np.ones(c.x.shape); vals[:, 1] = 2.0
+    P2 = {k: v.copy() for k, v in P.items()}
+    items = np.unique(c.x[:, 1])
+    P2["bias_params"][items, 0] *= 2.0
+    P2["entity_params"][items, :c.d] *= 2.0
+    zero = (np.zeros(1), np.zeros(c.T), np.zeros((c.T, c.d)))
+    a = O.variant_elbo(P, c.x, c.y, c.nb_occ, c.group_hi, c.group_n, c.nb_train, "sampled", values=vals, eps=zero)
+    b = O.variant_elbo(P2, c.x, c.y, c.nb_occ, c.group_hi, c.group_n, c.nb_train, "sampled", eps=zero)
+    assert rel_err(a["pred"].numpy(), b["pred"].numpy()) < 1e-12

@@ -62,6 +62,76 @@ class EpsRecorder:
         self.tn._standard_normal = self.orig
 
 
+def lift_cf_closed_form(namespace):
+    """Compile `class CF` of the reference's vfm-tomasrch.py (G id groups, learnable group priors :206-290,
+    closed-form expected log-likelihood :369-451) in `namespace`; its `torchmin` / `rich` imports are outside
+    the class and are not needed."""
+    path = os.path.join(REF, "vfm-tomasrch.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CF")
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+    return namespace["CF"], (node.lineno, node.end_lineno)
+
+
+def closed_form_case(name, group_sizes, d, B, nb_train, seed):
+    """One step of vfm-tomasrch.py's objective: model(inverse, present, closed_form_loss=True, target) (:548-553)
+    and the loss of :569-588 (the branch in effect), with every parameter -- the learnable priors too -- moved
+    off its initial value so that all of them matter; outputs + gradients of all parameters."""
+    if not wanted(name):
+        return
+    G, T = len(group_sizes), int(sum(group_sizes))
+    ns = {"torch": torch, "nn": nn, "distributions": distributions, "np": np, "N": group_sizes[0], "M": group_sizes[-1]}
+    CF, span = lift_cf_closed_form(ns)
+    g = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(group_sizes)[:-1]])
+    Xall = np.stack([off[f] + g.integers(0, group_sizes[f], nb_train) for f in range(G)], 1)
+    entity_count = torch.bincount(torch.as_tensor(Xall).flatten(), minlength=T).float()      # :182
+    x = torch.as_tensor(Xall[:B], dtype=torch.int64)
+    y = torch.as_tensor(g.integers(1, 6, B).astype(np.float32))
+    torch.manual_seed(seed)
+    model = CF(embedding_size=d, n_groups=G, group_sizes=list(group_sizes), alpha_0=1.7, output="reg")
+    with torch.no_grad():                      # move everything off the initial point
+        tg = torch.Generator().manual_seed(seed + 1)
+        rn = lambda *sh: torch.randn(*sh, generator=tg)
+        model.bias_params.copy_(torch.cat([0.4 * rn(T, 1), 0.2 + 0.5 * torch.rand(T, 1, generator=tg) * torch.sign(rn(T, 1))], 1))
+        model.entity_params.copy_(torch.cat([0.5 * rn(T, d), (0.2 + 0.6 * torch.rand(T, d, generator=tg)) * torch.sign(rn(T, d))], 1))
+        model.mean_global_bias.copy_(0.3 * rn(1)); model.scale_global_bias.copy_(torch.tensor([-0.7]))
+        model.mean_global_bias_prior.copy_(0.2 * rn(1)); model.scale_global_bias_prior.copy_(torch.tensor([1.3]))
+        for i in range(G):
+            model.mean_group_bias_prior[i].copy_(0.3 * rn(1)); model.scale_group_bias_prior[i].copy_(0.6 + torch.rand(1, generator=tg))
+            model.mean_group_entity_prior[i].copy_(0.3 * rn(d))
+            model.scale_group_entity_prior[i].copy_((0.6 + torch.rand(d, generator=tg)) * torch.sign(rn(d)))
+    present, inverse, counts = [], [], []
+    for i in range(G):                                            # :536-545
+        p_, inv, c_ = torch.unique(x[:, i], return_inverse=True, return_counts=True)
+        present.append(p_); inverse.append(inv); counts.append(c_)
+    outputs, kls, partial_loss = model(inverse, present, closed_form_loss=True, target=y)     # :548-553
+    loss = (- nb_train * partial_loss / len(x) + kls[0] + (                                   # :569-588
+        (kls[1] + kls[2].sum(axis=1))
+        * torch.cat([torch.Tensor(group_sizes[i] / (counts[i] / entity_count[present[i]]).sum()).repeat(len(present[i]))
+                     for i in range(G)])
+        * torch.concat(counts) / entity_count[torch.concat(present)]).sum())
+    model.zero_grad()
+    loss.backward()
+    rec = {"group_sizes": np.array(group_sizes), "d": d, "nb_train": nb_train, "x": x.numpy(), "y": y.numpy(),
+           "nb_occ": entity_count.numpy().astype(np.int64),
+           "y_bar": outputs.mean.detach().numpy().reshape(-1), "kl0": kls[0].detach().numpy().reshape(-1),
+           "partial_loss": partial_loss.detach().numpy().reshape(-1), "loss": loss.detach().numpy().reshape(-1)}
+
+    def put(key, prm):
+        rec["p_" + key] = prm.detach().numpy().copy()
+        rec["g_" + key] = (prm.grad.numpy().copy() if prm.grad is not None else np.zeros_like(prm.detach().numpy()))
+    put("alpha", model.alpha); put("mean_global_bias", model.mean_global_bias); put("scale_global_bias", model.scale_global_bias)
+    put("mean_global_bias_prior", model.mean_global_bias_prior); put("scale_global_bias_prior", model.scale_global_bias_prior)
+    put("bias_params", model.bias_params); put("entity_params", model.entity_params)
+    for i in range(G):
+        put(f"mean_group_bias_prior_{i}", model.mean_group_bias_prior[i]); put(f"scale_group_bias_prior_{i}", model.scale_group_bias_prior[i])
+        put(f"mean_group_entity_prior_{i}", model.mean_group_entity_prior[i]); put(f"scale_group_entity_prior_{i}", model.scale_group_entity_prior[i])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: lifted CF of vfm-tomasrch.py lines {span}, G={G} B={B} loss={float(loss)}")
+
+
 LINKS = {"abs": torch.abs, "softplus": nn.functional.softplus}     # vfm-torch.py:126 / :125
 ONLY = None
 
@@ -346,6 +416,11 @@ def main():
     trajectory_case(ns, CF, "eval_reg_d16", N, M, d, X[:nb], Y[:nb], 800, "reg", n_epochs=3, X_test=X[nb:])
     trajectory_case(ns, CF, "eval_class_d16_s2", N, M, d, X[:nb], (Y[:nb] >= 3).astype(np.float32), 800, "class",
                     n_epochs=2, n_samples=2, X_test=X[nb:])
+
+    # (7) the sibling script's objective (vfm-tomasrch.py): closed-form expected log-likelihood + learnable group
+    # priors, two groups (user, item) and three (the 'fr_en' layout: format, item, user)
+    closed_form_case("cf_reg_d8_g2", [50, 30], 8, 400, 4000, 21)
+    closed_form_case("cf_reg_d12_g3", [3, 40, 25], 12, 300, 3000, 22)
 
 
 if __name__ == "__main__":

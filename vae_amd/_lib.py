@@ -24,6 +24,7 @@ MAX_FWD_BLOCKS = 4096
 PARTIALS_LEN = N_PARTIALS * (1 + MAX_FWD_BLOCKS)
 P_LL, P_KL, P_G, P_ALPHA, P_BADID = 0, 1, 2, 3, 4
 LIK_NORMAL, LIK_BERNOULLI = 0, 1
+OBJ_SAMPLED, OBJ_CLOSED_FORM = 0, 1
 
 EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
@@ -31,6 +32,7 @@ EXPORTS = (
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
     "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index",
+    "vfm_variant_fwd_f32", "vfm_variant_bwd_f32",
 )
 
 
@@ -64,7 +66,20 @@ class Index(C.Structure):
                 ("n_items", C.c_int32)]
 
 
-HEAVY_LIST = int(os.environ.get("VFM_HEAVY_LIST", "64"))   # >= 8 (VFM_HEAVY_MIN); tuning knob of the plan builder
+HEAVY_LIST = int(os.environ.get("VFM_HEAVY_LIST", "0"))    # 0: chosen per plan (heavy_list_for); else >= 8 (VFM_HEAVY_MIN)
+HEAVY_UNITS = 8192     # lane groups' worth of independent work the entity-centric backward should have
+
+
+def heavy_list_for(n_occ: int, T: int) -> int:
+    """Length above which an occurrence list is cut in work items (vfm_index_t).  With many table rows the
+    backward has one lane group per row and only the few really long lists need cutting (64).  With a small
+    table (ML-100K shape: 2,625 entities, ~60 rows each per batch) the rows alone do not fill the chip, so the
+    lists are cut finer -- about n_occ / HEAVY_UNITS occurrences per work item, never below VFM_HEAVY_MIN."""
+    if HEAVY_LIST:
+        return max(8, HEAVY_LIST)
+    if T >= HEAVY_UNITS:
+        return 64
+    return max(8, min(64, n_occ // HEAVY_UNITS))
 
 
 class VfmLibraryError(RuntimeError):
@@ -111,6 +126,8 @@ def load():
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp]
+    lib.vfm_variant_fwd_f32.argtypes = [PP, i32] + [vp] * 18
+    lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name != "vfm_last_error":

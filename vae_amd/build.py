@@ -20,7 +20,7 @@ def _stale(target, sources):
 
 # translation units of libvfm_hip.so: (source, object suffix, extra flags).  The row kernels are
 # compiled once per link function (vfm-torch.py:125-126: |.| and softplus).
-_UNITS = [("vfm_abi.hip", "", []), ("vfm_index.hip", "", []),
+_UNITS = [("vfm_abi.hip", "", []), ("vfm_index.hip", "", []), ("vfm_variants.hip", "", []),
           ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"])]

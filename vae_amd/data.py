@@ -97,15 +97,31 @@ def load_ratings_frame(df, user_col="userId", item_col="movieId", rating_col="ra
     return N, M, X[tr], X[te], y[tr], y[te]
 
 
+def read_config(path, df=None):
+    """(nb_users, nb_items) of a data directory the way the TF sibling takes them (vfm.py:97-104): from the
+    optional `config.yml` (keys `nb_users`, `nb_items`), else guessed from the data as 1 + the largest id."""
+    cfg = Path(path) / "config.yml"
+    if cfg.is_file():
+        import yaml
+        with open(cfg) as f:
+            c = yaml.safe_load(f)
+        return int(c["nb_users"]), int(c["nb_items"])
+    if df is None:
+        import pandas as pd
+        df = pd.read_csv(Path(path) / "data.csv")
+    return 1 + int(df["user"].max()), 1 + int(df["item"].max())
+
+
 def load_fraction(path, test_size=0.2, seed=0):
     """The shipped toy set `data/fraction/data.csv` (536 users x 20 items, binary `outcome`).
-    It has no split files and no `shifted_item` column, so: item ids are shifted by N here and the
+    It has no split files, no `shifted_item` column and no `config.yml`, so: N, M come from `read_config`
+    (1 + max id, vfm.py:102-104: 536, 20), item ids are shifted by N here (vfm.py:105) and the
     split is a seeded 80/20 shuffle (the TF sibling falls back to train_test_split, vfm.py:211-212).
     Rows whose entities never occur in the training part are dropped from the test part.
     Returns (N, M, X_train, X_test, y_train, y_test)."""
     import pandas as pd
     df = pd.read_csv(os.path.join(path, "data.csv"))
-    N, M = int(df.user.nunique()), int(df.item.nunique())
+    N, M = read_config(path, df)          # config.yml if the directory has one (vfm.py:97-104), else 1 + max id
     X = np.stack([df.user.to_numpy(), df.item.to_numpy() + N], 1).astype(np.int64)
     y = df.outcome.to_numpy().astype(np.float32)
     perm = np.random.default_rng(seed).permutation(len(y))

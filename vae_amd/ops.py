@@ -148,7 +148,8 @@ class BatchPlan:
         readback at the end: (ids out of range, number of heavy lists, number of their work items)."""
         spec, dev = self.spec, self.x.device
         lib = _lib.load()
-        n, L = self.B * spec.F, _lib.HEAVY_LIST
+        n = self.B * spec.F
+        L = self.heavy_list = _lib.heavy_list_for(n, spec.T)
         nbytes = int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T))
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
@@ -173,8 +174,8 @@ class BatchPlan:
         self.heavy = None
         if n_heavy > 0:
             rec = 4 + (spec.d + 3) // 4 * 4
-            self.heavy = (hid[:n_heavy], items[:n_items],
-                          torch.zeros(spec.n_samples * n_heavy * rec, dtype=torch.float32, device=dev))
+            self.heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
+                          torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
 
     def index_tensors(self):
         """What the backward-family ops take as `index`."""
