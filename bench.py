@@ -69,6 +69,9 @@ def main():
                     help="A/B: eps of the forward / backward from tables (one fixed draw, as the parity tests feed "
                          "the reference's recorded draws) instead of the in-kernel Philox stream")
     ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
+    ap.add_argument("--lazy-adam", default="auto", choices=["auto", "on", "off"],
+                    help="lazy exact dense Adam (rows outside the batch are skipped and replayed later, bitwise the dense "
+                         "trajectory); auto: when a batch touches less than 35 %% of the table")
     ap.add_argument("--plain-moments", action="store_true",
                     help="A/B: keep the Adam moments in the plain form (no VFM_FLAG_SCALED_MOMENTS)")
     args = ap.parse_args()
@@ -119,6 +122,7 @@ def main():
     model = VFM(field_sizes=sizes, embedding_size=d, output=output, device=dev, rng_seed=1234)
     model.exchange = args.exchange
     model.scaled_moments = not args.plain_moments
+    model.lazy_adam = {"auto": "auto", "on": True, "off": False}[args.lazy_adam]
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -173,7 +177,7 @@ def main():
         torch.cuda.synchronize()
         plan_build[model.exchange if world > 1 else "single"] = (time.perf_counter() - t0) / nbt * 1e3
         for p in ps:
-            us.append(p.U if hasattr(p, "U") else int((p.occ_ptr[1:] != p.occ_ptr[:-1]).sum()))
+            us.append(p.U)
         return ps, us
 
     events = []
@@ -349,6 +353,7 @@ def main():
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "adam_moments": "scaled form (untouched rows do not write m, v)" if (
                            model.scaled_moments and world == 1 and not args.unfused) else "plain",
+                       "lazy_exact_adam": bool(model._lazy_last is not None),
                        "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
                        "exchange_autotune_ms_per_step": tune,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
@@ -393,12 +398,16 @@ def kernel_report(events, model, args, world, B, d, F, U):
             d_k, B_k = d, B
         bytes_fwd = U * (8 * d_k + 16) + B_k * (idb * F + 8)        # touched rows once + ids, y, pred
         bytes_bwd = bytes_fwd + U * (8 * d_k + 8)                   # re-read + one write per touched row
+        lazy = "catchup" in acc          # lazy exact dense Adam: only the batch's rows are read / written per step
         alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
+               # replay of the skipped updates on the batch's rows: read p, m, v, write p
+               "catchup": 16.0 * U * (2 * d_k + 2) + 8.0 * U,
                "allreduce": 4.0 * n_params,
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
                # (scaled moments: the rows a batch does not touch read p, m, v and write p only: 16 B/param)
-               "bwd_adam": B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
-                           (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0),
+               "bwd_adam": (B_k * (idb * F + 8) + U * 16 + 24.0 * U * (2 * d_k + 2)) if lazy else (
+                           B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
+                           (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0)),
                # dimension-sharded mode: the step's only exchange, and the per-row likelihood kernel after it
                "allreduce_row_values": 4.0 * (B_k + 4096), "lik": 16.0 * B_k,
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
@@ -413,7 +422,9 @@ def kernel_report(events, model, args, world, B, d, F, U):
             os.environ.get("VFM_FWD_KERNEL", "2") != "1"
         names = {"fwd": "k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "
                         "once per run)" if fwd2 else "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
-                 "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)", "adam": "k_adam (dense Adam)",
+                 "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)" + (", rows of the batch only (lazy exact Adam)" if lazy else ""),
+                 "adam": "k_adam (dense Adam)",
+                 "catchup": "k_adam_catchup (lazy exact dense Adam: replay of the skipped zero-gradient updates on the batch's rows)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",
                  "lik": "k_lik (likelihood terms + dloss/dpred of all rows)",
@@ -428,7 +439,7 @@ def kernel_report(events, model, args, world, B, d, F, U):
             gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0
             kern[k] = {"kernel": names[k], "avg_us": round(us, 2), "alg_bytes": int(alg[k]),
                        "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        cand = [k for k in kern if k in ("fwd", "bwd", "bwd_adam", "bwd_acc", "adam")]
+        cand = [k for k in kern if k in ("fwd", "bwd", "bwd_adam", "bwd_acc", "adam", "catchup")]
         dom = max(cand, key=lambda k: kern[k]["avg_us"])
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")

@@ -83,15 +83,6 @@ int main(int argc, char** argv) {
   auto bias = read_file<float>(dir + "/bias.f32", (size_t)(T * 2));
   auto scal = read_file<float>(dir + "/scalars.f32", 3);
 
-  // inverted index of the batch (entity -> rows): stable counting sort of the B*F occurrences by id
-  std::vector<int32_t> occ_ptr((size_t)T + 1, 0), occ_rows((size_t)(B * F));
-  for (long long o = 0; o < B * F; ++o) occ_ptr[(size_t)x[(size_t)o] + 1]++;
-  std::partial_sum(occ_ptr.begin(), occ_ptr.end(), occ_ptr.begin());
-  {
-    std::vector<int32_t> cur(occ_ptr.begin(), occ_ptr.end() - 1);
-    for (long long o = 0; o < B * F; ++o) occ_rows[(size_t)cur[(size_t)x[(size_t)o]]++] = (int32_t)(o / F);
-  }
-
   vfm_problem_t p{};
   p.B = B; p.B_global = B; p.T = T; p.nb_train = nb_train; p.F = (int32_t)F; p.d = (int32_t)d;
   p.likelihood = (int32_t)likelihood; p.id_bits = 64; p.n_samples = 1; p.flags = VFM_FLAG_SCALED_MOMENTS;
@@ -103,7 +94,16 @@ int main(int argc, char** argv) {
   float* d_y = to_device(y);
   int64_t* d_occ = to_device(occ);
   float *d_ent = to_device(ent), *d_bias = to_device(bias), *d_scal = to_device(scal);
-  int32_t *d_ptr = to_device(occ_ptr), *d_rows = to_device(occ_rows);
+  // inverted index of the batch (entity -> rows), built on the GPU by the library: workspace + outputs are
+  // caller-owned; one small readback tells how many heavy lists / work items it made
+  const int32_t L = vfm_heavy_list_for(B * F, T);
+  const int64_t cap_h = B * F / L + 1, cap_i = 2 * B * F / L + 2;
+  int32_t* d_ptr = device_zeros<int32_t>((size_t)T + 1);
+  int32_t* d_rows = device_zeros<int32_t>((size_t)(B * F));
+  int32_t* d_hid = device_zeros<int32_t>((size_t)cap_h);
+  int32_t* d_items = device_zeros<int32_t>((size_t)(4 * cap_i));
+  int32_t* d_counts = device_zeros<int32_t>(4);
+  char* d_ws = device_zeros<char>((size_t)vfm_index_workspace_bytes(B, (int32_t)F, T));
   float* d_inv = device_zeros<float>((size_t)T);
   double* d_W = device_zeros<double>((size_t)F);
   float* d_pred = device_zeros<float>((size_t)B);
@@ -119,8 +119,17 @@ int main(int argc, char** argv) {
 
   VFM_OK(vfm_inv_occ_f32(d_occ, d_inv, T, st));                       // once per training set
   VFM_OK(vfm_batch_norms(&p, d_x, d_inv, d_W, st));                   // once per batch
+  VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, d_counts, st));
+  int32_t counts[4];
+  HIP_OK(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  if (counts[0] != 0) { fprintf(stderr, "%d ids out of range\n", counts[0]); return 1; }
   vfm_index_t idx{};
-  idx.occ_ptr = d_ptr; idx.occ_rows = d_rows;                         // (no heavy lists: uniform ids)
+  idx.occ_ptr = d_ptr; idx.occ_rows = d_rows;
+  if (counts[1] > 0) {                                                // lists longer than L: work items + scratch records
+    idx.heavy_ids = d_hid; idx.heavy_items = d_items; idx.n_heavy = counts[1]; idx.n_items = counts[2];
+    idx.heavy_acc = device_zeros<float>((size_t)(counts[1] + counts[2]) * (size_t)(4 + (d + 3) / 4 * 4));
+  }
   for (int s = 0; s < n_steps; ++s) {
     p.step = (uint64_t)s;
     VFM_OK(vfm_elbo_fwd_f32(&p, d_x, d_y, d_ent, d_bias, d_inv, d_scal, d_W, nullptr, nullptr, nullptr, d_pred,

@@ -167,6 +167,10 @@ typedef struct vfm_index {
   float* heavy_acc;
   int32_t n_heavy;
   int32_t n_items;
+  /* optional: the sorted ids of the entities the batch contains.  Given together with VFM_FLAG_ROWS_TOUCHED,
+   * vfm_elbo_bwd_adam_f32 walks this list instead of scanning all T table rows (lazy Adam step). */
+  const int32_t* touched_ids;
+  int64_t n_touched;
 } vfm_index_t;
 
 int vfm_abi_version(void);
@@ -182,12 +186,21 @@ const char* vfm_last_error(void);
  *   heavy_list  entities with MORE occurrences than this get an entry in heavy_ids (id order) and
  *             ceil(count / heavy_list) work items (slot, begin, end, 0) in heavy_items [cap_items,4];
  *             capacities that always suffice: cap_heavy = B*F / heavy_list + 1, cap_items = 2*B*F / heavy_list + 2
+ *   touched_ids  NULL, or room for min(B*F, T) int32: receives the sorted ids of the entities the batch
+ *             contains (the row list of the lazy Adam step, vfm_index_t.touched_ids)
  *   counts    [4] int32, DEVICE: (ids outside [0,T) met -- they are indexed as id 0, like the forward
- *             clamps them --, n_heavy, n_items, 0): the caller reads them back once to fill vfm_index_t */
+ *             clamps them --, n_heavy, n_items, n_touched = entities in the batch): the caller reads them
+ *             back once to fill vfm_index_t */
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
+/* The heavy-list length to build an index with: VFM_HEAVY_LIST when the table has at least VFM_HEAVY_UNITS rows
+ * (one lane group per row already fills the chip and only the really long lists need cutting), else about
+ * n_occ / VFM_HEAVY_UNITS occurrences per work item, never below VFM_HEAVY_MIN (small tables -- ML-100K shape:
+ * 2,625 entities in ~60 rows each -- get their parallelism from the work items).  env VFM_HEAVY_LIST overrides. */
+#define VFM_HEAVY_UNITS 8192
+int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T);
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream);
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* counts, void* stream);
 
 /* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
  * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */
@@ -321,6 +334,24 @@ int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
  * pointers 16-byte aligned. */
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, void* stream);
+
+/* Lazy EXACT dense Adam for sparse-touch regimes (Criteo shape: a batch touches 6 % of the table).  With
+ * VFM_FLAG_SCALED_MOMENTS a row without gradient keeps its stored moments and its parameters move by a function
+ * of (p, m, v) and the step's constants alone -- so the caller may SKIP such rows (vfm_elbo_bwd_adam_f32 with
+ * VFM_FLAG_ROWS_TOUCHED) and replay the skipped zero-gradient updates later with this call, bitwise as the
+ * dense kernel would have applied them (same fp32 operations, same order):
+ *   for every listed row e (ids [n] int32, or NULL = all T rows, n == T): apply the updates of Adam steps
+ *   last_step[e]+1 .. upto, then last_step[e] = mark (>= upto: `mark = upto + 1` when the caller is about to
+ *   apply step upto+1 to exactly these rows).
+ * lr_of_step (HOST memory): the learning rate of the 1st, 2nd, ... step of the moment period containing `upto`
+ * (steps P+1 .. upto, P = floor((upto-1) / VFM_MOMENT_PERIOD) * VFM_MOMENT_PERIOD).  A row must not lag across
+ * a period boundary: at the last step of every period (step % VFM_MOMENT_PERIOD == 0) the caller brings ALL
+ * rows up to date and runs the dense call (which writes the plain moments for all rows).
+ * Call it on a batch's rows before the forward of a step, and on all rows before predicting / saving. */
+int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,
+                         const float* m_bias, const float* v_bias, int32_t* last_step, const int32_t* ids, int64_t n,
+                         int64_t T, int32_t d, const float* lr_of_step, float beta1, float beta2, float eps_adam,
+                         int64_t upto, int64_t mark, void* stream);
 
 /* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
  * both tables; the only per-step exchange is one all-reduce of B + VFM_MAX_FWD_BLOCKS floats):

@@ -44,6 +44,21 @@ def test_problem_struct_layout_matches_header(tmp_path):
                    Problem.coord_off.offset]
 
 
+def test_index_struct_layout_matches_header(tmp_path):
+    import subprocess
+    from vae_amd._lib import Index
+    src = tmp_path / "ix.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(vfm_index_t), offsetof(vfm_index_t, heavy_acc),'
+                   'offsetof(vfm_index_t, n_items), offsetof(vfm_index_t, touched_ids), offsetof(vfm_index_t, n_touched));'
+                   'return 0;}\n')
+    exe = tmp_path / "ix"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(Index), Index.heavy_acc.offset, Index.n_items.offset, Index.touched_ids.offset,
+                   Index.n_touched.offset]
+
+
 def test_problem_mirror_has_every_header_field_and_rejects_unknown_names():
     """Every member of vfm_problem_t is a ctypes field of the same name (ctypes would otherwise keep an
     assignment as a plain Python attribute and pass 0 to the library), and a flag set through the mirror

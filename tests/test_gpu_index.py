@@ -57,6 +57,8 @@ def test_index_equals_stable_sort(B, sizes, zipf, dtype):
         assert plan.heavy[2].numel() == (len(heavy_want) + len(items_want)) * (4 + 8)
     else:
         assert plan.heavy is None
+    uniq = np.unique(X.cpu().numpy())
+    assert plan.U == len(uniq) and np.array_equal(plan.touched_ids().cpu().numpy(), uniq)
     # W (vfm_batch_norms) with inv_occ = 1 is the row count of every column
     assert np.allclose(plan.W.cpu().numpy(), B)
 

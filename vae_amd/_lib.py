@@ -31,8 +31,8 @@ EXPORTS = (
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
-    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index",
-    "vfm_variant_fwd_f32", "vfm_variant_bwd_f32",
+    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
+    "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_adam_catchup_f32",
 )
 
 
@@ -63,23 +63,12 @@ class Index(C.Structure):
     """Mirror of `vfm_index_t`."""
     _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
                 ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
-                ("n_items", C.c_int32)]
-
-
-HEAVY_LIST = int(os.environ.get("VFM_HEAVY_LIST", "0"))    # 0: chosen per plan (heavy_list_for); else >= 8 (VFM_HEAVY_MIN)
-HEAVY_UNITS = 8192     # lane groups' worth of independent work the entity-centric backward should have
+                ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64)]
 
 
 def heavy_list_for(n_occ: int, T: int) -> int:
-    """Length above which an occurrence list is cut in work items (vfm_index_t).  With many table rows the
-    backward has one lane group per row and only the few really long lists need cutting (64).  With a small
-    table (ML-100K shape: 2,625 entities, ~60 rows each per batch) the rows alone do not fill the chip, so the
-    lists are cut finer -- about n_occ / HEAVY_UNITS occurrences per work item, never below VFM_HEAVY_MIN."""
-    if HEAVY_LIST:
-        return max(8, HEAVY_LIST)
-    if T >= HEAVY_UNITS:
-        return 64
-    return max(8, min(64, n_occ // HEAVY_UNITS))
+    """Length above which an occurrence list is cut in work items: the library's rule (vfm_heavy_list_for)."""
+    return int(load().vfm_heavy_list_for(int(n_occ), int(T)))
 
 
 class VfmLibraryError(RuntimeError):
@@ -125,7 +114,10 @@ def load():
     lib.vfm_elbo_lik_f32.argtypes = [PP, vp, vp, vp, vp, vp, vp, vp]
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
-    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp]
+    lib.vfm_heavy_list_for.argtypes = [i64, i64]
+    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp]
+    lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
+                                         i64, i64, vp]
     lib.vfm_variant_fwd_f32.argtypes = [PP, i32] + [vp] * 18
     lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
     for name in EXPORTS:

@@ -180,7 +180,7 @@ int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow,
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
                      (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d);
-  nb = ((int64_t)idx->n_heavy + GPB - 1) / GPB;
+  nb = idx->n_heavy;                                             // one workgroup per heavy entity
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy_sum<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
                      (int)idx->n_items, (int)idx->n_heavy, item_acc, hacc, d);
@@ -347,7 +347,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias,
-            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr};
+            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
@@ -387,7 +387,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                       eps_bias, eps_global);
   a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr};
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   if (!untouched_only)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -395,8 +395,15 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = dispatch_bwd(p, s, eps, (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1, a, b, ad, (hipStream_t)stream))
-    return rc;
+  int adam = (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1;
+  if (rows_flags == VFM_FLAG_ROWS_TOUCHED && idx->touched_ids && idx->n_touched >= 0) {
+    // the rows of the batch as a LIST (lazy exact Adam): the skip-untouched instances walk it instead of scanning
+    // all T rows; same arithmetic as the dense instances on the rows they visit
+    b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
+    a.row_filter = 0;
+    adam = 2;
+  }
+  if (int rc = dispatch_bwd(p, s, eps, adam, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");
 }
 
@@ -410,7 +417,7 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
-            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr};
+            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   // (the pre-reduction covers whole lists, so with several entity chunks it runs with the first one)
   if (p->e_lo == 0)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
@@ -446,7 +453,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   if (rec_pos != nullptr && rec_ptr == nullptr)      // (rec_pos may be NULL when rec_ptr lists no record at all)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_pos without rec_ptr");
   BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws};
+            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -523,6 +530,38 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
   hipLaunchKernelGGL(k_adam, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
                      beta2, eps, step_size, bc2_sqrt);
   return after_launch("vfm_adam_f32");
+}
+
+int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,
+                         const float* m_bias, const float* v_bias, int32_t* last_step, const int32_t* ids, int64_t n,
+                         int64_t T, int32_t d, const float* lr_of_step, float beta1, float beta2, float eps_adam,
+                         int64_t upto, int64_t mark, void* stream) {
+  if (!entity_params || !bias_params || !m_entity || !v_entity || !m_bias || !v_bias || !last_step || n < 0 || T < 1 ||
+      d < 1 || upto < 0 || mark < upto || mark > 0x7FFFFFFFLL || (ids == nullptr && n != T))
+    return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: bad argument (ids == NULL means all T rows: n == T)");
+  if (d & 1) return fail(VFM_E_UNSUPPORTED, "vfm_adam_catchup_f32: odd embedding size");
+  if (n == 0 || upto == 0) {          // nothing to replay (before the first step); still stamp the rows
+    if (n == 0) return 0;
+  }
+  // the steps of the moment period that contains `upto`: period_start + 1 .. upto
+  const int64_t pstart = upto > 0 ? ((upto - 1) / VFM_MOMENT_PERIOD) * VFM_MOMENT_PERIOD : 0;
+  const int kmax = (int)(upto - pstart);
+  if (kmax > 0 && !lr_of_step) return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: lr_of_step (host, one per step of the period) is NULL");
+  CatchTab tab;
+  memset(&tab, 0, sizeof(tab));
+  for (int k = 1; k <= kmax; ++k) {   // exactly the constants vfm_elbo_bwd_adam_f32 forms for that step
+    float step_size, bc2_sqrt;
+    adam_consts(lr_of_step[k - 1], beta1, beta2, pstart + k, &step_size, &bc2_sqrt);
+    const double s1 = pow((double)beta1, (double)k), s2 = pow((double)beta2, (double)k);
+    if (!(s1 > 1e-30) || !(s2 > 1e-30)) return fail(VFM_E_UNSUPPORTED, "vfm_adam_catchup_f32: beta^k underflows");
+    tab.c[k] = make_float4(step_size, (float)s1, (float)s2, 1.0f / bc2_sqrt);
+  }
+  int64_t nb = (n + BLOCK / 64 - 1) / (BLOCK / 64);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_adam_catchup, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
+                     m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
+                     (int32_t)mark, eps_adam, tab);
+  return after_launch("vfm_adam_catchup_f32");
 }
 
 int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,

@@ -39,6 +39,67 @@ __global__ __launch_bounds__(BLOCK) void k_adam(float* __restrict__ p, const flo
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Lazy EXACT dense Adam (sparse-touch regimes: Criteo shape, 6 % of the rows in a batch).  Dense Adam moves
+// every row every step; a row WITHOUT gradient moves by a function of its own (p, m, v) and the step's
+// constants only, and in the scaled-moment form (VFM_FLAG_SCALED_MOMENTS) its stored moments do not change
+// at all.  So such a row can be skipped and REPLAYED later: k_adam_catchup applies the zero-gradient updates
+// of the steps last_step[e]+1 .. upto to the listed rows, with the same fp32 operations in the same order as
+// k_bwd<ADAM> (adam_update, scaled form, g = 0) -- bitwise the dense trajectory.  The constants of the steps
+// of the current moment period travel by value as a kernel argument (2 KB).  One wave per row.
+// ---------------------------------------------------------------------------------------
+struct CatchTab {
+  float4 c[VFM_MOMENT_PERIOD + 1];      // c[k] = (step_size, s1 = b1^k, s2 = b2^k, 1 / sqrt(bc2)) of the k-th step of the period
+};
+
+__device__ __forceinline__ float catchup_one(float p, float m, float v, const float4 c, float eps) {
+  const float mt = m * c.y, vt = v * c.z;
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(vt), c.w, eps);
+  return fmaf(-c.x * mt, __builtin_amdgcn_rcpf(denom), p);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ entity, float* __restrict__ bias,
+                                                        const float* __restrict__ m_entity, const float* __restrict__ v_entity,
+                                                        const float* __restrict__ m_bias, const float* __restrict__ v_bias,
+                                                        int32_t* __restrict__ last_step, const int32_t* __restrict__ ids,
+                                                        int64_t n, int d, int32_t pstart, int32_t upto, int32_t mark,
+                                                        float eps, const CatchTab tab) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * (BLOCK / 64);
+  const int n4 = (2 * d) >> 2;                     // float4 pieces of an entity row (d % 2 == 0 checked on the host)
+  for (int64_t i = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); i < n; i += nw) {
+    const int64_t e = ids ? (int64_t)ids[i] : i;
+    int k0 = last_step[e] - pstart;
+    const int k1 = upto - pstart;
+    if (k0 < 0) k0 = 0;                            // (never: a period boundary brings every row up to date)
+    if (k1 > k0) {
+      const size_t ro = (size_t)e * (2 * (size_t)d);
+      for (int j = lane; j < n4; j += 64) {
+        float4 p = reinterpret_cast<float4*>(entity + ro)[j];
+        const v4f m = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j);
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j);
+        for (int k = k0 + 1; k <= k1; ++k) {
+          const float4 c = tab.c[k];
+          p.x = catchup_one(p.x, m.x, v.x, c, eps); p.y = catchup_one(p.y, m.y, v.y, c, eps);
+          p.z = catchup_one(p.z, m.z, v.z, c, eps); p.w = catchup_one(p.w, m.w, v.w, c, eps);
+        }
+        reinterpret_cast<float4*>(entity + ro)[j] = p;
+      }
+      if (lane == 0) {
+        float2 p = *reinterpret_cast<float2*>(bias + 2 * (size_t)e);
+        const float2 m = *reinterpret_cast<const float2*>(m_bias + 2 * (size_t)e);
+        const float2 v = *reinterpret_cast<const float2*>(v_bias + 2 * (size_t)e);
+        for (int k = k0 + 1; k <= k1; ++k) {
+          const float4 c = tab.c[k];
+          p.x = catchup_one(p.x, m.x, v.x, c, eps); p.y = catchup_one(p.y, m.y, v.y, c, eps);
+        }
+        *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = p;
+      }
+    }
+    if (lane == 0) last_step[e] = mark;
+  }
+}
+
 // m *= c1, v *= c2 (conversion between the plain and the scaled moment representation)
 __global__ __launch_bounds__(BLOCK) void k_rescale2(float* __restrict__ m, float* __restrict__ v, int64_t n, float c1,
                                                     float c2) {

@@ -128,11 +128,16 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   // loop runs over the local index li and the statistics records are indexed by li
   const bool sharded = STAGE == STAGE_APPLY && a.own_mod > 1;
   float klacc = 0.f;                                   // sum of c_e * KL_e over this thread's entities
-  int64_t li = a.e_lo + (int64_t)blockIdx.x * GPB + tid / LPE;
+  // ADAM == 2 with a row list: li runs over the list (the batch's entities), not over the table
+  const bool listed = ADAM == 2 && STAGE == STAGE_FULL && b.row_ids != nullptr;
+  const int64_t li_end = listed ? b.n_rows : a.e_hi;
+  int64_t li = (listed ? 0 : a.e_lo) + (int64_t)blockIdx.x * GPB + tid / LPE;
+  int64_t e_cur = li;
+  if (ADAM == 2 && listed && li < li_end) e_cur = b.row_ids[li];
   int2 pq = make_int2(0, 0);
-  if (STAGE != STAGE_APPLY && li < a.e_hi) pq = make_int2(b.occ_ptr[li], b.occ_ptr[li + 1]);
-  for (; li < a.e_hi; li += stride) {
-    const int64_t e = sharded ? (int64_t)a.own_rank + li * a.own_mod : li;
+  if (STAGE != STAGE_APPLY && li < li_end) pq = make_int2(b.occ_ptr[e_cur], b.occ_ptr[e_cur + 1]);
+  for (; li < li_end; li += stride) {
+    const int64_t e = (ADAM == 2 && listed) ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
     int beg = pq.x, end = pq.y;
     const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
@@ -149,7 +154,11 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       }
       beg = 0; end = 0;
     } else {
-      if (en < a.e_hi) pq = make_int2(b.occ_ptr[en], b.occ_ptr[en + 1]);   // next entity's offsets, early
+      if (en < li_end) {                                                    // next entity's offsets, early
+        const int64_t e_next = (ADAM == 2 && listed) ? (int64_t)b.row_ids[en] : en;
+        e_cur = e_next;
+        pq = make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]);
+      }
     }
     float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
     float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);

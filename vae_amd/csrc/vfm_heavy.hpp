@@ -62,20 +62,32 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
   }
 }
 
-// heavy entity `slot`: sum of its work items' records (the items of a slot are consecutive and in list order)
+// heavy entity `slot`: sum of its work items' records (the items of a slot are consecutive and in list order).
+// One WORKGROUP per slot: lane group g adds the items lo+g, lo+g+GPB, ... in that order, then the GPB partial
+// records are added in group order through LDS -- a fixed summation tree, whatever the scheduling.
 template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__ items, int n_items, int n_heavy,
                                                      const float* __restrict__ item_acc,
                                                      float* __restrict__ heavy_acc, int d) {
   constexpr int GPB = BLOCK / LPE;
-  const int lig = threadIdx.x % LPE;
+  __shared__ float sh[BLOCK * CPL * VEC + 2 * GPB];
+  const int lig = threadIdx.x % LPE, grp = threadIdx.x / LPE;
   const int C = (d + VEC - 1) / VEC;
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
-  for (int slot = blockIdx.x * GPB + threadIdx.x / LPE; slot < n_heavy; slot += gridDim.x * GPB) {
+  for (int slot = blockIdx.x; slot < n_heavy; slot += gridDim.x) {
     int lo = 0, hi = n_items;                 // first item of this slot
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (items[4 * mid] < slot) lo = mid + 1; else hi = mid;
+    }
+    int end = lo;                             // one past its last item
+    {
+      int l2 = lo, h2 = n_items;
+      while (l2 < h2) {
+        const int mid = (l2 + h2) >> 1;
+        if (items[4 * mid] <= slot) l2 = mid + 1; else h2 = mid;
+      }
+      end = l2;
     }
     Chunk<VEC> A[CPL];
 #pragma unroll
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__
 #pragma unroll
       for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
     float gs = 0.f, cnt = 0.f;
-    for (int it = lo; it < n_items && items[4 * it] == slot; ++it) {
+    for (int it = lo + grp; it < end; it += GPB) {
       const float* rec = item_acc + (size_t)it * xs;
       gs += rec[0]; cnt += rec[1];
 #pragma unroll
@@ -96,12 +108,32 @@ __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__
         }
       }
     }
-    float* out = heavy_acc + (size_t)slot * xs;
+    __syncthreads();                          // (LDS of the previous slot has been read)
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int j = lig + i * LPE;
-      if (j < C) st_chunk<VEC>(out + 4 + (size_t)j * VEC, A[i]);
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) sh[((grp * CPL + i) * VEC + t) * LPE + lig] = A[i].v[t];
+    if (lig == 0) { sh[BLOCK * CPL * VEC + 2 * grp] = gs; sh[BLOCK * CPL * VEC + 2 * grp + 1] = cnt; }
+    __syncthreads();
+    if (grp == 0) {
+      float* out = heavy_acc + (size_t)slot * xs;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int j = lig + i * LPE;
+        Chunk<VEC> tot;
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+          float acc = 0.f;
+          for (int g2 = 0; g2 < GPB; ++g2) acc += sh[((g2 * CPL + i) * VEC + t) * LPE + lig];
+          tot.v[t] = acc;
+        }
+        if (j < C) st_chunk<VEC>(out + 4 + (size_t)j * VEC, tot);
+      }
+      if (lig == 0) {
+        float tg = 0.f, tc = 0.f;
+        for (int g2 = 0; g2 < GPB; ++g2) { tg += sh[BLOCK * CPL * VEC + 2 * g2]; tc += sh[BLOCK * CPL * VEC + 2 * g2 + 1]; }
+        *reinterpret_cast<float4*>(out) = make_float4(tg, tc, 0.f, 0.f);
+      }
     }
-    if (lig == 0) *reinterpret_cast<float4*>(out) = make_float4(gs, cnt, 0.f, 0.f);
   }
 }

@@ -69,32 +69,42 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
   hist[(size_t)threadIdx.x * NB + blockIdx.x] = sh[threadIdx.x];
 }
 
-// exclusive prefix sum of a[0..m) in place, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t* __restrict__ a, int m) {
-  __shared__ uint32_t sh[1024 / 64];
-  __shared__ uint32_t sh_total;
-  const int tid = threadIdx.x;
-  const int chunk = (m + 1023) / 1024;
-  const int beg = tid * chunk, end = (beg + chunk < m) ? beg + chunk : m;
+// exclusive prefix sum over hist[digit][tile] in (digit-major, tile-minor) order, in place.  One workgroup of
+// 1024 threads: 4 threads per digit, each owning a contiguous quarter of the tiles (a serial walk over a
+// [256 * NB] array by fewer threads is a 30 us latency chain at NB = 98).
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist, int NB) {
+  __shared__ uint32_t sh_dig[256];
+  const int tid = threadIdx.x, dg = tid >> 2, part = tid & 3;
+  const int per = (NB + 3) >> 2;
+  const int b0 = part * per, b1 = (b0 + per < NB) ? b0 + per : NB;
+  uint32_t* row = hist + (size_t)dg * NB;
   uint32_t s = 0;
-  for (int i = beg; i < end; ++i) s += a[i];
-  // exclusive scan of the 1024 chunk sums: inside the wave with shuffles, across the 16 waves through LDS
+  for (int b = b0; b < b1; ++b) s += row[b];
+  // the 4 parts of a digit sit in adjacent lanes: inclusive scan over the quad
   uint32_t incl = s;
+  {
+    uint32_t t = __shfl_up(incl, 1, 64); if (part >= 1) incl += t;
+    t = __shfl_up(incl, 2, 64);          if (part >= 2) incl += t;
+  }
+  if (part == 3) sh_dig[dg] = incl;              // total of the digit
+  __syncthreads();
+  if (tid < 64) {                                // exclusive scan of the 256 digit totals: 4 per lane + wave scan
+    uint32_t v[4], tot = 0;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o, 64);
-    if ((tid & 63) >= o) incl += t;
+    for (int i = 0; i < 4; ++i) { v[i] = sh_dig[4 * tid + i]; tot += v[i]; }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += t;
+    }
+    uint32_t run = inc - tot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh_dig[4 * tid + i] = run; run += v[i]; }
   }
-  if ((tid & 63) == 63) sh[tid >> 6] = incl;
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int w = 0; w < 1024 / 64; ++w) { const uint32_t t = sh[w]; sh[w] = run; run += t; }
-    sh_total = run;
-  }
-  __syncthreads();
-  uint32_t run = sh[tid >> 6] + incl - s;
-  for (int i = beg; i < end; ++i) { const uint32_t t = a[i]; a[i] = run; run += t; }
+  uint32_t run = sh_dig[dg] + incl - s;
+  for (int b = b0; b < b1; ++b) { const uint32_t t = row[b]; row[b] = run; run += t; }
 }
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ kin,
@@ -164,67 +174,77 @@ __global__ __launch_bounds__(RS_THREADS) void k_index_finish(const uint32_t* __r
   }
 }
 
-// ---- heavy lists: entities with more than L occurrences, in id order, + their work items ----
-__device__ __forceinline__ void heavy_of(const int32_t* occ_ptr, int64_t e, int64_t T, int L, int& cnt, int& beg) {
+// ---- compaction passes over the entities, in id order: (a) entities with more than L occurrences and their work
+// items, (b) the entities the batch contains at all (`touched`: the row list of the lazy Adam step) ----
+__device__ __forceinline__ void heavy_of(const int32_t* occ_ptr, int64_t e, int64_t T, int L, int& cnt, int& beg, bool& any) {
   cnt = 0; beg = 0;
   if (e < T) { beg = occ_ptr[e]; cnt = occ_ptr[e + 1] - beg; }
+  any = cnt > 0;
   if (cnt <= L) cnt = 0;
 }
 
 __global__ __launch_bounds__(HV_CHUNK) void k_heavy_count(const int32_t* __restrict__ occ_ptr, int64_t T, int L,
-                                                          uint32_t* __restrict__ blk /*[2][NBH]*/, int NBH) {
-  __shared__ uint32_t sh[2][HV_CHUNK / 64];
+                                                          uint32_t* __restrict__ blk /*[3][NBH]*/, int NBH) {
+  __shared__ uint32_t sh[3][HV_CHUNK / 64];
   const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + threadIdx.x;
-  int cnt, beg;
-  heavy_of(occ_ptr, e, T, L, cnt, beg);
-  uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u;
+  int cnt, beg; bool any;
+  heavy_of(occ_ptr, e, T, L, cnt, beg, any);
+  uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); c += __shfl_xor(c, m, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; sh[2][threadIdx.x >> 6] = c; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t ta = 0, tb = 0;
-    for (int w = 0; w < HV_CHUNK / 64; ++w) { ta += sh[0][w]; tb += sh[1][w]; }
-    blk[blockIdx.x] = ta; blk[NBH + blockIdx.x] = tb;
+  if (threadIdx.x < 3) {
+    uint32_t t = 0;
+    for (int w = 0; w < HV_CHUNK / 64; ++w) t += sh[threadIdx.x][w];
+    blk[(size_t)threadIdx.x * NBH + blockIdx.x] = t;
   }
 }
 
-// exclusive scans of the two block-count rows; totals -> counters[1], counters[2]
-__global__ __launch_bounds__(64) void k_heavy_scan(uint32_t* __restrict__ blk, int NBH, unsigned int* __restrict__ counters) {
-  if (threadIdx.x < 2) {
-    uint32_t* row = blk + (size_t)threadIdx.x * NBH;
-    uint32_t run = 0;
-    for (int i = 0; i < NBH; ++i) { const uint32_t t = row[i]; row[i] = run; run += t; }
-    counters[1 + threadIdx.x] = run;
+// exclusive scans of the three block-count rows (one wave each); totals -> counters[1..3]
+__global__ __launch_bounds__(192) void k_heavy_scan(uint32_t* __restrict__ blk, int NBH, unsigned int* __restrict__ counters) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* row = blk + (size_t)w * NBH;
+  uint32_t carry = 0;
+  for (int i0 = 0; i0 < NBH; i0 += 64) {
+    const int i = i0 + lane;
+    const uint32_t v = i < NBH ? row[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (i < NBH) row[i] = carry + inc - v;
+    carry += __shfl(inc, 63, 64);
   }
+  if (lane == 0) counters[1 + w] = carry;
 }
 
 __global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restrict__ occ_ptr, int64_t T, int L,
                                                           const uint32_t* __restrict__ blk, int NBH,
                                                           int32_t* __restrict__ heavy_ids, int32_t* __restrict__ items,
-                                                          int cap_h, int cap_i) {
-  __shared__ uint32_t sh[2][HV_CHUNK / 64];
+                                                          int cap_h, int cap_i, int32_t* __restrict__ touched_ids) {
+  __shared__ uint32_t sh[3][HV_CHUNK / 64];
   const int tid = threadIdx.x;
   const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
-  int cnt, beg;
-  heavy_of(occ_ptr, e, T, L, cnt, beg);
-  const uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u;
-  uint32_t ia = a, ib = b;                       // inclusive scans inside the wave
+  int cnt, beg; bool any;
+  heavy_of(occ_ptr, e, T, L, cnt, beg, any);
+  const uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
+  uint32_t ia = a, ib = b, ic = c;                // inclusive scans inside the wave
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
-    if ((tid & 63) >= o) { ia += ta; ib += tb; }
+    const uint32_t ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tc = __shfl_up(ic, o, 64);
+    if ((tid & 63) >= o) { ia += ta; ib += tb; ic += tc; }
   }
-  if ((tid & 63) == 63) { sh[0][tid >> 6] = ia; sh[1][tid >> 6] = ib; }
+  if ((tid & 63) == 63) { sh[0][tid >> 6] = ia; sh[1][tid >> 6] = ib; sh[2][tid >> 6] = ic; }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t ra = 0, rb = 0;
-    for (int w = 0; w < HV_CHUNK / 64; ++w) {
-      const uint32_t ta = sh[0][w], tb = sh[1][w];
-      sh[0][w] = ra; sh[1][w] = rb; ra += ta; rb += tb;
-    }
+  if (tid < 3) {
+    uint32_t r = 0;
+    for (int w = 0; w < HV_CHUNK / 64; ++w) { const uint32_t t = sh[tid][w]; sh[tid][w] = r; r += t; }
   }
   __syncthreads();
+  if (any && touched_ids) touched_ids[blk[2 * (size_t)NBH + blockIdx.x] + sh[2][tid >> 6] + ic - c] = (int32_t)e;
   if (cnt > 0) {
     const uint32_t slot = blk[blockIdx.x] + sh[0][tid >> 6] + ia - a;
     uint32_t it = blk[NBH + blockIdx.x] + sh[1][tid >> 6] + ib - b;
@@ -251,18 +271,26 @@ using namespace vfm;
 
 extern "C" {
 
+int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T) {
+  const int forced = env_int("VFM_HEAVY_LIST", 0);
+  if (forced > 0) return forced < VFM_HEAVY_MIN ? VFM_HEAVY_MIN : forced;
+  if (T >= VFM_HEAVY_UNITS) return VFM_HEAVY_LIST;
+  const int64_t l = n_occ / VFM_HEAVY_UNITS;
+  return (int32_t)(l < VFM_HEAVY_MIN ? VFM_HEAVY_MIN : (l > VFM_HEAVY_LIST ? VFM_HEAVY_LIST : l));
+}
+
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
   if (B < 0 || F < 1 || T < 1 || B * (int64_t)F > 0x7FFFFFFFLL) return -1;
   const int64_t n = B * F;
   const int64_t NB = (n + RS_TILE - 1) / RS_TILE;
   const int64_t NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
   // 4 key / value buffers, the radix histogram, the heavy block counts, a few counters
-  return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 4) * 4 + (2 * NBH + 4) * 4 + 64;
+  return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 4) * 4 + (3 * NBH + 4) * 4 + 64;
 }
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream) {
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* counts, void* stream) {
   if (B < 0 || F < 1 || F > VFM_MAX_FIELDS || T < 1 || T > 0xFFFFFFFELL || B * (int64_t)F > 0x7FFFFFFFLL ||
       (id_bits != 32 && id_bits != 64) || heavy_list < VFM_HEAVY_MIN)
     return fail(VFM_E_INVALID, "vfm_build_index: bad B, F, T, id_bits or heavy_list");
@@ -280,7 +308,7 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
   uint32_t* v1 = k1 + n4;
   uint32_t* hist = v1 + n4;
   uint32_t* blk = hist + (size_t)256 * NB + 4;
-  unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)2 * NBH + 4);
+  unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)3 * NBH + 4);
   hipError_t e = hipMemsetAsync(counters, 0, 16, st);
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index: memset");
   if (n > 0) {
@@ -291,7 +319,7 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
     const int passes = (key_bits(T) + 7) / 8;
     for (int p = 0; p < passes; ++p) {
       hipLaunchKernelGGL(k_radix_hist, dim3(NB), dim3(RS_THREADS), 0, st, k0, n, 8 * p, hist, NB);
-      hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, hist, 256 * NB);
+      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st, hist, NB);
       hipLaunchKernelGGL(k_radix_scatter, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
       uint32_t* t = k0; k0 = k1; k1 = t;
       t = v0; v0 = v1; v1 = t;
@@ -304,10 +332,10 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
     hipLaunchKernelGGL(k_index_finish, dim3((unsigned)g), dim3(RS_THREADS), 0, st, k0, v0, n, (int)F, T, occ_ptr, occ_rows);
   }
   hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, blk, NBH);
-  hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(64), 0, st, blk, NBH, counters);
+  hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);
   hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, blk, NBH, heavy_ids,
                      heavy_items, (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy),
-                     (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items));
+                     (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items), touched_ids);
   e = hipMemcpyAsync(counts, counters, 16, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index: copy of the counters");
   e = hipGetLastError();

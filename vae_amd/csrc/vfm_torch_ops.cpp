@@ -110,9 +110,13 @@ void elbo_finalize(Tensor partials, const Tensor& scalars, Tensor loss, int64_t 
 
 int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
 
-// index = [occ_ptr, occ_rows] or [occ_ptr, occ_rows, heavy_ids, heavy_items, heavy_acc]
-vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int64_t d, int64_t n_samples = 1) {
-  TORCH_CHECK(index.size() == 2 || index.size() == 5, "index = [occ_ptr, occ_rows] (+ [heavy_ids, heavy_items, heavy_acc])");
+// index = [occ_ptr, occ_rows] or [occ_ptr, occ_rows, heavy_ids, heavy_items, heavy_acc], each optionally followed by
+// [touched_ids] (3 or 6 tensors: the batch's entities as a sorted list, vfm_index_t.touched_ids)
+vfm_index_t index_of(at::TensorList index_all, int64_t T, int64_t B, int64_t F, int64_t d, int64_t n_samples = 1) {
+  TORCH_CHECK(index_all.size() == 2 || index_all.size() == 3 || index_all.size() == 5 || index_all.size() == 6,
+              "index = [occ_ptr, occ_rows] (+ [heavy_ids, heavy_items, heavy_acc]) (+ [touched_ids])");
+  const bool has_touched = index_all.size() == 3 || index_all.size() == 6;
+  at::TensorList index = index_all.slice(0, index_all.size() - (has_touched ? 1 : 0));
   dev_tensor(index[0], at::kInt, "occ_ptr"); dev_tensor(index[1], at::kInt, "occ_rows");
   TORCH_CHECK(index[0].numel() == T + 1 && index[1].numel() == B * F, "inverted index sizes");
   vfm_index_t ix{};
@@ -125,6 +129,11 @@ vfm_index_t index_of(at::TensorList index, int64_t T, int64_t B, int64_t F, int6
     ix.heavy_ids = index[2].data_ptr<int32_t>(); ix.heavy_items = index[3].data_ptr<int32_t>();
     ix.heavy_acc = index[4].data_ptr<float>();
     ix.n_heavy = (int32_t)index[2].numel(); ix.n_items = (int32_t)(index[3].numel() / 4);
+  }
+  if (has_touched) {
+    const at::Tensor& t = index_all[index_all.size() - 1];
+    dev_tensor(t, at::kInt, "touched_ids");
+    ix.touched_ids = t.numel() > 0 ? t.data_ptr<int32_t>() : nullptr; ix.n_touched = t.numel();
   }
   return ix;
 }

@@ -97,6 +97,16 @@ class VFM(nn.Module):
         # batch does not touch do not write their moments back; same dense Adam up to fp32 rounding)
         self.scaled_moments = True
         self._moments_scaled = False       # which form _adam_m / _adam_v are in right now
+        # Lazy EXACT dense Adam (single rank, fused step, scaled moments): rows a batch does not contain are skipped
+        # and their zero-gradient updates replayed -- bitwise as the dense kernel applies them -- right before a
+        # later batch (or predict / save) needs them.  Pays when a batch touches a small part of the table
+        # (Criteo shape: 6 %); "auto" turns it on per batch below `lazy_threshold` touched rows.  The trajectory
+        # is the dense one, bit for bit (tests/test_gpu_lazy_adam.py).
+        self.lazy_adam = "auto"
+        self.lazy_threshold = 0.35
+        self._lazy_last = None             # [T] int32: last Adam step applied to each row
+        self._lazy_dirty = False           # some rows lag behind _adam_t
+        self._lazy_lr = {}                 # {k: learning rate of the k-th step of the current moment period}
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
@@ -183,6 +193,12 @@ class VFM(nn.Module):
         # keep the parameters tied to the flat buffer across .to()/.cuda(); the kernels are fp32 only
         if fn(torch.zeros(1, dtype=torch.float32, device=self._flat.device)).dtype != torch.float32:
             raise TypeError("VFM computes in fp32 only (like the reference); dtype conversions are not supported")
+        if getattr(self, "_stale_group", None) is not None:
+            raise RuntimeError("sync_params() first: a sharded training mode holds slices / owned rows of the tables "
+                               "on this device")
+        self._dims = None            # (rebuilt from the full tables by the next dimension-sharded step)
+        if getattr(self, "_lazy_dirty", False):
+            self.sync_lazy()
         with torch.no_grad():
             cur = torch.cat([self.entity_params.weight.reshape(-1),
                              torch.zeros(self._off_bias - self._n_ent, device=self._flat.device),
@@ -193,10 +209,18 @@ class VFM(nn.Module):
         out = super()._apply(fn, *a, **k)
         self._flat = fn(cur)
         self._tie()
-        for name in ("inv_occ", "nb_occ", "_adam_m", "_adam_v", "_gflat", "_mean_flat", "_last_flat"):
+        for name in ("inv_occ", "nb_occ", "_adam_m", "_adam_v", "_gflat", "_mean_flat", "_last_flat", "_lazy_last",
+                     "_gout", "_partials"):
             t = getattr(self, name, None)
             if t is not None:
                 setattr(self, name, fn(t))
+        # buffers derived from the old device's tensors: rebuilt on demand (plans built before the move hold
+        # ids on the old device and must be rebuilt by the caller)
+        self.__dict__.pop("_view_cache", None)
+        self._xflat = None
+        self._shard_acc = self._shard_small = self._shard_klws = None
+        if getattr(self, "_state_bufs", None) is not None:
+            self._state_bufs = {}
         return out
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
@@ -210,6 +234,7 @@ class VFM(nn.Module):
         step count, the Philox step counter, the epoch-averaged posterior means of save_weights()."""
         if getattr(self, "_stale_group", None) is not None:
             self.sync_params(self._stale_group)       # (collective: every rank calls this together)
+        self.sync_lazy()
         opt = None
         if self._adam_m is not None:
             opt = {"m": self._adam_m.detach().cpu().clone(), "v": self._adam_v.detach().cpu().clone(),
@@ -231,6 +256,7 @@ class VFM(nn.Module):
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
+            self._lazy_last, self._lazy_dirty, self._lazy_lr = None, False, {}
         if getattr(self, "_dims", None) is not None:
             self._dims.scatter(self)
         if state.get("snapshots") is not None:
@@ -362,9 +388,37 @@ class VFM(nn.Module):
         self._stale_params = self._stale_moments = True
 
     def _fresh_params(self):
-        """Collective (every rank together): gather the parameters if a sharded mode left them stale."""
+        """Collective (every rank together): gather the parameters if a sharded mode left them stale; bring the rows
+        the lazy Adam mode skipped up to date."""
         if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_params", True):
             self.sync_params(self._stale_group, moments=False)
+        self.sync_lazy()
+
+    def sync_lazy(self):
+        """Lazy Adam mode: replay the skipped updates of every row (all rows are then at step _adam_t, exactly where
+        dense Adam has them).  A no-op otherwise.  Called before anything reads the parameters."""
+        if self._lazy_dirty:
+            ent, bia, _ = self._views(self._flat)
+            k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1
+            ops.adam_catchup(ent, bia, self._views(self._adam_m), self._views(self._adam_v), self._lazy_last, None,
+                             self._lazy_lrs(k), upto=self._adam_t, mark=self._adam_t)
+            self._lazy_dirty = False
+
+    def _lazy_lrs(self, kmax):
+        """Learning rates of steps 1..kmax of the current moment period (steps that were not fused steps are never
+        replayed -- every row was brought up to date before them -- so their entries are placeholders)."""
+        return [self._lazy_lr.get(k, 0.0) for k in range(1, kmax + 1)]
+
+    def state_dict(self, *a, **k):
+        self.sync_lazy()
+        return super().state_dict(*a, **k)
+
+    def _use_lazy(self, plan) -> bool:
+        if self.lazy_adam is True:
+            return True
+        if self.lazy_adam != "auto" or plan.B == 0:
+            return False
+        return plan.U < self.lazy_threshold * self.T
 
     @torch.no_grad()
     def save_weights(self):
@@ -446,6 +500,8 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
+        if process_group is not None:
+            self.sync_lazy()          # the multi-rank steps update every row they own
         # a step in another mode than the one that left the full tables stale: bring them up to date first
         if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_kind", None) not in (
                 None, self.exchange if process_group is not None else "single"):
@@ -475,10 +531,36 @@ class VFM(nn.Module):
         if fused is None:
             fused = self.fuse_adam
         fused = fused and adam and process_group is None
+        lazy = rows = None
         if fused:
             scaled = self.scaled_moments and not self.sparse_adam
             self._set_moment_form(scaled)
             self._adam_t += 1
+            lazy = scaled and self.n_samples >= 1 and self._use_lazy(plan)
+            k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1            # position of this step in its moment period
+            if k == 1:
+                self._lazy_lr = {}
+            self._lazy_lr[k] = float(lr)
+            if lazy or self._lazy_dirty:
+                if self._lazy_last is None:
+                    self._lazy_last = torch.empty(self.T, dtype=torch.int32, device=self.device)
+                if not self._lazy_dirty:     # no row lags: every row is at the step before this one, however it got there
+                    self._lazy_last.fill_(self._adam_t - 1)
+                mv, vv = self._views(self._adam_m), self._views(self._adam_v)
+                if lazy and k < ops.MOMENT_PERIOD:
+                    # rows of this batch: replay what they skipped, they get step _adam_t below; the others wait
+                    ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
+                                     upto=self._adam_t - 1, mark=self._adam_t)
+                    rows, self._lazy_dirty = "touched", True
+                else:
+                    # last step of a moment period (the dense kernel rewrites every row's moments), or a dense step
+                    # after lazy ones: every row up to date first, then the ordinary dense step
+                    ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, None, self._lazy_lrs(k - 1),
+                                     upto=self._adam_t - 1, mark=self._adam_t)
+                    self._lazy_dirty = False
+                mark("catchup")
+        elif self._lazy_dirty:
+            self.sync_lazy()
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
                               train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
@@ -487,7 +569,7 @@ class VFM(nn.Module):
             # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
                                    self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                   sparse=self.sparse_adam, scaled_moments=scaled)
+                                   sparse=self.sparse_adam, scaled_moments=scaled, rows=rows)
             mark("bwd_adam")
             return loss3, st.pred
         stats = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1

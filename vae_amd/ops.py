@@ -160,10 +160,13 @@ class BatchPlan:
         hid = torch.empty(cap_h, dtype=torch.int32, device=dev)
         items = torch.empty(cap_i, 4, dtype=torch.int32, device=dev)
         counts = torch.empty(4, dtype=torch.int32, device=dev)
+        touched = torch.empty(max(min(n, spec.T), 1), dtype=torch.int32, device=dev)
         check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
-                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(counts),
+                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched), ptr(counts),
                                   current_stream_ptr(dev)), "vfm_build_index")
-        n_bad, n_heavy, n_items, _ = (int(v) for v in counts.tolist())     # the plan build's one readback
+        n_bad, n_heavy, n_items, n_touched = (int(v) for v in counts.tolist())     # the plan build's one readback
+        self.U = n_touched                              # entities in the batch
+        self._touched = touched[:n_touched]
         if validate and n_bad and not self._checked:
             # nn.Embedding would raise IndexError (vfm-torch.py:207)
             raise IndexError(f"entity id out of range [0,{spec.T}): min {int(self.x.min())}, max {int(self.x.max())}")
@@ -177,12 +180,21 @@ class BatchPlan:
             self.heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
                           torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
 
-    def index_tensors(self):
-        """What the backward-family ops take as `index`."""
+    def touched_ids(self) -> torch.Tensor:
+        """Sorted ids of the entities this batch contains (int32; made by the index build)."""
+        if self.occ_ptr is None:
+            self.build_index()
+        return self._touched
+
+    def index_tensors(self, with_touched: bool = False):
+        """What the backward-family ops take as `index` (with_touched: + the batch's entities as a list, for the
+        touched-rows step of the lazy exact Adam mode)."""
         if self.occ_ptr is None:
             self.build_index()
         base = [self.occ_ptr, self.occ_rows]
-        return base + list(self.heavy) if self.heavy is not None else base
+        if self.heavy is not None:
+            base = base + list(self.heavy)
+        return base + [self._touched] if with_touched else base
 
 
 @dataclass
@@ -271,7 +283,8 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
     p, spec = st.problem, plan.spec
-    _lib.ops().elbo_bwd_adam(plan.index_tensors(), entity_params, bias_params, scalars, inv_occ, plan.W,
+    _lib.ops().elbo_bwd_adam(plan.index_tensors(with_touched=rows == "touched"), entity_params, bias_params, scalars,
+                             inv_occ, plan.W,
                              e[0], e[1], e[2], st.sumz, st.grow, st.partials, m_views[0], v_views[0],
                              m_views[1], v_views[1], m_views[2], v_views[2], spec.F, list(spec.group_hi),
                              list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
@@ -279,6 +292,19 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples,
                              p.coord_off)
+
+
+def adam_catchup(entity_params, bias_params, m_views, v_views, last_step, ids, lr_of_step, upto, mark,
+                 beta1=0.9, beta2=0.999, eps_adam=1e-8):
+    """Launch vfm_adam_catchup_f32 (lazy exact dense Adam): replay the skipped zero-gradient updates of steps
+    last_step[e]+1 .. upto on the rows `ids` (int32 tensor; None = all rows), then stamp them with `mark`."""
+    T, d = entity_params.shape[0], entity_params.shape[1] // 2
+    n = T if ids is None else ids.numel()
+    lrs = (C.c_float * max(len(lr_of_step), 1))(*[float(v) for v in lr_of_step])
+    check(_lib.load().vfm_adam_catchup_f32(ptr(entity_params), ptr(bias_params), ptr(m_views[0]), ptr(v_views[0]),
+                                           ptr(m_views[1]), ptr(v_views[1]), ptr(last_step), ptr(ids), n, T, d, lrs,
+                                           beta1, beta2, eps_adam, int(upto), int(mark),
+                                           current_stream_ptr(entity_params.device)), "vfm_adam_catchup_f32")
 
 
 def exchange_record_len(d: int) -> int:
