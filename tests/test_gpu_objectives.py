@@ -115,9 +115,8 @@ def test_variants_vs_oracle(seed):
         tol = 0.2 if F == 1 and objective == "sampled" else 5e-4      # (F = 1 sampled: A - z*sum(g) is pure cancellation)
         assert rel_err(g_ent.cpu().numpy(), Pt["entity_params"].grad.numpy()) < tol, cfg
         assert rel_err(g_bias.cpu().numpy(), Pt["bias_params"].grad.numpy()) < 5e-4, cfg
-        want_sc = np.array([Pt[k].grad.numpy()[0] for k in ("alpha", "global_bias_mean", "global_bias_scale")])
-        if output == "class":
-            want_sc[0] = 0.0
+        want_sc = np.array([0.0 if Pt[k].grad is None else Pt[k].grad.numpy()[0]       # (alpha: unused by Bernoulli)
+                            for k in ("alpha", "global_bias_mean", "global_bias_scale")])
         mag = np.abs(r["pred"].detach().numpy()).sum() * spec.nb_train / B + 1.0      # scale of the summed terms
         assert np.all(np.abs(g_sc.cpu().numpy() - want_sc) <= 5e-4 * np.abs(want_sc) + 2e-4 * mag), cfg
         if use_pri:

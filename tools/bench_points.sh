@@ -1,0 +1,37 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): the measurement points SURVEY 8(d) asks for besides the default bench line, one
+# JSON line each, into gpurun_out/points_$1.jsonl  (copy the file to profiles/ to have it judged).
+#   cfg2 (ML-100K shape) | cfg3 at B = 1,048,576 rows | cfg3 with Zipf(1.1) item popularity | cfg5 shape on one GPU
+#   (lazy exact Adam: auto) and the same with the dense step | cfg3 forward A/B: k_fwd (every occurrence sampled),
+#   k_fwd2 with table eps, k_fwd2 with the RNG compiled out
+# usage: tools/bench_points.sh r02
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/points_$TAG.jsonl
+mkdir -p $R/gpurun_out
+: > $OUT
+run() {  # label, env assignments (may be empty), bench args...
+  local label=$1; shift
+  local envs=$1; shift
+  echo "[points] $label" >&2
+  env $envs python3 $R/bench.py "$@" --no-cpu-baseline 2>> $R/gpurun_out/points_$TAG.err | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); j['point']='$label'; print(json.dumps(j))" >> $OUT || echo "{\"point\": \"$label\", \"error\": true}" >> $OUT
+}
+run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30
+run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6
+run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
+run cfg5_criteo_d256_lazy_auto "" --workload criteo_d256 --steps 200 --warmup 20
+run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --steps 40 --warmup 4
+run cfg3_fwd_ab_k_fwd "VFM_FWD_KERNEL=1" --steps 200 --warmup 20 --no-regions
+run cfg3_fwd_ab_k_fwd2 "" --steps 200 --warmup 20 --no-regions
+run cfg3_fwd_ab_k_fwd2_table_eps "" --fwd-eps table --steps 200 --warmup 20 --no-regions
+run cfg3_fwd_ab_k_fwd2_no_rng "VFM_FWD_AB_NORNG=1" --steps 200 --warmup 20 --no-regions
+run cfg3_unsorted_rows "" --no-sort --steps 200 --warmup 20 --no-regions
+python3 - <<PY
+import json
+for l in open("$OUT"):
+    j = json.loads(l)
+    if j.get("error"): print(j); continue
+    print(j["point"], "ms/step", j["ms_per_step"], "value", j["value"], {k: v["avg_us"] for k, v in j["kernels"].items()})
+PY

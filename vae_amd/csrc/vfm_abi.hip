@@ -396,12 +396,11 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   Shape s;
   pick_shape(p->d, &s);
   int adam = (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1;
-  if (rows_flags == VFM_FLAG_ROWS_TOUCHED && idx->touched_ids && idx->n_touched >= 0) {
-    // the rows of the batch as a LIST (lazy exact Adam): the skip-untouched instances walk it instead of scanning
-    // all T rows; same arithmetic as the dense instances on the rows they visit
+  if (rows_flags == VFM_FLAG_ROWS_TOUCHED && idx->touched_ids && idx->n_touched >= 0 && env_int("VFM_ROWS_LIST", 1) != 0) {
+    // the rows of the batch as a LIST (lazy exact Adam): the kernel walks it instead of scanning all T rows -- the
+    // same instance as the dense step, so both agree bit for bit on the rows they share
     b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
     a.row_filter = 0;
-    adam = 2;
   }
   if (int rc = dispatch_bwd(p, s, eps, adam, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");

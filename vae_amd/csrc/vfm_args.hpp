@@ -80,8 +80,8 @@ struct BwdArgs {
   int32_t n_heavy;
   int32_t heavy_stride;       // records per sample in heavy_acc (n_heavy + n_items)
   double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
-  // ADAM == 2 instances (rows outside the batch are skipped): the sorted ids of the rows to visit; NULL = scan
-  // all table rows.  The lazy exact-Adam step (VFM_FLAG_ROWS_TOUCHED + vfm_index_t.touched_ids) walks this list.
+  // fused-Adam instances: the sorted ids of the rows to visit; NULL = scan all table rows.  The lazy exact-Adam
+  // step (VFM_FLAG_ROWS_TOUCHED + vfm_index_t.touched_ids) walks this list.
   const int32_t* row_ids;
   int64_t n_rows;
 };

@@ -26,7 +26,7 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
   // (the untouched-rows launch shares the chip with the forward kernel: a small grid by default)
   const int per_cu = a.row_filter == 1 ? env_int("VFM_ADAMU_BLOCKS_PER_CU", 1) : env_int("VFM_BWD_BLOCKS_PER_CU", 8);
   int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
-  if (ADAM == 2 && b.row_ids) nb = (b.n_rows + GPB - 1) / GPB;     // the listed rows only
+  if (ADAM != 0 && b.row_ids) nb = (b.n_rows + GPB - 1) / GPB;     // the listed rows only
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;

@@ -128,16 +128,18 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   // loop runs over the local index li and the statistics records are indexed by li
   const bool sharded = STAGE == STAGE_APPLY && a.own_mod > 1;
   float klacc = 0.f;                                   // sum of c_e * KL_e over this thread's entities
-  // ADAM == 2 with a row list: li runs over the list (the batch's entities), not over the table
-  const bool listed = ADAM == 2 && STAGE == STAGE_FULL && b.row_ids != nullptr;
+  // fused Adam with a row list (the lazy exact-Adam step): li runs over the list (the batch's entities), not over
+  // the table.  The SAME instance serves the dense step, so the two agree bit for bit on the rows they share
+  // (different template instances are compiled with different fma contractions).
+  const bool listed = ADAM != 0 && STAGE == STAGE_FULL && b.row_ids != nullptr;
   const int64_t li_end = listed ? b.n_rows : a.e_hi;
   int64_t li = (listed ? 0 : a.e_lo) + (int64_t)blockIdx.x * GPB + tid / LPE;
   int64_t e_cur = li;
-  if (ADAM == 2 && listed && li < li_end) e_cur = b.row_ids[li];
+  if (ADAM != 0 && listed && li < li_end) e_cur = b.row_ids[li];
   int2 pq = make_int2(0, 0);
   if (STAGE != STAGE_APPLY && li < li_end) pq = make_int2(b.occ_ptr[e_cur], b.occ_ptr[e_cur + 1]);
   for (; li < li_end; li += stride) {
-    const int64_t e = (ADAM == 2 && listed) ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
+    const int64_t e = (ADAM != 0 && listed) ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
     int beg = pq.x, end = pq.y;
     const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       beg = 0; end = 0;
     } else {
       if (en < li_end) {                                                    // next entity's offsets, early
-        const int64_t e_next = (ADAM == 2 && listed) ? (int64_t)b.row_ids[en] : en;
+        const int64_t e_next = (ADAM != 0 && listed) ? (int64_t)b.row_ids[en] : en;
         e_cur = e_next;
         pq = make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]);
       }
