@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--fwd-eps", default="philox", choices=["philox", "table"],
                     help="A/B: eps of the forward / backward from tables (one fixed draw, as the parity tests feed "
                          "the reference's recorded draws) instead of the in-kernel Philox stream")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
+                    help="the software-pipelined step (the backward of step n writes the sample records of batch n+1, the "
+                         "forward gathers records: no sampling, no sumz); auto: from 2 rows per distinct entity")
     ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
     ap.add_argument("--lazy-adam", default="auto", choices=["auto", "on", "off"],
                     help="lazy exact dense Adam (rows outside the batch are skipped and replayed later, bitwise the dense "
@@ -123,6 +126,7 @@ def main():
     model.exchange = args.exchange
     model.scaled_moments = not args.plain_moments
     model.lazy_adam = {"auto": "auto", "on": True, "off": False}[args.lazy_adam]
+    model.pipeline = {"auto": "auto", "on": True, "off": False}[args.pipeline]
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -200,8 +204,12 @@ def main():
             v = float(t.item())
         return v
 
+    step_no = [0]                     # batches are cycled through in order across warm-up and timed region
+
     def run(n, record):
-        for s in range(n):
+        for _ in range(n):
+            s = step_no[0]
+            step_no[0] += 1
             if record:
                 ev = {}
                 events.append(ev)
@@ -212,7 +220,8 @@ def main():
                     ev[name] = e
             else:
                 mark = None
-            model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables)
+            model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables,
+                             next_plan=plans[(s + 1) % nbt] if (world == 1 and args.pipeline != "off") else None)
             if args.sync_each_step:
                 torch.cuda.synchronize()
 
@@ -287,6 +296,7 @@ def main():
     loss = float(model._gflat[model._n_flat].item())
     if world > 1 and model.exchange in ("sharded", "dims"):
         model.sync_params(pg)
+    model.sync_lazy()
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
@@ -354,6 +364,7 @@ def main():
                        "adam_moments": "scaled form (untouched rows do not write m, v)" if (
                            model.scaled_moments and world == 1 and not args.unfused) else "plain",
                        "lazy_exact_adam": bool(model._lazy_last is not None),
+                       "pipelined_step": bool(model._zrec is not None and world == 1),
                        "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
                        "exchange_autotune_ms_per_step": tune,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
@@ -362,7 +373,8 @@ def main():
                                  "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
                                          "on d/N coordinates"}[model.exchange]
                                 if world > 1 else "fwd+loss+bwd+dense-adam") if
-                               (world > 1 or args.unfused) else "fwd+loss+fused(bwd+dense-adam)",
+                               (world > 1 or args.unfused) else ("fwd(records)+loss+fused(bwd+dense-adam+next batch's sampling)" if (
+                                   model._zrec is not None) else "fwd+loss+fused(bwd+dense-adam)"),
                        "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
                                        f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
                        else f"row-sharded dp{world}"},
@@ -383,11 +395,11 @@ def kernel_report(events, model, args, world, B, d, F, U):
     kern = {}
     roof = None
     if events:
-        order = list(events[0].keys())           # marks in launch order: start, fwd, finalize, ...
-        acc = {k: 0.0 for k in order[1:]}
+        acc = {}                                  # marks in launch order: start, fwd, finalize, ...
         for ev in events:
+            order = list(ev.keys())
             for a_, b_ in zip(order[:-1], order[1:]):
-                acc[b_] += ev[a_].elapsed_time(ev[b_])
+                acc[b_] = acc.get(b_, 0.0) + ev[a_].elapsed_time(ev[b_])
         n_params = model._n_flat
         # ALGORITHMIC bytes per launch (fp32 params, ids as given, eps in-kernel):
         idb = 4 if args.id32 else 8
@@ -399,15 +411,22 @@ def kernel_report(events, model, args, world, B, d, F, U):
         bytes_fwd = U * (8 * d_k + 16) + B_k * (idb * F + 8)        # touched rows once + ids, y, pred
         bytes_bwd = bytes_fwd + U * (8 * d_k + 8)                   # re-read + one write per touched row
         lazy = "catchup" in acc          # lazy exact dense Adam: only the batch's rows are read / written per step
+        piped = model._zrec is not None and world == 1 and "sample_rec" not in acc     # software-pipelined step (steady state)
+        if piped:
+            # forward = gather of sample records: each touched record once (4d + 16 B) + ids, y, pred, grow
+            bytes_fwd = U * (4 * d_k + 16) + B_k * (idb * F + 12)
         alg = {"fwd": bytes_fwd, "bwd": bytes_bwd, "adam": 28.0 * n_params, "finalize": 0.0,
                # replay of the skipped updates on the batch's rows: read p, m, v, write p
                "catchup": 16.0 * U * (2 * d_k + 2) + 8.0 * U,
                "allreduce": 4.0 * n_params,
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
                # (scaled moments: the rows a batch does not touch read p, m, v and write p only: 16 B/param)
+               "sample_rec": U * (8 * d_k + 16) + U * (4 * d_k + 16),
                "bwd_adam": (B_k * (idb * F + 8) + U * 16 + 24.0 * U * (2 * d_k + 2)) if lazy else (
                            B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
-                           (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0)),
+                           (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0)
+                           # pipelined: + the next batch's records written, the other entities' records read once
+                           + (2.0 * U * (4 * d_k + 16) if piped else 0.0)),
                # dimension-sharded mode: the step's only exchange, and the per-row likelihood kernel after it
                "allreduce_row_values": 4.0 * (B_k + 4096), "lik": 16.0 * B_k,
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
@@ -420,10 +439,14 @@ def kernel_report(events, model, args, world, B, d, F, U):
         alg["allreduce"] = 4.0 * n_params
         fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and not dims_mode and \
             os.environ.get("VFM_FWD_KERNEL", "2") != "1"
-        names = {"fwd": "k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "
-                        "once per run)" if fwd2 else "k_fwd (gather->reparam->FM->ELBO)", "bwd": "k_bwd (entity-centric gradients)",
-                 "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)" + (", rows of the batch only (lazy exact Adam)" if lazy else ""),
+        names = {"fwd": ("k_fwd2<ZREC> (pipelined step: gather of this step's sample records -> FM -> ELBO; the records were "
+                         "written by the previous step's fused backward)") if piped else
+                        ("k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "
+                         "once per run)" if fwd2 else "k_fwd (gather->reparam->FM->ELBO)"), "bwd": "k_bwd (entity-centric gradients)",
+                 "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)" + (", rows of the batch only (lazy exact Adam)" if lazy else "")
+                             + (" + sampling of the next batch's entities (pipelined step)" if piped else ""),
                  "adam": "k_adam (dense Adam)",
+                 "sample_rec": "k_sample_rec (sample records of a batch from the tables: first step of a pipelined run)",
                  "catchup": "k_adam_catchup (lazy exact dense Adam: replay of the skipped zero-gradient updates on the batch's rows)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",

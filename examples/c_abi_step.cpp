@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
 
   VFM_OK(vfm_inv_occ_f32(d_occ, d_inv, T, st));                       // once per training set
   VFM_OK(vfm_batch_norms(&p, d_x, d_inv, d_W, st));                   // once per batch
-  VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, d_counts, st));
+  VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, nullptr, d_counts, st));
   int32_t counts[4];
   HIP_OK(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));

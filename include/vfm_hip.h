@@ -85,6 +85,12 @@ extern "C" {
                                      once -- vfm_shard_sample_f32 -- and ships z instead of mu and s); no
                                      KL term is formed (the owner adds it), bias_params / inv_occ / W may be
                                      NULL, eps_global alone may be given                                    */
+#define VFM_FLAG_ZREC 1024        /* vfm_elbo_fwd_f32 (two fields, one sample, d % 4 == 0, d <= 512, training): `entity_params`
+                                     holds this step's SAMPLES, one record (w, weighted KL, 0, 0 | z[0..d-1]) of 4 + d
+                                     floats per ENTITY ID (vfm_sample_records_f32 / vfm_elbo_bwd_adam_pipe_f32 write them);
+                                     x holds entity ids as usual.  Nothing is sampled and no sumz is written (the
+                                     pipelined backward gathers the samples themselves): bias_params, inv_occ, W, sumz
+                                     may be NULL.  Half the gather bytes of the (mu | s) rows, no RNG.             */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 #define VFM_FLAG_LINK_SOFTPLUS 16 /* LINK = softplus instead of |.| (vfm-torch.py:125-126; applies to alpha,
@@ -171,6 +177,8 @@ typedef struct vfm_index {
    * vfm_elbo_bwd_adam_f32 walks this list instead of scanning all T table rows (lazy Adam step). */
   const int32_t* touched_ids;
   int64_t n_touched;
+  /* optional, two fields: occ_other[i] = the entity in the other column of row occ_rows[i] (vfm_elbo_bwd_adam_pipe_f32) */
+  const int32_t* occ_other;
 } vfm_index_t;
 
 int vfm_abi_version(void);
@@ -188,6 +196,8 @@ const char* vfm_last_error(void);
  *             capacities that always suffice: cap_heavy = B*F / heavy_list + 1, cap_items = 2*B*F / heavy_list + 2
  *   touched_ids  NULL, or room for min(B*F, T) int32: receives the sorted ids of the entities the batch
  *             contains (the row list of the lazy Adam step, vfm_index_t.touched_ids)
+ *   occ_other NULL, or (F == 2 only) [B*2] int32: for every entry of occ_rows the entity in the OTHER column of
+ *             that row (vfm_index_t.occ_other: the software-pipelined step gathers that entity's sample)
  *   counts    [4] int32, DEVICE: (ids outside [0,T) met -- they are indexed as id 0, like the forward
  *             clamps them --, n_heavy, n_items, n_touched = entities in the batch): the caller reads them
  *             back once to fill vfm_index_t */
@@ -200,7 +210,8 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
 int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T);
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* counts, void* stream);
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other, int32_t* counts,
+                    void* stream);
 
 /* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
  * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */
@@ -334,6 +345,38 @@ int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
  * pointers 16-byte aligned. */
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, void* stream);
+
+/* Software-pipelined step (two fields, one sample, single rank, Philox eps).  The forward of a step needs, per
+ * entity of its batch, one sample z = mu + sigma*eps, the sampled first-order weight and the entity's KL -- all
+ * functions of the entity's OWN row.  The fused backward of the PREVIOUS step has every updated row in registers
+ * anyway (dense Adam), so it writes these records for the rows of the next batch there (51 MB at ML-20M shape
+ * instead of the forward re-reading 130 MB of table rows and drawing 16 M normals), and the forward shrinks to a
+ * gather of records (VFM_FLAG_ZREC).  The backward in turn gathers the OTHER entity's sample from the records
+ * instead of the per-row `sumz` the plain forward writes (no sumz at all).  Same draws (Philox counters of the
+ * step the record is for), same arithmetic: the trajectory equals the plain step's up to summation order.
+ *   zrec, zrec_next  [T, 4 + d] fp32 record tables, indexed by entity id (double buffer, caller-owned)
+ *   vfm_sample_records_f32   writes the records of the listed entities from the tables (first step of a run):
+ *                            p->step = the step the records are for; W = that batch's normalisers
+ *   vfm_elbo_bwd_adam_pipe_f32  = vfm_elbo_bwd_adam_f32 (plain dense step; no row flags) with sumz replaced by
+ *                            pipe->zrec + idx->occ_other, and -- when pipe->zrec_next != NULL -- the records of
+ *                            step pipe->next_step for every entity e with next_occ_ptr[e+1] != next_occ_ptr[e]
+ *                            (the next batch's inverted-index offsets), weighted with next_W. */
+typedef struct vfm_pipe {
+  const float* zrec;
+  float* zrec_next;
+  const int32_t* next_occ_ptr;
+  const double* next_W;
+  uint64_t next_step;
+} vfm_pipe_t;
+int vfm_sample_records_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
+                           const float* bias_params, const float* inv_occ, const double* W, float* zrec, void* stream);
+int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, const vfm_pipe_t* pipe,
+                               float* entity_params, float* bias_params, float* scalars,
+                               const float* inv_occ, const double* W, const float* grow, double* partials,
+                               float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                               float* m_scalars, float* v_scalars,
+                               float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                               void* stream);
 
 /* Lazy EXACT dense Adam for sparse-touch regimes (Criteo shape: a batch touches 6 % of the table).  With
  * VFM_FLAG_SCALED_MOMENTS a row without gradient keeps its stored moments and its parameters move by a function

@@ -45,7 +45,7 @@ def test_lazy_adam_is_bitwise_the_dense_trajectory(F, d):
 def test_lazy_adam_checkpoint_mode_switch_and_auto():
     dense, plans_d, X = _setup(False)
     lazy, plans_l, _ = _setup("auto")
-    lazy.lazy_threshold = 0.5
+    lazy.lazy_threshold, lazy.lazy_min_params = 0.5, 0
     for s in range(40):
         dense.train_step(plans_d[s % 12], lr=0.03)
         lazy.train_step(plans_l[s % 12], lr=0.03)

@@ -1,0 +1,106 @@
+"""GPU: the software-pipelined step (vfm_sample_records_f32, VFM_FLAG_ZREC forward, vfm_elbo_bwd_adam_pipe_f32)
+against the plain fused step: same draws, same arithmetic -- the records equal what the tables give, and the
+training trajectory equals the plain one up to summation order."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(d=32, sizes=(300, 120), zipf=None, nb=6, B=400, output="reg", link="abs"):
+    from vae_amd.model import VFM, sort_rows_within_batches
+    from vae_amd.data import synthetic_triples
+    torch.manual_seed(5)
+    m = VFM(sizes[0], sizes[1], d, output=output, device="cuda", rng_seed=21, link=link)
+    m.lazy_adam = False
+    m.pipeline = True                          # ("auto" would decide by rows per entity)
+    X, y = synthetic_triples(list(sizes), nb * B, seed=6, device="cuda", output=output, zipf=zipf)
+    m.set_training_data(X, nb_train=nb * B)
+    X, y = sort_rows_within_batches(X, y, B)
+    plans = [m.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
+    return m, plans
+
+
+def test_records_and_record_forward_match_the_tables():
+    """vfm_sample_records_f32 + the VFM_FLAG_ZREC forward reproduce the plain forward's predictions, loss terms and
+    dloss/dpred for the same (seed, step)."""
+    from vae_amd import ops
+    m, plans = _model()
+    ent, bia, scal = m._views(m._flat)
+    plan = plans[0]
+    plain = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, seed=3, step=9)
+    l_plain = ops.elbo_finalize(plain, scal).clone()
+    zrec = torch.zeros(m.T, ops.record_len(m.d), device="cuda")
+    ops.sample_records(plan, ent, bia, m.inv_occ, zrec, 3, 9)
+    pred, grow = torch.empty(plan.B, device="cuda"), torch.empty(plan.B, device="cuda")
+    part = torch.zeros(8 * 4097, dtype=torch.float64, device="cuda")
+    st = ops.elbo_forward_records(plan, zrec, scal, 3, 9, pred, grow, part)
+    l_rec = ops.elbo_finalize(st, scal)
+    assert rel_err(pred.cpu().numpy(), plain.pred.cpu().numpy()) < 1e-6
+    assert rel_err(grow.cpu().numpy(), plain.grow.cpu().numpy()) < 1e-5
+    assert rel_err(l_rec.cpu().numpy(), l_plain.cpu().numpy()) < 1e-6
+    # the sample itself: z of an entity = what the Philox dump gives
+    ee, eb, eg = ops.philox_eps(m.spec(), seed=3, step=9, device="cuda")
+    ids = plan.touched_ids().long()
+    z_want = ent[ids, :m.d] + ent[ids, m.d:].abs() * ee[ids]
+    assert rel_err(zrec[ids, 4:].cpu().numpy(), z_want.cpu().numpy()) < 1e-6
+    w_want = bia[ids, 0] + bia[ids, 1].abs() * eb[ids]
+    assert rel_err(zrec[ids, 0].cpu().numpy(), w_want.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(d=128, sizes=(2000, 300), B=1500), dict(zipf=1.3, B=3000, sizes=(400, 60)),
+                                 dict(output="class", link="softplus", d=20)])
+def test_pipelined_trajectory_equals_plain(cfg):
+    """40 steps: pipelined (next batch named, records written by the backward) vs plain fused steps.  Every step's
+    loss, the final parameters and moments agree to fp32 summation-order accuracy; heavy lists (zipf) included."""
+    a, plans_a = _model(**cfg)
+    b, plans_b = _model(**cfg)
+    b.pipeline = False
+    n = len(plans_a)
+    for s in range(40):
+        la, pa = a.train_step(plans_a[s % n], lr=0.02, next_plan=plans_a[(s + 1) % n])
+        lb, pb = b.train_step(plans_b[s % n], lr=0.02)
+        assert rel_err(la.cpu().numpy(), lb.cpu().numpy()) < (2e-5 if s < 5 else 2e-4), s      # (later: trajectory amplification)
+        if s in (0, 1, 39):
+            assert rel_err(pa.cpu().numpy(), pb.cpu().numpy()) < (1e-4 if s < 5 else 2e-3), s
+    assert a._zrec is not None and b._zrec is None
+    assert rel_err(a._flat.cpu().numpy(), b._flat.cpu().numpy()) < 2e-4
+    a._set_moment_form(False); b._set_moment_form(False)
+    assert rel_err(a._adam_m.cpu().numpy(), b._adam_m.cpu().numpy()) < 2e-3
+
+
+def test_pipeline_falls_back_when_records_are_stale():
+    """Records are tied to (plan, Philox step, version of the parameter buffer): a different next batch, a prediction
+    in between (it advances the Philox step) or an in-place change of the parameters makes the step resample
+    from the tables instead of using stale records."""
+    a, plans_a = _model()
+    b, plans_b = _model()
+    b.pipeline = False
+    a.train_step(plans_a[0], lr=0.02, next_plan=plans_a[1]); b.train_step(plans_b[0], lr=0.02)
+    a.train_step(plans_a[2], lr=0.02, next_plan=plans_a[3]); b.train_step(plans_b[2], lr=0.02)      # not the announced batch
+    a.predict(plans_a[0].x[:10]); b.predict(plans_b[0].x[:10])                                      # Philox step moves on
+    with torch.no_grad():
+        a.entity_params.weight.mul_(1.01); b.entity_params.weight.mul_(1.01)                        # tables change
+    la, _ = a.train_step(plans_a[3], lr=0.02, next_plan=plans_a[4]); lb, _ = b.train_step(plans_b[3], lr=0.02)
+    la2, _ = a.train_step(plans_a[4], lr=0.02); lb2, _ = b.train_step(plans_b[4], lr=0.02)          # uses the records
+    assert rel_err(la.cpu().numpy(), lb.cpu().numpy()) < 2e-5 and rel_err(la2.cpu().numpy(), lb2.cpu().numpy()) < 2e-5
+    assert rel_err(a._flat.cpu().numpy(), b._flat.cpu().numpy()) < 1e-4
+
+
+def test_fit_with_pipeline_matches_fit_without():
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    X, y = synthetic_triples([150, 100], 5000, seed=2)
+    hs = []
+    for pipe in (True, False):
+        torch.manual_seed(1)
+        m = VFM(150, 100, 16, device="cuda", rng_seed=8)
+        m.pipeline = "auto" if pipe else False          # (1,500 rows over <= 250 entities: auto pipelines)
+        hs.append((m.fit(X[:4000], y[:4000], n_epochs=3, batch_size=1500, X_test=X[4000:], y_test=y[4000:], verbose=False), m))
+    (h1, m1), (h2, m2) = hs
+    assert rel_err(np.array(h1["elbo"]), np.array(h2["elbo"])) < 1e-4
+    assert rel_err(m1._flat.cpu().numpy(), m2._flat.cpu().numpy()) < 1e-3
+    assert rel_err(np.array(h1["train_rmse"]), np.array(h2["train_rmse"])) < 1e-4

@@ -33,6 +33,7 @@ EXPORTS = (
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
     "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_adam_catchup_f32",
+    "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32",
 )
 
 
@@ -63,7 +64,14 @@ class Index(C.Structure):
     """Mirror of `vfm_index_t`."""
     _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
                 ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
-                ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64)]
+                ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64),
+                ("occ_other", C.c_void_p)]
+
+
+class Pipe(C.Structure):
+    """Mirror of `vfm_pipe_t`."""
+    _fields_ = [("zrec", C.c_void_p), ("zrec_next", C.c_void_p), ("next_occ_ptr", C.c_void_p), ("next_W", C.c_void_p),
+                ("next_step", C.c_uint64)]
 
 
 def heavy_list_for(n_occ: int, T: int) -> int:
@@ -115,9 +123,12 @@ def load():
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_heavy_list_for.argtypes = [i64, i64]
-    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp]
+    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp]
     lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
                                          i64, i64, vp]
+    lib.vfm_sample_records_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.vfm_elbo_bwd_adam_pipe_f32.argtypes = ([PP, C.POINTER(Index), C.POINTER(Pipe)] + [vp] * 13 +
+                                               [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
     lib.vfm_variant_fwd_f32.argtypes = [PP, i32] + [vp] * 18
     lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
     for name in EXPORTS:

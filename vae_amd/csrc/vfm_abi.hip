@@ -172,14 +172,14 @@ int dispatch_bwd(const vfm_problem_t* p, const Shape& s, int eps, int adam, KArg
 
 template <int LPE, int CPL, int VEC>
 int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, float* hacc, int d,
-                   hipStream_t st) {
+                   hipStream_t st, const float* zrec = nullptr) {
   constexpr int GPB = BLOCK / LPE;
   const size_t xs = 4 + (((size_t)d + 3) & ~(size_t)3);
   float* item_acc = hacc + xs * (size_t)idx->n_heavy;            // item records sit behind the entity records
   int64_t nb = ((int64_t)idx->n_items + GPB - 1) / GPB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
-                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d);
+                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec);
   nb = idx->n_heavy;                                             // one workgroup per heavy entity
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy_sum<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
@@ -189,7 +189,7 @@ int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow,
 
 // pre-reduce the long occurrence lists (if the index has any) and point the main kernel at the result
 int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz, const float* grow,
-              hipStream_t st, BwdArgs* b) {
+              hipStream_t st, BwdArgs* b, const float* zrec = nullptr) {
   b->heavy_ids = nullptr; b->heavy_acc = nullptr; b->n_heavy = 0; b->heavy_stride = 0;
   if (idx->n_heavy <= 0 || idx->n_items <= 0) return 0;
   if (!idx->heavy_ids || !idx->heavy_items || !idx->heavy_acc)
@@ -199,10 +199,10 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
   Shape s;
   pick_shape(p->d, &s);
   for (int sm = 0; sm < p->n_samples; ++sm) {
-    const float* sz = sumz + (size_t)sm * (size_t)p->B * (size_t)p->d;
+    const float* sz = sumz ? sumz + (size_t)sm * (size_t)p->B * (size_t)p->d : nullptr;
     float* hacc = idx->heavy_acc + (size_t)sm * per_sample;
 #define X(L_, C_, V_) \
-    if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(idx, sz, grow, hacc, p->d, st);
+    if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(idx, sz, grow, hacc, p->d, st, zrec);
     VFM_FOR_SHAPES(X)
 #undef X
   }
@@ -294,6 +294,18 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
     return after_launch("vfm_elbo_fwd_f32");
   }
   const bool zpre = (p->flags & VFM_FLAG_ZPRE) != 0;
+  const bool zrec = (p->flags & VFM_FLAG_ZREC) != 0;
+  if (zrec) {       // the forward of the software-pipelined step: a gather of this step's sample records
+    if (!use_fwd2(p, EPS_ZREC)) return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_ZREC: two fields, one sample, d % 4 == 0, d <= 512, no other mode flag");
+    if (!x || !y || !entity_params || !scalars || !pred || !grow || eps_entity || eps_bias || eps_global)
+      return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32 (VFM_FLAG_ZREC): x, y, the record table, scalars, pred, grow; no eps tables");
+    KArgs a = make_args(p, x, y, entity_params, nullptr, nullptr, scalars, nullptr, nullptr, nullptr, nullptr, 0);
+    FwdOut o{pred, partials, nullptr, grow};
+    if (int rc = softplus(p) ? launch_fwd2_softplus(EPS_ZREC, MODE_TRAIN, a, o, (hipStream_t)stream)
+                             : launch_fwd2_abs(EPS_ZREC, MODE_TRAIN, a, o, (hipStream_t)stream))
+      return rc;
+    return after_launch("vfm_elbo_fwd_f32");
+  }
   if (!x || !entity_params || (!bias_params && !zpre) || !scalars || !pred)
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: NULL pointer");
   const bool train = y != nullptr;
@@ -347,7 +359,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias,
-            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
@@ -387,7 +399,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                       eps_bias, eps_global);
   a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
   if (!untouched_only)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -416,7 +428,7 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
-            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
   // (the pre-reduction covers whole lists, so with several entity chunks it runs with the first one)
   if (p->e_lo == 0)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
@@ -452,7 +464,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   if (rec_pos != nullptr && rec_ptr == nullptr)      // (rec_pos may be NULL when rec_ptr lists no record at all)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_pos without rec_ptr");
   BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0};
+            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -529,6 +541,60 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
   hipLaunchKernelGGL(k_adam, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
                      beta2, eps, step_size, bc2_sqrt);
   return after_launch("vfm_adam_f32");
+}
+
+int vfm_sample_records_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
+                           const float* bias_params, const float* inv_occ, const double* W, float* zrec, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_sample_records_f32")) return rc;
+  if ((p->d & 3) != 0) return fail(VFM_E_UNSUPPORTED, "vfm_sample_records_f32: d % 4 == 0");
+  if (n < 0 || n > 0x7FFFFFFFLL || (n > 0 && (!ids || !entity_params || !bias_params || !inv_occ || !W || !zrec)))
+    return fail(VFM_E_INVALID, "vfm_sample_records_f32: bad argument");
+  if (n == 0) return 0;
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, nullptr, W, nullptr, nullptr, nullptr);
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = softplus(p) ? launch_sample_rec_softplus(s, a, ids, (int)n, zrec, (hipStream_t)stream)
+                           : launch_sample_rec_abs(s, a, ids, (int)n, zrec, (hipStream_t)stream))
+    return rc;
+  return after_launch("vfm_sample_records_f32");
+}
+
+int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, const vfm_pipe_t* pipe,
+                               float* entity_params, float* bias_params, float* scalars,
+                               const float* inv_occ, const double* W, const float* grow, double* partials,
+                               float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                               float* m_scalars, float* v_scalars,
+                               float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                               void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
+  if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
+  if (p->F != 2 || (p->d & 3) != 0 || p->d > 512)
+    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: two fields, d % 4 == 0, d <= 512");
+  if (p->flags & ~(VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_LINK_SOFTPLUS))
+    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: only VFM_FLAG_SCALED_MOMENTS / VFM_FLAG_LINK_SOFTPLUS");
+  if (!pipe || !pipe->zrec || (p->B > 0 && !idx->occ_other) ||
+      (pipe->zrec_next && (!pipe->next_occ_ptr || !pipe->next_W)))
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: pipe / idx->occ_other incomplete");
+  if (!entity_params || !bias_params || !scalars || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
+      !v_scalars || step < 1 || !inv_occ || !W || !partials || (p->B > 0 && !grow))
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: bad argument");
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
+  BwdArgs b{idx->occ_ptr, idx->occ_rows, nullptr, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+  if (int rc = run_heavy(p, idx, nullptr, grow, (hipStream_t)stream, &b, pipe->zrec)) return rc;
+  b.zrec = pipe->zrec; b.occ_other = idx->occ_other;
+  b.zrec_next = pipe->zrec_next; b.next_occ_ptr = pipe->next_occ_ptr; b.next_W = pipe->next_W;
+  b.next_key = a.key;
+  b.next_key.step_lo = (uint32_t)pipe->next_step; b.next_key.step_hi = (uint32_t)(pipe->next_step >> 32);
+  AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
+  adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = dispatch_bwd(p, s, EPS_PHILOX, 1, a, b, ad, (hipStream_t)stream)) return rc;
+  return after_launch("vfm_elbo_bwd_adam_pipe_f32");
 }
 
 int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,

@@ -84,6 +84,15 @@ struct BwdArgs {
   // step (VFM_FLAG_ROWS_TOUCHED + vfm_index_t.touched_ids) walks this list.
   const int32_t* row_ids;
   int64_t n_rows;
+  // software-pipelined step (PIPE instances, two fields): the walk gathers the OTHER entity's sample from this
+  // step's records instead of a sumz row, and rows of the NEXT batch get their next-step record written after
+  // their Adam update (vfm_elbo_bwd_adam_pipe_f32)
+  const float* zrec;
+  const int32_t* occ_other;
+  float* zrec_next;               // NULL: nothing to prepare
+  const int32_t* next_occ_ptr;    // inverted-index offsets of the next batch: membership test
+  const double* next_W;           // its normalisers
+  RngKey next_key;                // its Philox key (step + 1)
 };
 
 struct AdamArgs {
@@ -100,7 +109,7 @@ struct Shape {
   int lpe, cpl, vec;
 };
 
-enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3 };
+enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3, EPS_ZREC = 4 };
 enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
 enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
 enum { LINK_ABS = 0, LINK_SOFTPLUS = 1 };
@@ -119,7 +128,9 @@ VFM_INTERNAL int env_int(const char* name, int dflt);
   VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
                                        const AdamArgs& ad, hipStream_t st);                                    \
   VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \
-                                          float* out, hipStream_t st);
+                                          float* out, hipStream_t st);                                         \
+  VFM_INTERNAL int launch_sample_rec_##SUFFIX(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, \
+                                              hipStream_t st);
 VFM_DECLARE_LAUNCHERS(abs)
 VFM_DECLARE_LAUNCHERS(softplus)
 

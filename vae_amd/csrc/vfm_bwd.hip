@@ -30,6 +30,14 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
+  if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX && VEC == 4) {
+    if (b.zrec != nullptr) {      // software-pipelined step: gathers samples, writes the next step's records
+      if (a.S > 1) return fail(VFM_E_UNSUPPORTED, "pipelined step: one variational sample");
+      hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+      return 0;
+    }
+  }
+  if (b.zrec != nullptr) return fail(VFM_E_UNSUPPORTED, "pipelined step: fused Adam, Philox eps, d % 4 == 0 only");
   if constexpr (STAGE == STAGE_FULL) {
     if (a.S > 1) {       // variational samples: the instance with the per-sample walk
       hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
@@ -81,7 +89,31 @@ int dispatch_sample(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n
   return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
 }
 
+int dispatch_sample_rec(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
+#define X(L_, C_, V_)                                                                                   \
+  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                      \
+    constexpr int GPB = BLOCK / L_;                                                                     \
+    int64_t nb = ((int64_t)n + GPB - 1) / GPB;                                                          \
+    if (nb > 65535) nb = 65535;                                                                         \
+    hipLaunchKernelGGL((k_sample_rec<L_, C_, V_, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, n, zrec); \
+    return 0;                                                                                           \
+  }
+  VFM_FOR_SHAPES(X)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
+}
+
 }  // namespace
+
+#if VFM_LINK == 0
+int launch_sample_rec_abs(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
+  return dispatch_sample_rec(s, a, ids, n, zrec, st);
+}
+#else
+int launch_sample_rec_softplus(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
+  return dispatch_sample_rec(s, a, ids, n, zrec, st);
+}
+#endif
 
 #if VFM_LINK == 0
 int launch_bwd_abs(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {

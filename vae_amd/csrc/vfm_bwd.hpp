@@ -52,10 +52,12 @@ __device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
   return (n > 0 && ids[lo] == e) ? lo : -1;
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI>
-__global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI, bool PIPE = false>
+__global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
+  static_assert(!PIPE || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "the pipelined step is the fused single-sample one");
   __shared__ float sh_cs[VFM_MAX_FIELDS];
+  __shared__ float sh_cs_next[PIPE ? VFM_MAX_FIELDS : 1];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
   __shared__ double sh_fin[6][BLOCK / 64];
   const int tid = threadIdx.x;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
   if (STAGE != STAGE_ACC && tid < a.G) {
     sh_cs[tid] = a.W ? (float)(a.group_n[tid] / a.W[tid]) : 0.f;     // (W == NULL: untouched-rows launch)
     sh_hi[tid] = a.group_hi[tid];
+    if constexpr (PIPE) sh_cs_next[tid] = b.zrec_next ? (float)(a.group_n[tid] / b.next_W[tid]) : 0.f;
   }
   __syncthreads();
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         pq = make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]);
       }
     }
+    bool in_next = false;          // PIPE: e is in the next batch -> its next-step record is written below
+    if constexpr (PIPE) {
+      if (b.zrec_next) in_next = b.next_occ_ptr[e + 1] != b.next_occ_ptr[e];
+    }
     float* prow = const_cast<float*>(a.entity) + (size_t)e * (2 * (size_t)d);
     float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
     const bool touched = (STAGE == STAGE_APPLY) ? gc.y > 0.f : beg != end;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
           vb = *reinterpret_cast<const float2*>(ad.v_bias + 2 * (size_t)e);
         }
       }
-      if (touched) {
+      if (touched || (PIPE && in_next)) {
         io = a.inv_occ[e];
         if constexpr (EPS == EPS_TABLE) epw = a.eps_bias[e];
       }
@@ -223,16 +230,23 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         }
         o = end;
       }
+      // PIPE: the sample of the OTHER entity of the row (this step's records) stands in for the sumz row
+      auto src = [&](int oo, int r) -> const float* {
+        if constexpr (PIPE) return b.zrec + (size_t)b.occ_other[oo] * xs + 4;
+        return sz + (size_t)r * d;
+      };
       for (; o + 1 < end; o += 2) {       // two occurrences in flight
         const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
         const float g0 = b.grow[r0], g1 = b.grow[r1];
+        const float* p0 = src(o, r0);
+        const float* p1 = src(o + 1, r1);
         gs += g0 + g1;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int j = lig + i * LPE;
           if (j < C) {
-            const Chunk<VEC> s0v = ld_chunk<VEC>(sz + (size_t)r0 * d + (size_t)j * VEC);
-            const Chunk<VEC> s1v = ld_chunk<VEC>(sz + (size_t)r1 * d + (size_t)j * VEC);
+            const Chunk<VEC> s0v = ld_chunk<VEC>(p0 + (size_t)j * VEC);
+            const Chunk<VEC> s1v = ld_chunk<VEC>(p1 + (size_t)j * VEC);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g1, s1v.v[t], fmaf(g0, s0v.v[t], A[i].v[t]));
           }
@@ -241,12 +255,13 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       if (o < end) {
         const int r0 = b.occ_rows[o];
         const float g0 = b.grow[r0];
+        const float* p0 = src(o, r0);
         gs += g0;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int j = lig + i * LPE;
           if (j < C) {
-            const Chunk<VEC> s0v = ld_chunk<VEC>(sz + (size_t)r0 * d + (size_t)j * VEC);
+            const Chunk<VEC> s0v = ld_chunk<VEC>(p0 + (size_t)j * VEC);
 #pragma unroll
             for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g0, s0v.v[t], A[i].v[t]);
           }
@@ -313,6 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
       c = sh_cs[group_index(sh_hi, a.G, e)] * io * cntf;
     }
     float nb_eps = 0.f;
+    float nb_next = 0.f, kl_next = 0.f, w_next = 0.f;      // PIPE: the next step's first-order eps / KL / sampled weight
     // S > 1 (uniform): g1s = 1/S sum_s (A^s - z^s gs), g2s = 1/S sum_s eps^s (A^s - z^s gs), nb_eps = mean_s eps_w^s
     // (MULTI is a template parameter so that the S = 1 instances carry none of this: registers, occupancy)
     constexpr bool multi = MULTI && STAGE == STAGE_FULL;
@@ -386,7 +402,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
           for (int t = 0; t < VEC; ++t) {
             const float sg = link_f<LINK>(s[i].v[t]);
             const float z = fmaf(sg, epc.v[t], mu[i].v[t]);
-            const float gz = A[i].v[t] - z * gs;  // sum_r g_r (sumz_rk - z_ek)
+            // sum_r g_r (sumz_rk - z_ek); PIPE: A already sums the other entity's z alone
+            const float gz = PIPE ? A[i].v[t] : A[i].v[t] - z * gs;
             gm.v[t] = gout * (gz + c * mu[i].v[t]);
             gv.v[t] = gout * dlink_f<LINK>(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
             if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(mu[i].v[t], sg), klacc);
@@ -409,6 +426,22 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
             st_chunk_nt<VEC>(ad.m_entity + o2, mm[i]); st_chunk_nt<VEC>(ad.m_entity + o2 + d, ms[i]);
             st_chunk_nt<VEC>(ad.v_entity + o2, vm[i]); st_chunk_nt<VEC>(ad.v_entity + o2 + d, vs[i]);
           }
+          if constexpr (PIPE) {
+            if (in_next) {     // the updated row is in registers: sample it for the next step right here
+              Chunk<VEC> ep2, zn;
+              float nb2;
+              eps_of_chunk<VEC>(b.next_key, (uint32_t)e, j, ep2.v, nb2);
+              if (i == 0) nb_next = nb2;
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) {
+                const float sg2 = link_f<LINK>(ps.v[t]);
+                zn.v[t] = fmaf(sg2, ep2.v[t], pm.v[t]);
+                kl_next += kl_std_normal(pm.v[t], sg2);
+              }
+              st_chunk<VEC>(b.zrec_next + (size_t)e * xs + 4 + (size_t)j * VEC, zn);
+            }
+          }
+
         } else {
           st_chunk_nt<VEC>(grow_e + (size_t)j * VEC, gm);
           st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, gv);
@@ -430,12 +463,27 @@ __global__ __launch_bounds__(BLOCK) void k_bwd(const KArgs a, const BwdArgs b, c
         pn.x = adam_update(th.x, g0, mb.x, vb.x, ad);
         pn.y = adam_update(th.y, g1, mb.y, vb.y, ad);
         *reinterpret_cast<float2*>(const_cast<float*>(a.bias) + 2 * (size_t)e) = pn;
+        if constexpr (PIPE) {
+          if (in_next) {
+            const float sgw2 = link_f<LINK>(pn.y);
+            w_next = fmaf(sgw2, nb_next, pn.x);
+            kl_next += kl_std_normal(pn.x, sgw2);
+          }
+        }
         if (!ad.scaled || touched || ad.store_true) {
           *reinterpret_cast<float2*>(ad.m_bias + 2 * (size_t)e) = mb;
           *reinterpret_cast<float2*>(ad.v_bias + 2 * (size_t)e) = vb;
         }
       } else {
         *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(g0, g1);
+      }
+    }
+    if constexpr (PIPE) {
+      if (in_next) {           // (uniform over the lane group) header of the next-step record: (w, weighted KL, 0, 0)
+        kl_next = group_sum<LPE>(kl_next);
+        if (lig == 0)
+          *reinterpret_cast<float4*>(b.zrec_next + (size_t)e * xs) =
+              make_float4(w_next, kl_next * (sh_cs_next[group_index(sh_hi, a.G, e)] * io), 0.f, 0.f);
       }
     }
   }

@@ -40,7 +40,7 @@ template <int LPE, bool FULL>
 int launch_fwd2_s(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st) {
 #define FWD2(E_, M_) \
   if (eps == E_ && mode == M_) return launch_fwd2_t<LPE, FULL, E_, M_>(a, o, st);
-  FWD2(EPS_PHILOX, MODE_TRAIN) FWD2(EPS_TABLE, MODE_TRAIN) FWD2(EPS_ZERO, MODE_TRAIN)
+  FWD2(EPS_PHILOX, MODE_TRAIN) FWD2(EPS_TABLE, MODE_TRAIN) FWD2(EPS_ZERO, MODE_TRAIN) FWD2(EPS_ZREC, MODE_TRAIN)
   FWD2(EPS_PHILOX, MODE_PREDICT) FWD2(EPS_TABLE, MODE_PREDICT) FWD2(EPS_ZERO, MODE_PREDICT)
 #undef FWD2
   return fail(VFM_E_UNSUPPORTED, "forward (task stream): unsupported eps source / mode combination");

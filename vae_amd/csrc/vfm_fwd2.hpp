@@ -80,6 +80,17 @@ template <int EPS, int MODE>
 __device__ __forceinline__ void load_ent(const KArgs& a, uint32_t e, int off0, int off1, EntRegs<EPS>& R) {
   const size_t d = (size_t)a.d;
   R.e = e;
+  if constexpr (EPS == EPS_ZREC) {
+    // the "table" holds this step's SAMPLES, one record (w, weighted KL, 0, 0 | z[0..d-1]) per entity id, written
+    // by the previous step's backward (or vfm_sample_records_f32): nothing to sample, half the bytes of (mu | s)
+    const float* rec = a.entity + (size_t)e * (4 + d);
+    R.mu[0] = ld_chunk<4>(rec + 4 + off0);
+    R.mu[1] = ld_chunk<4>(rec + 4 + off1);
+    const float4 h = *reinterpret_cast<const float4*>(rec);
+    R.th = make_float2(h.x, 0.f);
+    R.io = h.y;
+    return;
+  }
   const float* row = a.entity + (size_t)e * (2 * d);
   R.mu[0] = ld_chunk<4>(row + off0);
   R.mu[1] = ld_chunk<4>(row + off1);
@@ -100,6 +111,16 @@ __device__ __forceinline__ void load_ent(const KArgs& a, uint32_t e, int off0, i
 template <bool FULL, int EPS, int MODE, int LINK>
 __device__ __forceinline__ void sample_ent(const RngKey& key, const EntRegs<EPS>& R, uint32_t pg, bool v0, bool v1,
                                            bool owns_bias, float cs, float (&z)[8], float& w, float& klw) {
+  if constexpr (EPS == EPS_ZREC) {          // precomputed sample: z, w and the entity's weighted KL come from the record
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      z[t] = (FULL || v0) ? R.mu[0].v[t] : 0.f;
+      z[4 + t] = (FULL || v1) ? R.mu[1].v[t] : 0.f;
+    }
+    w = owns_bias ? R.th.x : 0.f;
+    klw = (MODE == MODE_TRAIN && owns_bias) ? R.io : 0.f;
+    return;
+  }
   float ep[8], epw = 0.f;
   if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
@@ -155,13 +176,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const int lig = tid % LPE;
   const int C = a.d >> 2;                       // chunks of 4 coordinates (d % 4 == 0 here)
 
-  if (MODE == MODE_TRAIN && tid < 2) {
+  if (MODE == MODE_TRAIN && EPS != EPS_ZREC && tid < 2) {
     sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   // the global-bias eps: ONE wave draws it (a Philox call in every wave's prologue is a tenth of a
   // workgroup's arithmetic at B = 100K)
-  if constexpr (EPS == EPS_PHILOX) {
+  if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZREC) {
     if (tid < 64) {
       float n[8], nb;
       normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const bool owns_bias = (lig == 0) && has_bias;
   float cs0 = 0.f, cs1 = 0.f;
   uint32_t hi0 = 0u;                 // ids below hi0 belong to group 0 (ids are below 2^32)
-  if constexpr (MODE == MODE_TRAIN) {
+  if constexpr (MODE == MODE_TRAIN && EPS != EPS_ZREC) {
     cs0 = sh_cs[0]; cs1 = sh_cs[1];
     hi0 = sh_hi[0] > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (uint32_t)sh_hi[0];
   }
@@ -260,8 +281,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
           qv = zu * zv + qv;
         }
         const float val = group_sum<LPE>(qv.x + qv.y + w + wi);
-        if constexpr (MODE == MODE_TRAIN) {
-          tot[1] += klw + klwi;
+        if constexpr (MODE == MODE_TRAIN) tot[1] += klw + klwi;
+        if constexpr (MODE == MODE_TRAIN && EPS != EPS_ZREC) {     // (ZREC: the backward gathers the samples themselves)
           float* srow = out.sumz + (size_t)r_now * a.d;
           Chunk<4> s0c, s1c;
 #pragma unroll

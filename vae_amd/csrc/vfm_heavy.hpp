@@ -15,7 +15,8 @@ template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ items, int n_items,
                                                  const int32_t* __restrict__ occ_rows,
                                                  const float* __restrict__ sumz, const float* __restrict__ grow,
-                                                 float* __restrict__ item_acc, int d) {
+                                                 float* __restrict__ item_acc, int d,
+                                                 const int32_t* __restrict__ occ_other, const float* __restrict__ zrec) {
   constexpr int GPB = BLOCK / LPE;
   const int lig = threadIdx.x % LPE;
   const int C = (d + VEC - 1) / VEC;
@@ -30,12 +31,15 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
     float gs = 0.f;
     for (int o = beg; o < end; o += 4) {      // four occurrences in flight
       int r[4]; float g[4];
+      const float* src[4];           // the sumz row, or (pipelined step) the other entity's sample record
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool ok = o + u < end;
-        r[u] = occ_rows[ok ? o + u : beg];
+        const int oo = ok ? o + u : beg;
+        r[u] = occ_rows[oo];
         g[u] = ok ? grow[r[u]] : 0.f;
         gs += g[u];
+        src[u] = zrec ? zrec + (size_t)occ_other[oo] * xs + 4 : sumz + (size_t)r[u] * d;
       }
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
         if (j < C) {
           Chunk<VEC> sv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) sv[u] = ld_chunk<VEC>(sumz + (size_t)r[u] * d + (size_t)j * VEC);
+          for (int u = 0; u < 4; ++u) sv[u] = ld_chunk<VEC>(src[u] + (size_t)j * VEC);
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -159,10 +159,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
 
 __global__ __launch_bounds__(RS_THREADS) void k_index_finish(const uint32_t* __restrict__ keys,
                                                              const uint32_t* __restrict__ vals, int n, int F, int64_t T,
-                                                             int32_t* __restrict__ occ_ptr, int32_t* __restrict__ occ_rows) {
+                                                             int32_t* __restrict__ occ_ptr, int32_t* __restrict__ occ_rows,
+                                                             const void* __restrict__ x, int id64,
+                                                             int32_t* __restrict__ occ_other) {
   const int64_t total = (int64_t)n > T + 1 ? (int64_t)n : T + 1;
   for (int64_t i = blockIdx.x * (int64_t)RS_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * RS_THREADS) {
     if (i < n) occ_rows[i] = (int32_t)(vals[i] / (uint32_t)F);
+    if (occ_other && i < n) {      // two fields: the entity in the OTHER column of the occurrence's row (clamped like the keys)
+      const uint32_t op = vals[i] ^ 1u;
+      uint32_t lo, hi;
+      if (id64) { const uint2 t = reinterpret_cast<const uint2*>(x)[op]; lo = t.x; hi = t.y; }
+      else { lo = reinterpret_cast<const uint32_t*>(x)[op]; hi = (lo >> 31) ? 0xFFFFFFFFu : 0u; }
+      occ_other[i] = (hi == 0u && (int64_t)lo < T) ? (int32_t)lo : 0;
+    }
     if (i <= T) {            // first sorted position whose key is >= i
       int lo = 0, hi = n;
       while (lo < hi) {
@@ -290,10 +299,12 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* counts, void* stream) {
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other, int32_t* counts,
+                    void* stream) {
   if (B < 0 || F < 1 || F > VFM_MAX_FIELDS || T < 1 || T > 0xFFFFFFFELL || B * (int64_t)F > 0x7FFFFFFFLL ||
       (id_bits != 32 && id_bits != 64) || heavy_list < VFM_HEAVY_MIN)
     return fail(VFM_E_INVALID, "vfm_build_index: bad B, F, T, id_bits or heavy_list");
+  if (occ_other && F != 2) return fail(VFM_E_INVALID, "vfm_build_index: occ_other is defined for two fields");
   if (!ws || !occ_ptr || !counts || (B > 0 && (!x || !occ_rows)) || cap_heavy < 0 || cap_items < 0 ||
       (cap_heavy > 0 && !heavy_ids) || (cap_items > 0 && !heavy_items))
     return fail(VFM_E_INVALID, "vfm_build_index: NULL pointer");
@@ -329,7 +340,8 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
     const int64_t total = (int64_t)n > T + 1 ? (int64_t)n : T + 1;
     int64_t g = (total + RS_THREADS - 1) / RS_THREADS;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_index_finish, dim3((unsigned)g), dim3(RS_THREADS), 0, st, k0, v0, n, (int)F, T, occ_ptr, occ_rows);
+    hipLaunchKernelGGL(k_index_finish, dim3((unsigned)g), dim3(RS_THREADS), 0, st, k0, v0, n, (int)F, T, occ_ptr, occ_rows,
+                       x, (int)(id_bits == 64), occ_other);
   }
   hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, blk, NBH);
   hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);

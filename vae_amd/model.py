@@ -102,8 +102,22 @@ class VFM(nn.Module):
         # later batch (or predict / save) needs them.  Pays when a batch touches a small part of the table
         # (Criteo shape: 6 %); "auto" turns it on per batch below `lazy_threshold` touched rows.  The trajectory
         # is the dense one, bit for bit (tests/test_gpu_lazy_adam.py).
+        # Software-pipelined step (single rank, fused, two fields, one sample, Philox eps): when the caller names the
+        # NEXT batch (`train_step(plan, next_plan=...)`; fit() and bench.py do), the fused backward writes that
+        # batch's sample records while the updated rows are in its registers, and the next forward is a gather of
+        # those records -- no sampling, no sumz (include/vfm_hip.h: vfm_elbo_bwd_adam_pipe_f32).
+        # It pays when a batch has many more ROWS than distinct entities (the forward's saving grows with the rows, the
+        # backward's extra work -- sampling + writing one record per entity of the next batch -- with the entities):
+        # ML-100K shape, any real data set at the reference's B = 100,000, B = 1 M rows at ML-20M shape.  With
+        # uniform-random ids over 165 K entities and B = 100 K (U ~ B) it is a wash (measured: forward -20 us,
+        # backward +46 us), so "auto" turns it on from `pipeline_ratio` rows per entity of the next batch.
+        self.pipeline = "auto"
+        self.pipeline_ratio = 2.0
+        self._zrec = None                  # two record tables [T, 4 + d]
+        self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"
-        self.lazy_threshold = 0.35
+        self.lazy_threshold = 0.35         # "auto": batches touching less than this share of the rows ...
+        self.lazy_min_params = 1 << 24     # ... of a table with at least this many parameters (small tables: dense is cheap)
         self._lazy_last = None             # [T] int32: last Adam step applied to each row
         self._lazy_dirty = False           # some rows lag behind _adam_t
         self._lazy_lr = {}                 # {k: learning rate of the k-th step of the current moment period}
@@ -418,7 +432,7 @@ class VFM(nn.Module):
             return True
         if self.lazy_adam != "auto" or plan.B == 0:
             return False
-        return plan.U < self.lazy_threshold * self.T
+        return self._n_ent >= self.lazy_min_params and plan.U < self.lazy_threshold * self.T
 
     @torch.no_grad()
     def save_weights(self):
@@ -492,7 +506,8 @@ class VFM(nn.Module):
         return b
 
     def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
-                   process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None):
+                   process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None,
+                   next_plan: Optional[ops.BatchPlan] = None):
         """One iteration of vfm-torch.py:351-370 without autograd: forward, loss, backward, dense
         Adam (betas (0.9, 0.999), eps 1e-8).  Everything is enqueued on the current stream; nothing
         synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B])."""
@@ -537,6 +552,13 @@ class VFM(nn.Module):
             self._set_moment_form(scaled)
             self._adam_t += 1
             lazy = scaled and self.n_samples >= 1 and self._use_lazy(plan)
+            if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
+                    and out_pred is None and ops.pipeline_supported(plan.spec)):
+                ready = self._records_ready(plan, step)
+                if next_plan is not None and self.pipeline == "auto" and next_plan.B < self.pipeline_ratio * next_plan.U:
+                    next_plan = None          # too few rows per entity for the records to pay: do not prepare them
+                if ready or (next_plan is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
+                    return self._train_step_pipelined(plan, next_plan, lr, step, scaled, mark)
             k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1            # position of this step in its moment period
             if k == 1:
                 self._lazy_lr = {}
@@ -614,6 +636,37 @@ class VFM(nn.Module):
             mark("adam")
         return loss3, st.pred
 
+    def _records_ready(self, plan, step) -> bool:
+        f = self._zrec_for
+        return f is not None and f[0] is plan and f[1] == step and f[2] == self._flat._version
+
+    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark):
+        """The fused step with the sampling of the NEXT batch moved into this step's backward (see __init__)."""
+        ent, bia, scal = self._views(self._flat)
+        loss3 = self._gflat[self._n_flat: self._n_flat + 3]
+        if self._zrec is None:
+            rl = ops.record_len(self.d)
+            self._zrec = [torch.zeros(self.T, rl, dtype=torch.float32, device=self.device) for _ in range(2)]
+        cur, nxt = self._zrec
+        if not self._records_ready(plan, step):       # first step of a run (or the tables changed since): from the tables
+            ops.sample_records(plan, ent, bia, self.inv_occ, cur, self.rng_seed, step)
+            mark("sample_rec")
+        _, grow, pred = self._step_buffers(plan.B)
+        st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials)
+        mark("fwd")
+        if next_plan is not None and (next_plan.spec.T != self.T or next_plan.y is None):
+            next_plan = None
+        ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
+                                    self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
+                                    scaled_moments=scaled)
+        mark("bwd_adam")
+        if next_plan is not None:
+            self._zrec = [nxt, cur]
+            self._zrec_for = (next_plan, step + 1, self._flat._version)
+        else:
+            self._zrec_for = None
+        return loss3, st.pred
+
     def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,
             y_test=None, display_every: int = 1, lr: Optional[float] = None, verbose: bool = True,
             process_group=None, sort_within_batch: bool = True):
@@ -656,7 +709,9 @@ class VFM(nn.Module):
                     loss3, pr = self.train_step(plan, process_group=process_group)
                     train_pred[a:b] = pr
                 elif self.n_samples == 1:
-                    loss3, _ = self.train_step(plan, out_pred=train_pred[a:b], process_group=process_group)
+                    nxt = plans[(i + 1) % len(plans)] if world == 1 else None      # (pipelined step: names the next batch)
+                    loss3, pr = self.train_step(plan, process_group=process_group, next_plan=nxt)
+                    train_pred[a:b] = pr
                 else:       # [S,B] predictions: the train metrics use their mean over the samples
                     loss3, pr = self.train_step(plan, process_group=process_group)
                     train_pred[a:b] = pr.mean(0)
@@ -687,6 +742,7 @@ class VFM(nn.Module):
                           (f"Minibatch train RMSE {rec['train_rmse']:.4f}" if self.output == "reg" else
                            f"Minibatch train AUC {rec['train_auc']:.4f} Minibatch train MAP {rec['train_map']:.4f}"),
                           rec.get("test", ""))
+        self.sync_lazy()          # (lazy Adam mode: every row up to date before the caller looks at the tables)
         return hist
 
     @torch.no_grad()

@@ -161,9 +161,11 @@ class BatchPlan:
         items = torch.empty(cap_i, 4, dtype=torch.int32, device=dev)
         counts = torch.empty(4, dtype=torch.int32, device=dev)
         touched = torch.empty(max(min(n, spec.T), 1), dtype=torch.int32, device=dev)
+        # two fields: also the entity in the other column of every occurrence (the pipelined step gathers its sample)
+        self.occ_other = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if spec.F == 2 else None
         check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
-                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched), ptr(counts),
-                                  current_stream_ptr(dev)), "vfm_build_index")
+                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched),
+                                  ptr(self.occ_other), ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
         n_bad, n_heavy, n_items, n_touched = (int(v) for v in counts.tolist())     # the plan build's one readback
         self.U = n_touched                              # entities in the batch
         self._touched = touched[:n_touched]
@@ -292,6 +294,67 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples,
                              p.coord_off)
+
+
+FLAG_ZREC = 1024
+
+
+def record_len(d: int) -> int:
+    """Floats per entity in a sample-record table of the pipelined step: (w, weighted KL, 0, 0 | z[0..d-1])."""
+    return 4 + d
+
+
+def pipeline_supported(spec: Spec) -> bool:
+    """The software-pipelined step covers the reference's own shape: two fields, one sample, d % 4 == 0, d <= 512."""
+    return spec.F == 2 and int(spec.n_samples) == 1 and spec.d % 4 == 0 and spec.d <= 512 and spec.coord_off == 0
+
+
+def sample_records(plan: BatchPlan, entity_params, bias_params, inv_occ, zrec, seed, step):
+    """vfm_sample_records_f32: the sample records of `plan`'s entities for Philox step `step`, from the tables."""
+    p = _problem(plan.spec, plan.B, plan.B_global, plan.id_bits, seed, step, 0)
+    ids = plan.touched_ids()
+    check(_lib.load().vfm_sample_records_f32(C.byref(p), ptr(ids), ids.numel(), ptr(entity_params), ptr(bias_params),
+                                             ptr(inv_occ), ptr(plan.W), ptr(zrec), current_stream_ptr(zrec.device)),
+          "vfm_sample_records_f32")
+
+
+def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, out_grow, out_partials) -> FwdState:
+    """The forward of the pipelined step (VFM_FLAG_ZREC): a gather of this step's sample records; no sumz."""
+    spec = plan.spec
+    p = _problem(spec, plan.B, plan.B_global, plan.id_bits, seed, step, FLAG_ZREC)
+    check(_lib.load().vfm_elbo_fwd_f32(C.byref(p), ptr(plan.x), ptr(plan.y), ptr(zrec), None, None, ptr(scalars), None,
+                                       None, None, None, ptr(out_pred), ptr(out_partials), None, ptr(out_grow),
+                                       current_stream_ptr(zrec.device)), "vfm_elbo_fwd_f32 (records)")
+    p.flags = spec.link_flag
+    return FwdState(out_pred, out_partials, None, out_grow, p, None)
+
+
+def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next_plan, next_step, entity_params,
+                            bias_params, scalars, inv_occ, m_views, v_views, lr, step, loss_out, beta1=0.9, beta2=0.999,
+                            eps_adam=1e-8, scaled_moments=True):
+    """vfm_elbo_bwd_adam_pipe_f32: loss + backward + dense Adam, gathering samples from `zrec`, and (next_plan given)
+    writing the records of `next_plan`'s entities for Philox step `next_step` into `zrec_next`."""
+    t = plan.index_tensors()
+    ix = _lib.Index()
+    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
+    if len(t) == 5:
+        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
+        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+    ix.occ_other = plan.occ_other.data_ptr()
+    pipe = _lib.Pipe()
+    pipe.zrec = zrec.data_ptr()
+    if next_plan is not None:
+        if next_plan.occ_ptr is None:
+            next_plan.build_index()
+        pipe.zrec_next, pipe.next_occ_ptr, pipe.next_W = zrec_next.data_ptr(), next_plan.occ_ptr.data_ptr(), next_plan.W.data_ptr()
+        pipe.next_step = int(next_step)
+    p = st.problem
+    p.flags = plan.spec.link_flag | (FLAG_SCALED_MOMENTS if scaled_moments else 0)
+    check(_lib.load().vfm_elbo_bwd_adam_pipe_f32(
+        C.byref(p), C.byref(ix), C.byref(pipe), ptr(entity_params), ptr(bias_params), ptr(scalars), ptr(inv_occ),
+        ptr(plan.W), ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
+        ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), ptr(loss_out),
+        current_stream_ptr(zrec.device)), "vfm_elbo_bwd_adam_pipe_f32")
 
 
 def adam_catchup(entity_params, bias_params, m_views, v_views, last_step, ids, lr_of_step, upto, mark,
