@@ -2,8 +2,9 @@
 # Run on the GPU box (via gpurun): the measurement points SURVEY 8(d) asks for besides the default bench line, one
 # JSON line each, into gpurun_out/points_$1.jsonl  (copy the file to profiles/ to have it judged).
 #   cfg2 (ML-100K shape) | cfg3 at B = 1,048,576 rows | cfg3 with Zipf(1.1) item popularity | cfg5 shape on one GPU
-#   (lazy exact Adam: auto) and the same with the dense step | cfg3 forward A/B: k_fwd (every occurrence sampled),
-#   k_fwd2 with table eps, k_fwd2 with the RNG compiled out
+#   (lazy exact Adam: auto) and the same with the dense step | the software-pipelined step on / off where "auto"
+#   decides either way | cfg3 forward A/B: k_fwd (every occurrence sampled), k_fwd2 with table eps, k_fwd2 with the
+#   RNG compiled out, rows not sorted
 # usage: tools/bench_points.sh r02
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,6 +21,9 @@ j=json.loads(sys.stdin.readline()); j['point']='$label'; print(json.dumps(j))" >
 }
 run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30
 run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6
+run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --pipeline off
+run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions
+run cfg2_ml100k_d20_plain_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline off
 run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
 run cfg5_criteo_d256_lazy_auto "" --workload criteo_d256 --steps 200 --warmup 20
 run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --steps 40 --warmup 4

@@ -232,10 +232,17 @@ void adam_consts(float lr, float beta1, float beta2, int64_t step, float* step_s
   *bc2_sqrt = (float)sqrt(bc2);
 }
 
+// the two folded constants of a scaled-form step (one definition: the dense kernel and the catch-up table use it)
+void scaled_step_consts(float step_size, float bc2_sqrt, double s1, double s2, float* a1, float* q2) {
+  *a1 = (float)((double)step_size * s1);
+  *q2 = (float)(sqrt(s2) / (double)bc2_sqrt);
+}
+
 // VFM_FLAG_SCALED_MOMENTS: scale factors of Adam step `step` (k = position inside the period, 1..R)
 int scaled_moment_consts(const vfm_problem_t* p, float beta1, float beta2, int64_t step, AdamArgs* ad) {
   ad->scaled = 0; ad->store_true = 0; ad->s1 = ad->s2 = 1.f; ad->c1 = 1.f - beta1; ad->c2 = 1.f - beta2;
   ad->inv_bc2_sqrt = 1.0f / ad->bc2_sqrt;
+  ad->a1 = ad->step_size; ad->q2 = ad->inv_bc2_sqrt;
   if (!(p->flags & VFM_FLAG_SCALED_MOMENTS)) return 0;
   if (p->flags & VFM_FLAG_SPARSE_ADAM)
     return fail(VFM_E_INVALID, "VFM_FLAG_SCALED_MOMENTS and VFM_FLAG_SPARSE_ADAM exclude each other");
@@ -246,6 +253,7 @@ int scaled_moment_consts(const vfm_problem_t* p, float beta1, float beta2, int64
   ad->scaled = 1; ad->store_true = (k == VFM_MOMENT_PERIOD);
   ad->s1 = (float)s1; ad->s2 = (float)s2;
   ad->c1 = (float)((1.0 - (double)beta1) / s1); ad->c2 = (float)((1.0 - (double)beta2) / s2);
+  scaled_step_consts(ad->step_size, ad->bc2_sqrt, s1, s2, &ad->a1, &ad->q2);
   return 0;
 }
 
@@ -619,7 +627,9 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
     adam_consts(lr_of_step[k - 1], beta1, beta2, pstart + k, &step_size, &bc2_sqrt);
     const double s1 = pow((double)beta1, (double)k), s2 = pow((double)beta2, (double)k);
     if (!(s1 > 1e-30) || !(s2 > 1e-30)) return fail(VFM_E_UNSUPPORTED, "vfm_adam_catchup_f32: beta^k underflows");
-    tab.c[k] = make_float4(step_size, (float)s1, (float)s2, 1.0f / bc2_sqrt);
+    float a1, q2;
+    scaled_step_consts(step_size, bc2_sqrt, s1, s2, &a1, &q2);
+    tab.c[k] = make_float4(a1, q2, 0.f, 0.f);
   }
   int64_t nb = (n + BLOCK / 64 - 1) / (BLOCK / 64);
   if (nb > 8192) nb = 8192;

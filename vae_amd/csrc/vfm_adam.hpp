@@ -49,13 +49,13 @@ __global__ __launch_bounds__(BLOCK) void k_adam(float* __restrict__ p, const flo
 // of the current moment period travel by value as a kernel argument (2 KB).  One wave per row.
 // ---------------------------------------------------------------------------------------
 struct CatchTab {
-  float4 c[VFM_MOMENT_PERIOD + 1];      // c[k] = (step_size, s1 = b1^k, s2 = b2^k, 1 / sqrt(bc2)) of the k-th step of the period
+  float4 c[VFM_MOMENT_PERIOD + 1];      // c[k] = (a1 = step_size b1^k, q2 = sqrt(b2^k) / sqrt(bc2), -, -) of the period's k-th step
 };
 
-__device__ __forceinline__ float catchup_one(float p, float m, float v, const float4 c, float eps) {
-  const float mt = m * c.y, vt = v * c.z;
-  const float denom = fmaf(__builtin_amdgcn_sqrtf(vt), c.w, eps);
-  return fmaf(-c.x * mt, __builtin_amdgcn_rcpf(denom), p);
+// one replayed zero-gradient step, given r = sqrt(stored second moment) -- the scaled branch of adam_update (vfm_bwd.hpp)
+__device__ __forceinline__ float catchup_one(float p, float m, float r, const float4 c, float eps) {
+  const float denom = fmaf(r, c.y, eps);
+  return fmaf(-c.x * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ entity, float* __restrict__ bias,
@@ -78,10 +78,12 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
         float4 p = reinterpret_cast<float4*>(entity + ro)[j];
         const v4f m = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j);
         const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j);
+        const float rx = __builtin_amdgcn_sqrtf(v.x), ry = __builtin_amdgcn_sqrtf(v.y);
+        const float rz = __builtin_amdgcn_sqrtf(v.z), rw = __builtin_amdgcn_sqrtf(v.w);
         for (int k = k0 + 1; k <= k1; ++k) {
           const float4 c = tab.c[k];
-          p.x = catchup_one(p.x, m.x, v.x, c, eps); p.y = catchup_one(p.y, m.y, v.y, c, eps);
-          p.z = catchup_one(p.z, m.z, v.z, c, eps); p.w = catchup_one(p.w, m.w, v.w, c, eps);
+          p.x = catchup_one(p.x, m.x, rx, c, eps); p.y = catchup_one(p.y, m.y, ry, c, eps);
+          p.z = catchup_one(p.z, m.z, rz, c, eps); p.w = catchup_one(p.w, m.w, rw, c, eps);
         }
         reinterpret_cast<float4*>(entity + ro)[j] = p;
       }
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
         float2 p = *reinterpret_cast<float2*>(bias + 2 * (size_t)e);
         const float2 m = *reinterpret_cast<const float2*>(m_bias + 2 * (size_t)e);
         const float2 v = *reinterpret_cast<const float2*>(v_bias + 2 * (size_t)e);
+        const float rx = __builtin_amdgcn_sqrtf(v.x), ry = __builtin_amdgcn_sqrtf(v.y);
         for (int k = k0 + 1; k <= k1; ++k) {
           const float4 c = tab.c[k];
-          p.x = catchup_one(p.x, m.x, v.x, c, eps); p.y = catchup_one(p.y, m.y, v.y, c, eps);
+          p.x = catchup_one(p.x, m.x, rx, c, eps); p.y = catchup_one(p.y, m.y, ry, c, eps);
         }
         *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = p;
       }

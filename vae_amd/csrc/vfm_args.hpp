@@ -102,6 +102,9 @@ struct AdamArgs {
   // c1 = (1-b1)/s1, c2 = (1-b2)/s2; store_true: this step ends a period (write the true moments back)
   int32_t scaled, store_true;
   float s1, s2, c1, c2, inv_bc2_sqrt;
+  // scaled form, folded per-step constants: a1 = step_size * b1^k (times the stored moment = step_size * m),
+  // q2 = sqrt(b2^k) / sqrt(bc2) (times sqrt of the stored second moment = sqrt(v) / sqrt(bc2))
+  float a1, q2;
 };
 
 // lane-group shape of the row kernels for an embedding size (see pick_shape in vfm_abi.hip)

@@ -30,12 +30,15 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
     // (this form is not bitwise torch's anyway: hardware sqrt / rcp, 1 ulp each, instead of the IEEE
     // sqrt and the two IEEE divisions of the plain form below -- ~10 instead of ~45 VALU instructions
     // per coordinate, which the kernel would otherwise not hide behind its memory traffic)
+    // p -= step_size m_t / (sqrt(v_t) / sqrt(bc2) + eps) with m_t = ms b1^k, v_t = vs b2^k, the per-step factors folded
+    // into two scalars (a1, q2): sqrt is taken of the STORED second moment, so a row without gradient needs it once
+    // however many steps are replayed (k_adam_catchup runs exactly these operations)
     m = fmaf(ad.c1, g, m);
     v = fmaf(ad.c2 * g, g, v);
-    const float mt = m * ad.s1, vt = v * ad.s2;
-    const float denom = fmaf(__builtin_amdgcn_sqrtf(vt), ad.inv_bc2_sqrt, ad.eps);
-    if (ad.store_true) { m = mt; v = vt; }
-    return fmaf(-ad.step_size * mt, __builtin_amdgcn_rcpf(denom), p);
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), ad.q2, ad.eps);
+    const float pn = fmaf(-ad.a1 * m, __builtin_amdgcn_rcpf(denom), p);
+    if (ad.store_true) { m = m * ad.s1; v = v * ad.s2; }
+    return pn;
   }
   m = m + (g - m) * (1.0f - ad.b1);
   v = v * ad.b2 + ((1.0f - ad.b2) * g) * g;
