@@ -18,7 +18,9 @@ X, y = sort_rows_within_batches(X, y, B)
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    plans = [model.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(NB)]
+    plans = [model.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B], defer_readback=True) for i in range(NB)]   # as fit() does
+    for p in plans:
+        p.U                    # (collect the 16-byte readbacks)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / NB * 1e3
     print(f"rep {rep}: plan build {dt:.3f} ms per batch (B={B}, T={sum(sizes)}, heavy lists {0 if plans[0].heavy is None else plans[0].heavy[0].numel()})", flush=True)

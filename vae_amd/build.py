@@ -23,6 +23,7 @@ def _stale(target, sources):
 _UNITS = [("vfm_abi.hip", "", []), ("vfm_index.hip", "", []), ("vfm_variants.hip", "", []),
           ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2.hip", "_softplus", ["-DVFM_LINK=1"]),
+          ("vfm_fwd2m.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2m.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"])]
 
 

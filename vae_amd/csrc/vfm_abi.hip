@@ -148,8 +148,9 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
 // sampling tasks (k_fwd2: an id repeated in consecutive rows of the second column is sampled once per run);
 // everything else -- general F, S > 1, the multi-rank forms that feed the kernel slots / partial row values --
 // runs k_fwd.  VFM_FWD_KERNEL=1 forces k_fwd (A/B runs, tests of both kernels).
-bool use_fwd2(const vfm_problem_t* p, int eps) {
-  if (p->F != 2 || p->n_samples != 1 || (p->d & 3) != 0 || p->d > 512) return false;
+bool use_fwd2(const vfm_problem_t* p, int eps, bool multi = false) {
+  if (p->F != 2 || (p->d & 3) != 0 || p->d > 512) return false;
+  if (multi ? (p->n_samples < 2 || p->n_samples > 4 || eps == EPS_ZERO) : p->n_samples != 1) return false;
   if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS)) return false;
   if (eps == EPS_ZPRE) return false;
   return env_int("VFM_FWD_KERNEL", 2) != 1;
@@ -331,6 +332,12 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   FwdOut o{pred, partials, sumz, grow};
   Shape s;
   pick_shape(p->d, &s);
+  if (use_fwd2(p, eps, true)) {        // two fields, 2..4 samples: ONE launch, the sample loop runs inside the kernel
+    KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias, eps_global, 0);
+    const int md = train ? MODE_TRAIN : MODE_PREDICT;
+    if (int rc = softplus(p) ? launch_fwd2m_softplus(eps, md, a, o, st) : launch_fwd2m_abs(eps, md, a, o, st)) return rc;
+    return after_launch("vfm_elbo_fwd_f32");
+  }
   for (int sm = 0; sm < p->n_samples; ++sm) {      // one launch per variational sample (vfm_fwd.hpp)
     KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                         eps_global, sm);

@@ -3,6 +3,7 @@
 //   vfm_abi.hip  C ABI (include/vfm_hip.h), argument checks, small / Adam / shard glue kernels, k_heavy
 //   vfm_fwd.hip  k_fwd instances + dispatch            (compiled once per link function, -DVFM_LINK=0|1)
 //   vfm_fwd2.hip k_fwd2 instances + dispatch           (two fields, task-stream form; once per link function)
+//   vfm_fwd2m.hip k_fwd2m instances + dispatch         (the same with 2..4 variational samples inside the kernel)
 //   vfm_bwd.hip  k_bwd, k_sample instances + dispatch  (compiled once per link function)
 // Splitting keeps every kernel family in its own object (built in parallel by vae_amd/build.py); a
 // kernel is always launched from the unit that defines it, so no relocatable device code is needed.
@@ -128,6 +129,7 @@ VFM_INTERNAL int env_int(const char* name, int dflt);
   VFM_INTERNAL int launch_fwd_##SUFFIX(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,   \
                                        hipStream_t st);                                                        \
   VFM_INTERNAL int launch_fwd2_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
+  VFM_INTERNAL int launch_fwd2m_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);         \
   VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
                                        const AdamArgs& ad, hipStream_t st);                                    \
   VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \

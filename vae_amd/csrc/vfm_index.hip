@@ -74,12 +74,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 // [256 * NB] array by fewer threads is a 30 us latency chain at NB = 98).
 __global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist, int NB) {
   __shared__ uint32_t sh_dig[256];
+  constexpr int CH = 32;                         // tiles held in registers at a time: the loads go out together
   const int tid = threadIdx.x, dg = tid >> 2, part = tid & 3;
   const int per = (NB + 3) >> 2;
   const int b0 = part * per, b1 = (b0 + per < NB) ? b0 + per : NB;
   uint32_t* row = hist + (size_t)dg * NB;
   uint32_t s = 0;
-  for (int b = b0; b < b1; ++b) s += row[b];
+  for (int c0 = b0; c0 < b1; c0 += CH) {
+    uint32_t v[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = (c0 + i < b1) ? row[c0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s += v[i];
+  }
   // the 4 parts of a digit sit in adjacent lanes: inclusive scan over the quad
   uint32_t incl = s;
   {
@@ -104,7 +111,16 @@ __global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist
   }
   __syncthreads();
   uint32_t run = sh_dig[dg] + incl - s;
-  for (int b = b0; b < b1; ++b) { const uint32_t t = row[b]; row[b] = run; run += t; }
+  for (int c0 = b0; c0 < b1; c0 += CH) {
+    uint32_t v[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v[i] = (c0 + i < b1) ? row[c0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (c0 + i < b1) row[c0 + i] = run;
+      run += v[i];
+    }
+  }
 }
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ kin,

@@ -300,7 +300,7 @@ class VFM(nn.Module):
             raise ValueError("nb_occ must have one entry per entity")
         self.inv_occ = ops.inv_occ_from_counts(self.nb_occ)
 
-    def plan(self, x, y=None, B_global=None, build_index=True, process_group=None) -> ops.BatchPlan:
+    def plan(self, x, y=None, B_global=None, build_index=True, process_group=None, defer_readback=False) -> ops.BatchPlan:
         x = torch.as_tensor(x).to(self.device)
         if x.dtype not in (torch.int32, torch.int64):
             x = x.to(torch.int64)
@@ -320,7 +320,8 @@ class VFM(nn.Module):
                                process_group, torch.distributed.get_rank(process_group),
                                torch.distributed.get_world_size(process_group))
         return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
-                             build_index=build_index and y is not None, process_group=process_group)
+                             build_index=build_index and y is not None, process_group=process_group,
+                             defer_readback=defer_readback)
 
     def _resolve_exchange(self, process_group):
         """exchange == "auto" -> the pattern for this model / world size (see __init__)."""
@@ -698,7 +699,8 @@ class VFM(nn.Module):
                 a, b = lo, hi                 # every rank handles all rows, d / N coordinates (vae_amd/dims.py)
             else:
                 a, b = shard_rows(lo, hi, rank, world)
-            plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group))
+            plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group,
+                                   defer_readback=True))      # (the index builds are enqueued back to back)
             spans.append((a, b))
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}

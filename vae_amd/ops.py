@@ -103,7 +103,9 @@ class BatchPlan:
 
     def __init__(self, spec: Spec, x: torch.Tensor, y: Optional[torch.Tensor],
                  inv_occ: Optional[torch.Tensor], B_global: Optional[int] = None,
-                 build_index: bool = True, validate: bool = True, process_group=None):
+                 build_index: bool = True, validate: bool = True, process_group=None, defer_readback: bool = False):
+        """defer_readback: enqueue the index build and return; its 16-byte readback (and the IndexError an id out
+        of range raises) happens when the plan is first used -- a loop that builds many plans then never waits."""
         _need_cuda(x, "x")
         if x.dim() != 2 or x.shape[1] != spec.F:
             raise ValueError(f"x must be [B,{spec.F}], got {tuple(x.shape)}")
@@ -122,7 +124,9 @@ class BatchPlan:
                 raise ValueError("y must be [B]")
         self.W = None
         self.occ_ptr = self.occ_rows = None
-        self.heavy = None
+        self._heavy = self._pend = None
+        self._U = 0
+        self._touched = None
         self._checked = False
         dev = x.device
         lib = _lib.load()
@@ -135,14 +139,14 @@ class BatchPlan:
                 from .dist import sum_normalisers
                 sum_normalisers(self.W, process_group)
         if build_index and y is not None:
-            self.build_index(validate=validate)        # (its one readback carries the id check too)
+            self.build_index(validate=validate, defer=defer_readback)     # (its one readback carries the id check too)
         elif validate and self.B > 0:
             # nn.Embedding would raise IndexError (vfm-torch.py:207): one readback
             if bool(((x < 0) | (x >= spec.T)).any()):
                 raise IndexError(f"entity id out of range [0,{spec.T}): min {int(x.min())}, max {int(x.max())}")
             self._checked = True
 
-    def build_index(self, validate: bool = False):
+    def build_index(self, validate: bool = False, defer: bool = False):
         """Inverted index entity -> batch rows: `vfm_build_index` (a stable radix sort in HIP, csrc/vfm_index.hip;
         what the reference gets from torch.unique, vfm-torch.py:190-192).  Launch-only except for ONE small
         readback at the end: (ids out of range, number of heavy lists, number of their work items)."""
@@ -166,26 +170,57 @@ class BatchPlan:
         check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
                                   ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched),
                                   ptr(self.occ_other), ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
-        n_bad, n_heavy, n_items, n_touched = (int(v) for v in counts.tolist())     # the plan build's one readback
-        self.U = n_touched                              # entities in the batch
+        self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
+        # the plan build's one readback: 16 bytes into pinned host memory, asynchronously
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        self._pend = (host, done, hid, items, touched, validate, counts)
+        if not defer:
+            self._finish()
+
+    def _finish(self):
+        """Complete a deferred index build: read (bad ids, heavy lists, work items, entities) and size the lists."""
+        if self._pend is None:
+            return
+        host, done, hid, items, touched, validate, _keep = self._pend
+        self._pend = None
+        done.synchronize()
+        n_bad, n_heavy, n_items, n_touched = (int(v) for v in host.tolist())
+        spec, dev = self.spec, self.x.device
+        self._U = n_touched                              # entities in the batch
         self._touched = touched[:n_touched]
         if validate and n_bad and not self._checked:
             # nn.Embedding would raise IndexError (vfm-torch.py:207)
             raise IndexError(f"entity id out of range [0,{spec.T}): min {int(self.x.min())}, max {int(self.x.max())}")
         self._checked = True
-        self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
-        # long lists (skewed data): cut in work items of at most HEAVY_LIST occurrences, pre-reduced by
-        # their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
-        self.heavy = None
+        # long lists (skewed data, small tables): cut in work items of at most `heavy_list` occurrences, pre-reduced
+        # by their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
+        self._heavy = None
         if n_heavy > 0:
             rec = 4 + (spec.d + 3) // 4 * 4
-            self.heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
-                          torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
+            self._heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
+                           torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
+
+    @property
+    def U(self) -> int:
+        """Number of distinct entities in the batch."""
+        if self.occ_ptr is None:
+            self.build_index()
+        self._finish()
+        return self._U
+
+    @property
+    def heavy(self):
+        self._finish()
+        return self._heavy
 
     def touched_ids(self) -> torch.Tensor:
         """Sorted ids of the entities this batch contains (int32; made by the index build)."""
         if self.occ_ptr is None:
             self.build_index()
+        self._finish()
         return self._touched
 
     def index_tensors(self, with_touched: bool = False):
@@ -193,6 +228,7 @@ class BatchPlan:
         touched-rows step of the lazy exact Adam mode)."""
         if self.occ_ptr is None:
             self.build_index()
+        self._finish()
         base = [self.occ_ptr, self.occ_rows]
         if self.heavy is not None:
             base = base + list(self.heavy)
