@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="the software-pipelined step (the backward of step n writes the sample records of batch n+1, the "
                          "forward gathers records: no sampling, no sumz); auto: from 2 rows per distinct entity")
+    ap.add_argument("--lookahead", default="on", choices=["on", "off"],
+                    help="look-ahead lazy exact Adam: the fused step skips the rows that are neither in this batch nor in "
+                         "the next (bitwise the dense trajectory); off = every row every step")
     ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
     ap.add_argument("--lazy-adam", default="auto", choices=["auto", "on", "off"],
                     help="lazy exact dense Adam (rows outside the batch are skipped and replayed later, bitwise the dense "
@@ -127,6 +130,7 @@ def main():
     model.scaled_moments = not args.plain_moments
     model.lazy_adam = {"auto": "auto", "on": True, "off": False}[args.lazy_adam]
     model.pipeline = {"auto": "auto", "on": True, "off": False}[args.pipeline]
+    model.lookahead = args.lookahead == "on"
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -224,7 +228,7 @@ def main():
             else:
                 mark = None
             model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables,
-                             next_plan=plans[(s + 1) % nbt] if (world == 1 and args.pipeline != "off") else None)
+                             next_plan=plans[(s + 1) % nbt] if world == 1 else None)
             if args.sync_each_step:
                 torch.cuda.synchronize()
 
@@ -299,11 +303,12 @@ def main():
     loss = float(model._gflat[model._n_flat].item())
     if world > 1 and model.exchange in ("sharded", "dims"):
         model.sync_params(pg)
+    lazy_kind = model._lazy_kind          # which lazy exact form the timed steps ran in (None: every row every step)
     model.sync_lazy()
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
-    kern, roof = kernel_report(events, model, args, world, B, d, F, U)
+    kern, roof = kernel_report(events, model, args, world, B, d, F, U, lazy_kind)
     copy_gbs = stream_copy_rate(dev)
     if roof is not None:
         roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
@@ -366,7 +371,8 @@ def main():
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "adam_moments": "scaled form (untouched rows do not write m, v)" if (
                            model.scaled_moments and world == 1 and not args.unfused) else "plain",
-                       "lazy_exact_adam": bool(model._lazy_last is not None),
+                       "lazy_exact_adam": {"list": "rows of the batch only + replay pass", "la": "look-ahead (this batch + next batch)",
+                                           None: False}[lazy_kind],
                        "pipelined_step": bool(model._zrec is not None and world == 1),
                        "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
                        "exchange_autotune_ms_per_step": tune,
@@ -392,7 +398,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_report(events, model, args, world, B, d, F, U):
+def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
     """Per-kernel averages of the HIP events recorded inside the timed region, each with its ALGORITHMIC bytes
      and the resulting GB/s, and the `roofline` object of the kernel that takes most time."""
     kern = {}
@@ -413,7 +419,8 @@ def kernel_report(events, model, args, world, B, d, F, U):
             d_k, B_k = d, B
         bytes_fwd = U * (8 * d_k + 16) + B_k * (idb * F + 8)        # touched rows once + ids, y, pred
         bytes_bwd = bytes_fwd + U * (8 * d_k + 8)                   # re-read + one write per touched row
-        lazy = "catchup" in acc          # lazy exact dense Adam: only the batch's rows are read / written per step
+        look = lazy_kind == "la"  # look-ahead lazy exact Adam: rows in neither this nor the next batch are skipped
+        lazy = "catchup" in acc and not look   # lazy exact dense Adam: only the batch's rows are read / written per step
         piped = model._zrec is not None and world == 1 and "sample_rec" not in acc     # software-pipelined step (steady state)
         if piped:
             # forward = gather of sample records: each touched record once (4d + 16 B) + ids, y, pred, grow
@@ -425,7 +432,9 @@ def kernel_report(events, model, args, world, B, d, F, U):
                # fused backward+Adam: gradients stay on chip -> per-row inputs + Adam state traffic
                # (scaled moments: the rows a batch does not touch read p, m, v and write p only: 16 B/param)
                "sample_rec": U * (8 * d_k + 16) + U * (4 * d_k + 16),
-               "bwd_adam": (B_k * (idb * F + 8) + U * 16 + 24.0 * U * (2 * d_k + 2)) if lazy else (
+               # look-ahead: rows of the batch 24 B/parameter, rows of the next batch only 16, the others nothing
+               "bwd_adam": (B_k * (idb * F + 8) + U * 16 + (2 * d_k + 2) * (24.0 * U + 16.0 * U * (1.0 - U / model.T)))
+               if look else (B_k * (idb * F + 8) + U * 16 + 24.0 * U * (2 * d_k + 2)) if lazy else (
                            B_k * (idb * F + 8) + U * 16 + 24.0 * n_params -
                            (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0)
                            # pipelined: + the next batch's records written, the other entities' records read once
@@ -447,7 +456,8 @@ def kernel_report(events, model, args, world, B, d, F, U):
                         ("k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "
                          "once per run)" if fwd2 else "k_fwd (gather->reparam->FM->ELBO)"), "bwd": "k_bwd (entity-centric gradients)",
                  "bwd_adam": "k_bwd<ADAM> (gradients + dense Adam fused)" + (", rows of the batch only (lazy exact Adam)" if lazy else "")
-                             + (" + sampling of the next batch's entities (pipelined step)" if piped else ""),
+                             + (" + sampling of the next batch's entities (pipelined step)" if piped else "")
+                             + (", look-ahead lazy exact form (rows in neither this batch nor the next are skipped)" if look else ""),
                  "adam": "k_adam (dense Adam)",
                  "sample_rec": "k_sample_rec (sample records of a batch from the tables: first step of a pipelined run)",
                  "catchup": "k_adam_catchup (lazy exact dense Adam: replay of the skipped zero-gradient updates on the batch's rows)",

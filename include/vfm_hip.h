@@ -396,6 +396,26 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
                          int64_t T, int32_t d, const float* lr_of_step, float beta1, float beta2, float eps_adam,
                          int64_t upto, int64_t mark, void* stream);
 
+/* Look-ahead form of the lazy exact Adam (mid-range touch fractions, e.g. ML-20M shape at B = 100 K: 59 % of the
+ * rows per batch): the fused dense step visits a row only if it is in THIS batch (gradient update) or in the NEXT one
+ * (`next_occ_ptr`: that batch's inverted-index offsets; the row replays whatever it skipped plus this step's
+ * zero-gradient update, so the next forward reads current parameters) -- a row in neither waits.  With independent
+ * batches touching a share f of the rows each, (1-f)^2 of the table is not read or written at all.  No separate
+ * catch-up pass: the replay runs inside the kernel, constants of the period's steps in `step_tab`
+ * (2 * (VFM_MOMENT_PERIOD + 1) floats, device; every look-ahead call records its own step there).  Bitwise the dense
+ * trajectory.  Requirements: the rows of THIS batch are up to date through step-1 (they are if the previous step was a
+ * look-ahead call naming this batch, or after vfm_adam_catchup_f32 on them); `last_step` as in vfm_adam_catchup_f32;
+ * not for the last step of a moment period (step % VFM_MOMENT_PERIOD == 0: bring all rows up to date and run the dense
+ * call).  Same arguments as vfm_elbo_bwd_adam_f32 otherwise (Philox eps). */
+int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* idx,
+                                    float* entity_params, float* bias_params, float* scalars,
+                                    const float* inv_occ, const double* W,
+                                    const float* sumz, const float* grow, double* partials,
+                                    float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                                    float* m_scalars, float* v_scalars,
+                                    float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                                    int32_t* last_step, const int32_t* next_occ_ptr, float* step_tab, void* stream);
+
 /* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
  * both tables; the only per-step exchange is one all-reduce of B + VFM_MAX_FWD_BLOCKS floats):
  *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_PRIOR_TERMS (+ coord_off; + VFM_FLAG_NO_BIAS on

@@ -14,6 +14,7 @@ def _setup(lazy, n_samples=1, F=3, d=16, T_sizes=(900, 700, 400), B=48, nb=12):
     torch.manual_seed(3)
     m = VFM(field_sizes=list(T_sizes)[:F], embedding_size=d, device="cuda", rng_seed=11, n_samples=n_samples)
     m.lazy_adam = lazy
+    m.pipeline = False
     X, y = synthetic_triples(list(T_sizes)[:F], nb * B, seed=4, device="cuda")
     m.set_training_data(X, nb_train=nb * B)
     plans = [m.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
@@ -85,3 +86,33 @@ def test_catchup_argument_checks():
     lib = _lib.load()
     lr = (C.c_float * 1)(0.1)
     assert lib.vfm_adam_catchup_f32(None, None, None, None, None, None, None, None, 0, 10, 8, lr, 0.9, 0.999, 1e-8, 1, 1, None) == -1
+
+
+@pytest.mark.parametrize("B,F,d", [(48, 3, 16), (700, 2, 128)])
+def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d):
+    """The look-ahead form (train_step(plan, next_plan=...): the fused step visits only the rows of this batch and of
+    the next) against the dense fused step: bitwise over 300 steps with changing learning rates, an un-announced
+    batch in between (its rows are caught up by the separate pass), predictions, and two moment-period boundaries."""
+    dense, plans_d, X = _setup(False, F=F, d=d, B=B)
+    la, plans_l, _ = _setup(False, F=F, d=d, B=B)
+    dense.lookahead = False
+    dense.pipeline = la.pipeline = False
+    n = len(plans_l)
+    f = plans_l[0].U / la.T
+    assert (1 - f) ** 2 >= la.lookahead_min_skip
+    order = list(range(300))
+    order[100] = 7                                        # step 100 does not take the batch step 99 announced
+    for s in range(300):
+        lr = 0.05 if s % 7 else 0.02
+        i, j = order[s] % n, order[s + 1] % n if s + 1 < 300 else 0
+        ld, _ = dense.train_step(plans_d[i], lr=lr)
+        ll, _ = la.train_step(plans_l[i], lr=lr, next_plan=plans_l[j])
+        assert la._lazy_kind in ("la", None)
+        if s % 50 == 17:
+            assert torch.equal(ld, ll), s
+        if s == 140:
+            assert torch.equal(dense.predict(X[:200])["y_pred"], la.predict(X[:200])["y_pred"])
+    assert la._lazy_dirty
+    la.sync_lazy()
+    assert torch.equal(dense._flat, la._flat)
+    assert torch.equal(dense._adam_m, la._adam_m) and torch.equal(dense._adam_v, la._adam_v)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Assemble the judged evidence under profiles/ from the scratch output of a GPU run (gpurun_out/):
+    tools/collect_profiles.py r02 [bench_line.json]
+reads gpurun_out/prof_<tag>/ (tools/profile_round.sh <tag>: rocprofv3 kernel trace + the separate PMC passes of the
+default bench command) and writes profiles/<tag>_kernel_stats.csv (our kernels' rows of the --stats summary),
+profiles/<tag>_pmc_summary.{txt,json}, profiles/latest_traffic.json (HBM bytes per launch of the step's kernels:
+what bench.py reports as roofline.traffic) and, if given, profiles/<tag>_bench.json (the bench line)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.reader(open(stats)))
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+    w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if "vfm::" in r[0]:
+            w.writerow(r)
+txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--json",
+                      os.path.join(dst, f"{tag}_pmc_summary.json"), os.path.join(src, "trace"), os.path.join(src, "pmc_fetch"),
+                      os.path.join(src, "pmc_write"), os.path.join(src, "pmc_sq")], capture_output=True, text=True, check=True).stdout
+open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(txt)
+summ = json.load(open(os.path.join(dst, f"{tag}_pmc_summary.json")))
+traffic = {}
+for k, v in summ.items():
+    name = "fwd" if k.startswith("k_fwd") else ("bwd_adam" if k.startswith("k_bwd") else None)
+    if name and "hbm_bytes_per_launch" in v and v.get("launches", 0) >= 50:
+        traffic[name] = {"kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "fetch_size_bytes_raw": v["fetch_bytes_raw"],
+                         "write_size_bytes": v["write_bytes"], "l2_hit_rate": v.get("l2_hit_rate"),
+                         "avg_us_under_rocprof": v["avg_us"].get("trace")}
+traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum passes of `python bench.py --steps 100 "
+                      f"--warmup 10 --no-cpu-baseline --no-events` (tools/profile_round.sh {tag}); hbm_bytes = 2*FETCH_SIZE*1024 + "
+                      "WRITE_SIZE*1024 (gfx950 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md; Infinity-Cache hits are "
+                      "included in the count)")
+json.dump(traffic, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
+if len(sys.argv) > 2:
+    shutil.copy(sys.argv[2], os.path.join(dst, f"{tag}_bench.json"))
+print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag) or f == "latest_traffic.json"))

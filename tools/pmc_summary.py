@@ -14,7 +14,8 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("k_fwd", "k_bwd", "k_adam", "k_finalize", "k_norms", "k_zero", "k_inv_occ", "k_philox")
+OURS = ("k_fwd", "k_bwd", "k_adam_catchup", "k_adam", "k_finalize", "k_norms", "k_zero", "k_inv_occ", "k_philox", "k_heavy_sum",
+        "k_heavy", "k_sample_rec", "k_radix", "k_index", "k_var_")
 
 
 def short(name):

@@ -33,7 +33,7 @@ EXPORTS = (
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
     "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_adam_catchup_f32",
-    "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32",
+    "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
 )
 
 
@@ -129,6 +129,8 @@ def load():
     lib.vfm_sample_records_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.vfm_elbo_bwd_adam_pipe_f32.argtypes = ([PP, C.POINTER(Index), C.POINTER(Pipe)] + [vp] * 13 +
                                                [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])
+    lib.vfm_elbo_bwd_adam_lookahead_f32.argtypes = ([PP, C.POINTER(Index)] + [vp] * 14 +
+                                                    [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp, vp, vp, vp])
     lib.vfm_variant_fwd_f32.argtypes = [PP, i32] + [vp] * 18
     lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
     for name in EXPORTS:

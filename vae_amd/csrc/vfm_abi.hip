@@ -374,7 +374,7 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias,
-            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
@@ -414,7 +414,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                       eps_bias, eps_global);
   a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (!untouched_only)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -443,7 +443,7 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
-            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   // (the pre-reduction covers whole lists, so with several entity chunks it runs with the first one)
   if (p->e_lo == 0)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
@@ -479,7 +479,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
   if (rec_pos != nullptr && rec_ptr == nullptr)      // (rec_pos may be NULL when rec_ptr lists no record at all)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_pos without rec_ptr");
   BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -597,7 +597,7 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: bad argument");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, nullptr, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}};
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (int rc = run_heavy(p, idx, nullptr, grow, (hipStream_t)stream, &b, pipe->zrec)) return rc;
   b.zrec = pipe->zrec; b.occ_other = idx->occ_other;
   b.zrec_next = pipe->zrec_next; b.next_occ_ptr = pipe->next_occ_ptr; b.next_W = pipe->next_W;
@@ -610,6 +610,41 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, EPS_PHILOX, 1, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_adam_pipe_f32");
+}
+
+int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* idx,
+                                    float* entity_params, float* bias_params, float* scalars,
+                                    const float* inv_occ, const double* W,
+                                    const float* sumz, const float* grow, double* partials,
+                                    float* m_entity, float* v_entity, float* m_bias, float* v_bias,
+                                    float* m_scalars, float* v_scalars,
+                                    float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
+                                    int32_t* last_step, const int32_t* next_occ_ptr, float* step_tab, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (int rc = single_sample_only(p, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
+  if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
+  if ((p->flags & ~VFM_FLAG_LINK_SOFTPLUS) != VFM_FLAG_SCALED_MOMENTS)
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: VFM_FLAG_SCALED_MOMENTS (and optionally the link flag) only");
+  if (!entity_params || !bias_params || !scalars || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
+      !v_scalars || step < 1 || !inv_occ || !W || !partials || (p->B > 0 && (!sumz || !grow)) || !last_step ||
+      !next_occ_ptr || !step_tab)
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: bad argument");
+  if (step % VFM_MOMENT_PERIOD == 0)
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: the last step of a moment period is a dense one "
+                               "(bring every row up to date, then vfm_elbo_bwd_adam_f32)");
+  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
+  BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
+            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
+  b.last_step = last_step; b.next_occ_ptr = next_occ_ptr; b.step_tab = reinterpret_cast<float2*>(step_tab);
+  b.la_step = (int32_t)step; b.la_k = (int32_t)((step - 1) % VFM_MOMENT_PERIOD + 1);
+  AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
+  adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+  if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
+  Shape s;
+  pick_shape(p->d, &s);
+  if (int rc = dispatch_bwd(p, s, EPS_PHILOX, 1, a, b, ad, (hipStream_t)stream)) return rc;
+  return after_launch("vfm_elbo_bwd_adam_lookahead_f32");
 }
 
 int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,

@@ -94,6 +94,12 @@ struct BwdArgs {
   const int32_t* next_occ_ptr;    // inverted-index offsets of the next batch: membership test
   const double* next_W;           // its normalisers
   RngKey next_key;                // its Philox key (step + 1)
+  // look-ahead lazy Adam (LA instances, vfm_elbo_bwd_adam_lookahead_f32): a row that is neither in this batch nor
+  // in the next (next_occ_ptr) is skipped; a row that was skipped replays its zero-gradient updates (the constants
+  // of the period's steps live in step_tab) before this step's update
+  int32_t* last_step;             // [T] last Adam step applied to each row
+  float2* step_tab;               // [VFM_MOMENT_PERIOD + 1] (a1, q2) of the k-th step of the moment period
+  int32_t la_step, la_k;          // this Adam step and its position in the period
 };
 
 struct AdamArgs {

@@ -38,6 +38,14 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
     }
   }
   if (b.zrec != nullptr) return fail(VFM_E_UNSUPPORTED, "pipelined step: fused Adam, Philox eps, d % 4 == 0 only");
+  if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX) {
+    if (b.last_step != nullptr) {     // look-ahead lazy Adam
+      if (a.S > 1) return fail(VFM_E_UNSUPPORTED, "look-ahead lazy Adam: one variational sample");
+      hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false, false, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+      return 0;
+    }
+  }
+  if (b.last_step != nullptr) return fail(VFM_E_UNSUPPORTED, "look-ahead lazy Adam: fused Adam with Philox eps only");
   if constexpr (STAGE == STAGE_FULL) {
     if (a.S > 1) {       // variational samples: the instance with the per-sample walk
       hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);

@@ -55,10 +55,17 @@ __device__ __forceinline__ int heavy_slot_of(const int32_t* ids, int n, int e) {
   return (n > 0 && ids[lo] == e) ? lo : -1;
 }
 
-template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI, bool PIPE = false>
+// one replayed zero-gradient step of the scaled-moment form, given r = sqrt(stored second moment) and the step's
+// (a1, q2): exactly adam_update's scaled branch with g = 0 (k_adam_catchup, vfm_adam.hpp, runs the same operations)
+__device__ __forceinline__ float replay_one(float p, float m, float r, float2 c, float eps) {
+  return fmaf(-c.x * m, __builtin_amdgcn_rcpf(fmaf(r, c.y, eps)), p);
+}
+
+template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI, bool PIPE = false, bool LA = false>
 __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
   constexpr int GPB = BLOCK / LPE;
   static_assert(!PIPE || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "the pipelined step is the fused single-sample one");
+  static_assert(!LA || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI && !PIPE), "look-ahead lazy Adam is a form of the fused dense step");
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ float sh_cs_next[PIPE ? VFM_MAX_FIELDS : 1];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
@@ -73,6 +80,9 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     if constexpr (PIPE) sh_cs_next[tid] = b.zrec_next ? (float)(a.group_n[tid] / b.next_W[tid]) : 0.f;
   }
   __syncthreads();
+  if constexpr (LA) {
+    if (blockIdx.x == 0 && tid == 0) b.step_tab[b.la_k] = make_float2(ad.a1, ad.q2);     // for later replays of this step
+  }
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
   const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);     // (dimension-sharded mode: one rank carries bias_params)
 
@@ -176,6 +186,11 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     float* grow_e = (ADAM || STAGE == STAGE_ACC) ? nullptr : b.g_entity + (size_t)e * (2 * (size_t)d);
     const bool touched = (STAGE == STAGE_APPLY) ? gc.y > 0.f : beg != end;
     const float cntf = (STAGE == STAGE_APPLY) ? gc.y : (float)(end - beg);
+    int la_gap = 0;                        // LA: skipped zero-gradient steps this row applies before this step's update
+    if constexpr (LA) {
+      if (!touched && b.next_occ_ptr[e + 1] == b.next_occ_ptr[e]) continue;     // in neither batch: the row waits
+      la_gap = (b.la_step - 1) - b.last_step[e];
+    }
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
     if (ADAM == 1 && STAGE == STAGE_FULL && a.row_filter != 0 && (a.row_filter == 1) == touched) continue;
 
@@ -415,6 +430,21 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 #pragma unroll
           for (int t = 0; t < VEC; ++t) { gm.v[t] = 0.f; gv.v[t] = 0.f; }
         }
+        if constexpr (LA) {
+          if (la_gap > 0) {            // (uniform over the lane group) bring the row up to the step before this one
+            float rm[VEC], rs[VEC];
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) { rm[t] = __builtin_amdgcn_sqrtf(vm[i].v[t]); rs[t] = __builtin_amdgcn_sqrtf(vs[i].v[t]); }
+            for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
+              const float2 c = b.step_tab[k];
+#pragma unroll
+              for (int t = 0; t < VEC; ++t) {
+                mu[i].v[t] = replay_one(mu[i].v[t], mm[i].v[t], rm[t], c, ad.eps);
+                s[i].v[t] = replay_one(s[i].v[t], ms[i].v[t], rs[t], c, ad.eps);
+              }
+            }
+          }
+        }
         if constexpr (ADAM) {
           Chunk<VEC> pm, ps;
 #pragma unroll
@@ -460,6 +490,17 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         g0 = gout * (gs + c * th.x);
         g1 = gout * dlink_f<LINK>(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
         if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(th.x, sg), klacc);
+      }
+      if constexpr (LA) {
+        if (la_gap > 0) {
+          const float r0 = __builtin_amdgcn_sqrtf(vb.x), r1 = __builtin_amdgcn_sqrtf(vb.y);
+          for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
+            const float2 c = b.step_tab[k];
+            th.x = replay_one(th.x, mb.x, r0, c, ad.eps);
+            th.y = replay_one(th.y, mb.y, r1, c, ad.eps);
+          }
+        }
+        b.last_step[e] = b.la_step;
       }
       if constexpr (ADAM) {
         float2 pn;

@@ -1,21 +1,7 @@
-"""Row-sharded data parallelism for the VFM step.
-
-Every batch is cut into contiguous row blocks, one per rank; both tables, `nb_occ` and the scalars
-are replicated.  Because the ELBO is a sum over rows (plus terms that only depend on the
-parameters), three exchanges reproduce the single-process step exactly:
-
-  1. once per batch (parameter-free, cached over epochs): SUM of the column normalisers W_f
-     -> `sum_normalisers`  (they sit inside a ratio n_g / W_g, so they must be global BEFORE the
-     KL term and its gradient are formed);
-  2. once per step: ONE all-reduce (SUM) of the flat fp32 buffer
-     [g_entity | g_bias | g_scalars | loss, nll, kl]  -> `allreduce_flat`.
-     Rank 0 alone adds the terms that do not depend on rows (KL of the global bias and its
-     gradient: VFM_FLAG_NO_PRIOR_TERMS on the other ranks), so the sum counts them once;
-  3. identical dense Adam on every rank keeps the replicas bit-identical (no broadcast needed).
-
-eps is keyed on (seed, step, entity id), so every rank draws the same sample for an entity.
-`backend="nccl"` is RCCL on ROCm (xGMI inside a node); the CPU tests use gloo.
-"""
+"""Row-sharded data parallelism helpers (the exchange itself is described in DESIGN.md section 6):
+contiguous row blocks per rank, SUM of the batch normalisers W_f once per batch, ONE all-reduce of the flat
+[gradients | loss] buffer per step, rank 0 alone adding the row-independent terms (VFM_FLAG_NO_PRIOR_TERMS elsewhere).
+`backend="nccl"` is RCCL on ROCm; the CPU tests use gloo."""
 from __future__ import annotations
 
 import torch

@@ -121,6 +121,14 @@ class VFM(nn.Module):
         self._lazy_last = None             # [T] int32: last Adam step applied to each row
         self._lazy_dirty = False           # some rows lag behind _adam_t
         self._lazy_lr = {}                 # {k: learning rate of the k-th step of the current moment period}
+        self._lazy_kind = None             # which step form let rows lag: "list" (lazy_adam) or "la" (look-ahead)
+        # Look-ahead form of the same idea for mid-range touch fractions (cfg3: 59 % of the rows per batch): when the
+        # caller names the next batch, the fused dense step skips the rows that are in neither batch -- (1-f)^2 of the
+        # table -- and rows of the next batch replay what they skipped inside that kernel (no separate pass).
+        self.lookahead = True
+        self.lookahead_min_skip = 0.05     # ... when at least this share of the rows would be skipped
+        self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
+        self._la_ready_for = None          # (plan, adam step): rows of that plan are current through that step
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
@@ -243,10 +251,16 @@ class VFM(nn.Module):
         return out
 
     # ------------------------------------------------------------------ checkpoint / resume
-    def training_state_dict(self):
+    def training_state_dict(self, sync: bool = True):
         """Everything needed to resume training bit-for-bit: parameters (state_dict), Adam moments and
-        step count, the Philox step counter, the epoch-averaged posterior means of save_weights()."""
+        step count, the Philox step counter, the epoch-averaged posterior means of save_weights().
+        After steps of a sharded multi-rank mode ("sharded", "dims") the full tables of a rank are stale and this
+        call is COLLECTIVE (it gathers them: every rank must call it).  For a rank-0-only checkpoint call
+        `sync_params(group)` on every rank first; `sync=False` raises instead of starting a hidden collective."""
         if getattr(self, "_stale_group", None) is not None:
+            if not sync:
+                raise RuntimeError("the tables of this rank are stale (sharded training mode): call sync_params(group) on "
+                                   "every rank before a checkpoint taken by one rank alone")
             self.sync_params(self._stale_group)       # (collective: every rank calls this together)
         self.sync_lazy()
         opt = None
@@ -271,6 +285,7 @@ class VFM(nn.Module):
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
             self._lazy_last, self._lazy_dirty, self._lazy_lr = None, False, {}
+            self._lazy_kind = self._la_ready_for = None
         if getattr(self, "_dims", None) is not None:
             self._dims.scatter(self)
         if state.get("snapshots") is not None:
@@ -409,15 +424,16 @@ class VFM(nn.Module):
             self.sync_params(self._stale_group, moments=False)
         self.sync_lazy()
 
-    def sync_lazy(self):
-        """Lazy Adam mode: replay the skipped updates of every row (all rows are then at step _adam_t, exactly where
-        dense Adam has them).  A no-op otherwise.  Called before anything reads the parameters."""
+    def sync_lazy(self, upto=None):
+        """Lazy Adam modes: replay the skipped updates of every row (all rows are then at step `upto` = _adam_t, exactly
+        where dense Adam has them).  A no-op otherwise.  Called before anything reads the parameters."""
         if self._lazy_dirty:
+            upto = self._adam_t if upto is None else upto
             ent, bia, _ = self._views(self._flat)
-            k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1
+            k = (upto - 1) % ops.MOMENT_PERIOD + 1 if upto > 0 else 0
             ops.adam_catchup(ent, bia, self._views(self._adam_m), self._views(self._adam_v), self._lazy_last, None,
-                             self._lazy_lrs(k), upto=self._adam_t, mark=self._adam_t)
-            self._lazy_dirty = False
+                             self._lazy_lrs(k), upto=upto, mark=upto)
+            self._lazy_dirty, self._lazy_kind, self._la_ready_for = False, None, None
 
     def _lazy_lrs(self, kmax):
         """Learning rates of steps 1..kmax of the current moment period (steps that were not fused steps are never
@@ -427,6 +443,11 @@ class VFM(nn.Module):
     def state_dict(self, *a, **k):
         self.sync_lazy()
         return super().state_dict(*a, **k)
+
+    def _lookahead_pays(self, plan, next_plan) -> bool:
+        if not self.lookahead:
+            return False
+        return (1.0 - plan.U / self.T) * (1.0 - next_plan.U / self.T) >= self.lookahead_min_skip
 
     def _use_lazy(self, plan) -> bool:
         if self.lazy_adam is True:
@@ -548,6 +569,7 @@ class VFM(nn.Module):
             fused = self.fuse_adam
         fused = fused and adam and process_group is None
         lazy = rows = None
+        la = False
         if fused:
             scaled = self.scaled_moments and not self.sparse_adam
             self._set_moment_form(scaled)
@@ -556,15 +578,23 @@ class VFM(nn.Module):
             if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
                     and out_pred is None and ops.pipeline_supported(plan.spec)):
                 ready = self._records_ready(plan, step)
-                if next_plan is not None and self.pipeline == "auto" and next_plan.B < self.pipeline_ratio * next_plan.U:
-                    next_plan = None          # too few rows per entity for the records to pay: do not prepare them
-                if ready or (next_plan is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
-                    return self._train_step_pipelined(plan, next_plan, lr, step, scaled, mark)
+                nxt = next_plan
+                if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
+                    nxt = None                # too few rows per entity for the records to pay: do not prepare them
+                if ready or (nxt is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
+                    return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark)
             k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1            # position of this step in its moment period
             if k == 1:
                 self._lazy_lr = {}
             self._lazy_lr[k] = float(lr)
-            if lazy or self._lazy_dirty:
+            # look-ahead form: visit only the rows of this batch and of the next (named by the caller)
+            la = (scaled and not lazy and k < ops.MOMENT_PERIOD and eps is None and self.n_samples == 1
+                  and next_plan is not None and next_plan.y is not None and next_plan.spec.T == self.T
+                  and self._lookahead_pays(plan, next_plan))
+            kind = "list" if lazy else ("la" if la else None)
+            if self._lazy_dirty and kind != self._lazy_kind:
+                self.sync_lazy(self._adam_t - 1)      # another step form than the one that let rows lag: all rows current first
+            if kind is not None:
                 if self._lazy_last is None:
                     self._lazy_last = torch.empty(self.T, dtype=torch.int32, device=self.device)
                 if not self._lazy_dirty:     # no row lags: every row is at the step before this one, however it got there
@@ -574,20 +604,40 @@ class VFM(nn.Module):
                     # rows of this batch: replay what they skipped, they get step _adam_t below; the others wait
                     ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
                                      upto=self._adam_t - 1, mark=self._adam_t)
-                    rows, self._lazy_dirty = "touched", True
+                    rows, self._lazy_dirty, self._lazy_kind = "touched", True, "list"
+                    mark("catchup")
+                elif la:
+                    if self._la_tab is None:
+                        self._la_tab = torch.zeros(2 * (ops.MOMENT_PERIOD + 1), dtype=torch.float32, device=self.device)
+                    ready = self._la_ready_for
+                    if self._lazy_dirty and not (ready is not None and ready[0] is plan and ready[1] == self._adam_t - 1):
+                        # this batch was not the one announced to the previous step: bring its rows up to date now
+                        ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
+                                         upto=self._adam_t - 1, mark=self._adam_t - 1)
+                        mark("catchup")
                 else:
-                    # last step of a moment period (the dense kernel rewrites every row's moments), or a dense step
-                    # after lazy ones: every row up to date first, then the ordinary dense step
+                    # last step of a moment period (the dense kernel rewrites every row's moments): every row up to
+                    # date first, then the ordinary dense step
                     ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, None, self._lazy_lrs(k - 1),
                                      upto=self._adam_t - 1, mark=self._adam_t)
                     self._lazy_dirty = False
-                mark("catchup")
+                    mark("catchup")
+            elif self._lazy_dirty:
+                self.sync_lazy(self._adam_t - 1)
         elif self._lazy_dirty:
             self.sync_lazy()
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
                               train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
         mark("fwd")
+        if fused and la:
+            # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
+            ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                             self._views(self._adam_v), lr, self._adam_t, loss3, self._lazy_last, self._la_tab)
+            self._lazy_dirty, self._lazy_kind = True, "la"
+            self._la_ready_for = (next_plan, self._adam_t)
+            mark("bwd_adam")
+            return loss3, st.pred
         if fused:
             # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),

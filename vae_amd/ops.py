@@ -98,6 +98,18 @@ def inv_occ_from_counts(nb_occ: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_WS = {}
+
+
+def _index_workspace(n_int32: int, dev) -> torch.Tensor:
+    """One scratch buffer per (device, stream) for vfm_build_index (stream-ordered reuse; grown on demand)."""
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < n_int32:
+        t = _WS[key] = torch.empty(n_int32, dtype=torch.int32, device=dev)
+    return t
+
+
 class BatchPlan:
     """Parameter-independent state of one batch (or one rank's row shard of it)."""
 
@@ -157,7 +169,7 @@ class BatchPlan:
         nbytes = int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T))
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
-        ws = torch.empty(nbytes // 4 + 4, dtype=torch.int32, device=dev)
+        ws = _index_workspace(nbytes // 4 + 4, dev)       # scratch of the build only: shared by all plans of a device
         occ_ptr = torch.empty(spec.T + 1, dtype=torch.int32, device=dev)
         occ_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
@@ -391,6 +403,29 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
         ptr(plan.W), ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
         ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), ptr(loss_out),
         current_stream_ptr(zrec.device)), "vfm_elbo_bwd_adam_pipe_f32")
+
+
+def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: BatchPlan, entity_params, bias_params,
+                                 scalars, inv_occ, m_views, v_views, lr, step, loss_out, last_step, step_tab,
+                                 beta1=0.9, beta2=0.999, eps_adam=1e-8):
+    """vfm_elbo_bwd_adam_lookahead_f32: the fused dense step visiting only the rows of this batch and of the next."""
+    t = plan.index_tensors()
+    ix = _lib.Index()
+    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
+    if len(t) == 5:
+        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
+        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+    if next_plan.occ_ptr is None:
+        next_plan.build_index()
+    p = st.problem
+    p.flags = plan.spec.link_flag | FLAG_SCALED_MOMENTS
+    check(_lib.load().vfm_elbo_bwd_adam_lookahead_f32(
+        C.byref(p), C.byref(ix), ptr(entity_params), ptr(bias_params), ptr(scalars), ptr(inv_occ), ptr(plan.W),
+        ptr(st.sumz), ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
+        ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), ptr(loss_out), ptr(last_step),
+        ptr(next_plan.occ_ptr), ptr(step_tab), current_stream_ptr(entity_params.device)),
+        "vfm_elbo_bwd_adam_lookahead_f32")
+    p.flags = plan.spec.link_flag
 
 
 def adam_catchup(entity_params, bias_params, m_views, v_views, last_step, ids, lr_of_step, upto, mark,
