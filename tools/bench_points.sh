@@ -4,7 +4,7 @@
 #   cfg2 (ML-100K shape) | cfg3 at B = 1,048,576 rows | cfg3 with Zipf(1.1) item popularity | cfg5 shape on one GPU
 #   (lazy exact Adam: auto) and the same with the dense step | the software-pipelined step on / off where "auto"
 #   decides either way | cfg3 forward A/B: k_fwd (every occurrence sampled), k_fwd2 with table eps, k_fwd2 with the
-#   RNG compiled out, rows not sorted
+#   RNG compiled out, rows not sorted | cfg3 without the look-ahead lazy Adam form (every row every step)
 # usage: tools/bench_points.sh r02
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -27,6 +27,7 @@ run cfg2_ml100k_d20_plain_step "" --workload ml100k_d20 --steps 300 --warmup 30 
 run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
 run cfg5_criteo_d256_lazy_auto "" --workload criteo_d256 --steps 200 --warmup 20
 run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --steps 40 --warmup 4
+run cfg3_lookahead_off "" --lookahead off --steps 200 --warmup 20 --no-regions
 run cfg3_fwd_ab_k_fwd "VFM_FWD_KERNEL=1" --steps 200 --warmup 20 --no-regions
 run cfg3_fwd_ab_k_fwd2 "" --steps 200 --warmup 20 --no-regions
 run cfg3_fwd_ab_k_fwd2_table_eps "" --fwd-eps table --steps 200 --warmup 20 --no-regions

@@ -17,6 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
+# gpurun merges every call's output into gpurun_out/: keep only the newest process' files of each pass
+for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq"):
+    files = glob.glob(os.path.join(src, sub, "**", "*_agent_info.csv"), recursive=True)
+    if len(files) > 1:
+        newest = max(files, key=os.path.getmtime)
+        keep = os.path.basename(newest).split("_")[0]
+        for f in glob.glob(os.path.join(os.path.dirname(newest), "*.csv")):
+            if not os.path.basename(f).startswith(keep + "_"):
+                os.remove(f)
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 rows = list(csv.reader(open(stats)))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
