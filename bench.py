@@ -479,7 +479,10 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
         dom = max(cand, key=lambda k: kern[k]["avg_us"])
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath) and args.workload == "ml20m_d128" and B == 100000 and not args.no_sort:
+        same_cmd = (args.workload == "ml20m_d128" and B == 100000 and not args.no_sort and world == 1 and not piped
+                    and look and not getattr(args, "zipf", None) and args.fwd_eps == "philox"
+                    and not os.environ.get("VFM_FWD_KERNEL") and not os.environ.get("VFM_FWD_AB_NORNG"))
+        if os.path.exists(tpath) and same_cmd:
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (counters cannot be read from inside the process; see profiles/README.md)
             tj = json.load(open(tpath))
