@@ -486,6 +486,10 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (counters cannot be read from inside the process; see profiles/README.md)
             tj = json.load(open(tpath))
+            from vae_amd.build import sources_digest
+            if tj.get("_csrc_sha1") not in (None, sources_digest()):
+                tj = {}          # the kernels changed since those passes: no figure rather than a stale one
+                traffic_src = "profiles/latest_traffic.json is older than vae_amd/csrc (re-run tools/profile_round.sh)"
             if dom in tj:
                 traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], "profiles/latest_traffic.json"
             for k in kern:

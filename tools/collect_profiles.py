@@ -50,6 +50,9 @@ traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_su
                       f"--warmup 10 --no-cpu-baseline --no-events` (tools/profile_round.sh {tag}); hbm_bytes = 2*FETCH_SIZE*1024 + "
                       "WRITE_SIZE*1024 (gfx950 FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md; Infinity-Cache hits are "
                       "included in the count)")
+sys.path.insert(0, ROOT)
+from vae_amd.build import sources_digest        # noqa: E402  (hash of csrc/: bench.py drops the figures when the kernels changed)
+traffic["_csrc_sha1"] = sources_digest()
 json.dump(traffic, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
 if len(sys.argv) > 2:
     shutil.copy(sys.argv[2], os.path.join(dst, f"{tag}_bench.json"))

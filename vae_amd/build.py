@@ -11,6 +11,21 @@ ROOT = os.path.dirname(HERE)
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def sources_digest() -> str:
+    """sha1 over the kernel sources (csrc/*.hip, *.hpp, *.cpp + include/vfm_hip.h), in name order: ties measured
+    figures (profiles/latest_traffic.json) to the code they were measured on."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp")))
+    files.append(os.path.join(os.path.dirname(here), "include", "vfm_hip.h"))
+    h = hashlib.sha1()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target, sources):
     if not os.path.exists(target):
         return True

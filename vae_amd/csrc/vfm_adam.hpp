@@ -65,39 +65,76 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
                                                         int64_t n, int d, int32_t pstart, int32_t upto, int32_t mark,
                                                         float eps, const CatchTab tab) {
   const int lane = threadIdx.x & 63;
+  // The period's step constants live in REGISTERS, two entries per lane (k = 1 + lane, 65 + lane); a replayed step
+  // fetches its pair with v_readlane (k is wave-uniform).  Indexing the by-value table with k inside the loop made
+  // every replayed step wait for a vector load from the kernarg segment (first version: 222 us at the Criteo shape).
+  const float4 c_lo = tab.c[1 + lane], c_hi = tab.c[(65 + lane) <= VFM_MOMENT_PERIOD ? 65 + lane : VFM_MOMENT_PERIOD];
+  const int a_lo = __float_as_int(c_lo.x), q_lo = __float_as_int(c_lo.y);
+  const int a_hi = __float_as_int(c_hi.x), q_hi = __float_as_int(c_hi.y);
+  auto consts = [&](int k) -> float4 {              // k in 1 .. VFM_MOMENT_PERIOD, wave-uniform
+    const int i = k - 1;
+    float4 c;
+    if (i < 64) {
+      c.x = __int_as_float(__builtin_amdgcn_readlane(a_lo, i)); c.y = __int_as_float(__builtin_amdgcn_readlane(q_lo, i));
+    } else {
+      c.x = __int_as_float(__builtin_amdgcn_readlane(a_hi, i - 64)); c.y = __int_as_float(__builtin_amdgcn_readlane(q_hi, i - 64));
+    }
+    c.z = 0.f; c.w = 0.f;
+    return c;
+  };
   const int64_t nw = (int64_t)gridDim.x * (BLOCK / 64);
   const int n4 = (2 * d) >> 2;                     // float4 pieces of an entity row (d % 2 == 0 checked on the host)
   for (int64_t i = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); i < n; i += nw) {
     const int64_t e = ids ? (int64_t)ids[i] : i;
-    int k0 = last_step[e] - pstart;
+    int k0 = __builtin_amdgcn_readfirstlane(last_step[e] - pstart);
     const int k1 = upto - pstart;
     if (k0 < 0) k0 = 0;                            // (never: a period boundary brings every row up to date)
     if (k1 > k0) {
       const size_t ro = (size_t)e * (2 * (size_t)d);
-      for (int j = lane; j < n4; j += 64) {
-        float4 p = reinterpret_cast<float4*>(entity + ro)[j];
-        const v4f m = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j);
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j);
-        const float rx = __builtin_amdgcn_sqrtf(v.x), ry = __builtin_amdgcn_sqrtf(v.y);
-        const float rz = __builtin_amdgcn_sqrtf(v.z), rw = __builtin_amdgcn_sqrtf(v.w);
-        for (int k = k0 + 1; k <= k1; ++k) {
-          const float4 c = tab.c[k];
-          p.x = catchup_one(p.x, m.x, rx, c, eps); p.y = catchup_one(p.y, m.y, ry, c, eps);
-          p.z = catchup_one(p.z, m.z, rz, c, eps); p.w = catchup_one(p.w, m.w, rw, c, eps);
-        }
-        reinterpret_cast<float4*>(entity + ro)[j] = p;
-      }
+      // bias pair of the row: lane 0, loaded before and replayed inside the first pass' step loop
+      float2 pb = make_float2(0.f, 0.f), mb = pb;
+      float rbx = 1.f, rby = 1.f;
       if (lane == 0) {
-        float2 p = *reinterpret_cast<float2*>(bias + 2 * (size_t)e);
-        const float2 m = *reinterpret_cast<const float2*>(m_bias + 2 * (size_t)e);
-        const float2 v = *reinterpret_cast<const float2*>(v_bias + 2 * (size_t)e);
-        const float rx = __builtin_amdgcn_sqrtf(v.x), ry = __builtin_amdgcn_sqrtf(v.y);
-        for (int k = k0 + 1; k <= k1; ++k) {
-          const float4 c = tab.c[k];
-          p.x = catchup_one(p.x, m.x, rx, c, eps); p.y = catchup_one(p.y, m.y, ry, c, eps);
-        }
-        *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = p;
+        pb = *reinterpret_cast<float2*>(bias + 2 * (size_t)e);
+        mb = *reinterpret_cast<const float2*>(m_bias + 2 * (size_t)e);
+        const float2 vb = *reinterpret_cast<const float2*>(v_bias + 2 * (size_t)e);
+        rbx = __builtin_amdgcn_sqrtf(vb.x); rby = __builtin_amdgcn_sqrtf(vb.y);
       }
+      // two float4 pieces per lane and pass: eight independent update chains under one fetch of the constants
+      for (int j0 = 0; j0 < n4; j0 += 128) {
+        const int j = j0 + lane;
+        const bool h0 = j < n4, h1 = j + 64 < n4;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
+        if (h0) {
+          p0 = reinterpret_cast<float4*>(entity + ro)[j];
+          m0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j);
+          v0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j);
+        }
+        if (h1) {
+          p1 = reinterpret_cast<float4*>(entity + ro)[j + 64];
+          m1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j + 64);
+          v1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j + 64);
+        }
+        const float r0x = __builtin_amdgcn_sqrtf(v0.x), r0y = __builtin_amdgcn_sqrtf(v0.y);
+        const float r0z = __builtin_amdgcn_sqrtf(v0.z), r0w = __builtin_amdgcn_sqrtf(v0.w);
+        const float r1x = __builtin_amdgcn_sqrtf(v1.x), r1y = __builtin_amdgcn_sqrtf(v1.y);
+        const float r1z = __builtin_amdgcn_sqrtf(v1.z), r1w = __builtin_amdgcn_sqrtf(v1.w);
+        const bool with_bias = j0 == 0;
+        for (int k = k0 + 1; k <= k1; ++k) {
+          const float4 c = consts(k);
+          p0.x = catchup_one(p0.x, m0.x, r0x, c, eps); p0.y = catchup_one(p0.y, m0.y, r0y, c, eps);
+          p0.z = catchup_one(p0.z, m0.z, r0z, c, eps); p0.w = catchup_one(p0.w, m0.w, r0w, c, eps);
+          p1.x = catchup_one(p1.x, m1.x, r1x, c, eps); p1.y = catchup_one(p1.y, m1.y, r1y, c, eps);
+          p1.z = catchup_one(p1.z, m1.z, r1z, c, eps); p1.w = catchup_one(p1.w, m1.w, r1w, c, eps);
+          if (with_bias) {                         // (uniform; lanes other than 0 carry zeros)
+            pb.x = catchup_one(pb.x, mb.x, rbx, c, eps); pb.y = catchup_one(pb.y, mb.y, rby, c, eps);
+          }
+        }
+        if (h0) reinterpret_cast<float4*>(entity + ro)[j] = p0;
+        if (h1) reinterpret_cast<float4*>(entity + ro)[j + 64] = p1;
+      }
+      if (lane == 0) *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = pb;
     }
     if (lane == 0) last_step[e] = mark;
   }

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   __shared__ float sh_cs_next[PIPE ? VFM_MAX_FIELDS : 1];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
   __shared__ double sh_fin[6][BLOCK / 64];
+  __shared__ float2 sh_tab[LA ? VFM_MOMENT_PERIOD + 1 : 1];      // LA: (a1, q2) of the period's earlier steps, for replays
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int d = a.d;
@@ -78,6 +79,9 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     sh_cs[tid] = a.W ? (float)(a.group_n[tid] / a.W[tid]) : 0.f;     // (W == NULL: untouched-rows launch)
     sh_hi[tid] = a.group_hi[tid];
     if constexpr (PIPE) sh_cs_next[tid] = b.zrec_next ? (float)(a.group_n[tid] / b.next_W[tid]) : 0.f;
+  }
+  if constexpr (LA) {
+    for (int k = tid; k < b.la_k; k += BLOCK) sh_tab[k] = b.step_tab[k];
   }
   __syncthreads();
   if constexpr (LA) {
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 #pragma unroll
             for (int t = 0; t < VEC; ++t) { rm[t] = __builtin_amdgcn_sqrtf(vm[i].v[t]); rs[t] = __builtin_amdgcn_sqrtf(vs[i].v[t]); }
             for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
-              const float2 c = b.step_tab[k];
+              const float2 c = sh_tab[k];
 #pragma unroll
               for (int t = 0; t < VEC; ++t) {
                 mu[i].v[t] = replay_one(mu[i].v[t], mm[i].v[t], rm[t], c, ad.eps);
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         if (la_gap > 0) {
           const float r0 = __builtin_amdgcn_sqrtf(vb.x), r1 = __builtin_amdgcn_sqrtf(vb.y);
           for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
-            const float2 c = b.step_tab[k];
+            const float2 c = sh_tab[k];
             th.x = replay_one(th.x, mb.x, r0, c, ad.eps);
             th.y = replay_one(th.y, mb.y, r1, c, ad.eps);
           }

@@ -240,6 +240,8 @@ class VFM(nn.Module):
         # ids on the old device and must be rebuilt by the caller)
         self.__dict__.pop("_view_cache", None)
         self._xflat = None
+        self._la_tab = self._la_ready_for = None          # (look-ahead step table: no row lags after sync_lazy above)
+        self._zrec = self._zrec_for = None                # (sample records of the pipelined step: re-made on demand)
         self._shard_acc = self._shard_small = self._shard_klws = None
         if getattr(self, "_state_bufs", None) is not None:
             self._state_bufs = {}
