@@ -21,7 +21,7 @@ def _setup(lazy, n_samples=1, F=3, d=16, T_sizes=(900, 700, 400), B=48, nb=12):
     return m, plans, X
 
 
-@pytest.mark.parametrize("F,d", [(3, 16), (2, 128)])
+@pytest.mark.parametrize("F,d", [(3, 16), (2, 128), (2, 5)])
 def test_lazy_adam_is_bitwise_the_dense_trajectory(F, d):
     dense, plans_d, X = _setup(False, F=F, d=d)
     lazy, plans_l, _ = _setup(True, F=F, d=d)
@@ -88,7 +88,7 @@ def test_catchup_argument_checks():
     assert lib.vfm_adam_catchup_f32(None, None, None, None, None, None, None, None, 0, 10, 8, lr, 0.9, 0.999, 1e-8, 1, 1, None) == -1
 
 
-@pytest.mark.parametrize("B,F,d", [(48, 3, 16), (700, 2, 128)])
+@pytest.mark.parametrize("B,F,d", [(48, 3, 16), (700, 2, 128), (48, 2, 5)])
 def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d):
     """The look-ahead form (train_step(plan, next_plan=...): the fused step visits only the rows of this batch and of
     the next) against the dense fused step: bitwise over 300 steps with changing learning rates, an un-announced

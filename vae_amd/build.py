@@ -35,11 +35,15 @@ def _stale(target, sources):
 
 # translation units of libvfm_hip.so: (source, object suffix, extra flags).  The row kernels are
 # compiled once per link function (vfm-torch.py:125-126: |.| and softplus).
-_UNITS = [("vfm_abi.hip", "", []), ("vfm_index.hip", "", []), ("vfm_variants.hip", "", []),
+# -ffp-contract=on (a*b+c fuses only inside one source expression) for the units holding the update arithmetic: under
+# hipcc's default ("fast": fusion across statements, decided after inlining) two template instances of k_bwd rounded
+# the same source differently in the last bit, and the lazy / look-ahead step forms are specified as BITWISE the dense one.
+_EXACT = ["-ffp-contract=" + os.environ.get("VFM_FP_CONTRACT", "on")]      # (the variable: A/B builds only)
+_UNITS = [("vfm_abi.hip", "", _EXACT), ("vfm_index.hip", "", []), ("vfm_variants.hip", "", []),
           ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2m.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2m.hip", "_softplus", ["-DVFM_LINK=1"]),
-          ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"])]
+          ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"] + _EXACT), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"] + _EXACT)]
 
 
 def build_hip_library(force=False, verbose=False):
@@ -49,7 +53,7 @@ def build_hip_library(force=False, verbose=False):
     hdr = os.path.join(ROOT, "include", "vfm_hip.h")
     parts = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hpp", ".hip"))]
     out = os.path.join(HERE, "libvfm_hip.so")
-    if not force and not _stale(out, [hdr] + parts):
+    if not force and not _stale(out, [hdr, os.path.abspath(__file__)] + parts):      # (this file holds the compile flags)
         return out
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -654,7 +654,6 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
   if (!entity_params || !bias_params || !m_entity || !v_entity || !m_bias || !v_bias || !last_step || n < 0 || T < 1 ||
       d < 1 || upto < 0 || mark < upto || mark > 0x7FFFFFFFLL || (ids == nullptr && n != T))
     return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: bad argument (ids == NULL means all T rows: n == T)");
-  if (d & 1) return fail(VFM_E_UNSUPPORTED, "vfm_adam_catchup_f32: odd embedding size");
   if (n == 0 || upto == 0) {          // nothing to replay (before the first step); still stamp the rows
     if (n == 0) return 0;
   }
@@ -675,9 +674,14 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
   }
   int64_t nb = (n + BLOCK / 64 - 1) / (BLOCK / 64);
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(k_adam_catchup, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
-                     m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
-                     (int32_t)mark, eps_adam, tab);
+  if ((d & 1) == 0)
+    hipLaunchKernelGGL(k_adam_catchup<4>, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
+                       m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
+                       (int32_t)mark, eps_adam, tab);
+  else
+    hipLaunchKernelGGL(k_adam_catchup<1>, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
+                       m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
+                       (int32_t)mark, eps_adam, tab);
   return after_launch("vfm_adam_catchup_f32");
 }
 

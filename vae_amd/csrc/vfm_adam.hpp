@@ -58,6 +58,7 @@ __device__ __forceinline__ float catchup_one(float p, float m, float r, const fl
   return fmaf(-c.x * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
+template <int VEC>        // 4: rows of 2d floats are 16-byte aligned (d even); 1: any d
 __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ entity, float* __restrict__ bias,
                                                         const float* __restrict__ m_entity, const float* __restrict__ v_entity,
                                                         const float* __restrict__ m_bias, const float* __restrict__ v_bias,
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
     return c;
   };
   const int64_t nw = (int64_t)gridDim.x * (BLOCK / 64);
-  const int n4 = (2 * d) >> 2;                     // float4 pieces of an entity row (d % 2 == 0 checked on the host)
+  const int np = (2 * d) / VEC;                    // pieces of an entity row
   for (int64_t i = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); i < n; i += nw) {
     const int64_t e = ids ? (int64_t)ids[i] : i;
     int k0 = __builtin_amdgcn_readfirstlane(last_step[e] - pstart);
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
     if (k0 < 0) k0 = 0;                            // (never: a period boundary brings every row up to date)
     if (k1 > k0) {
       const size_t ro = (size_t)e * (2 * (size_t)d);
-      // bias pair of the row: lane 0, loaded before and replayed inside the first pass' step loop
+      // bias pair of the row: lane 0, loaded first and replayed inside the first pass' step loop
       float2 pb = make_float2(0.f, 0.f), mb = pb;
       float rbx = 1.f, rby = 1.f;
       if (lane == 0) {
@@ -100,39 +101,39 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
         const float2 vb = *reinterpret_cast<const float2*>(v_bias + 2 * (size_t)e);
         rbx = __builtin_amdgcn_sqrtf(vb.x); rby = __builtin_amdgcn_sqrtf(vb.y);
       }
-      // two float4 pieces per lane and pass: eight independent update chains under one fetch of the constants
-      for (int j0 = 0; j0 < n4; j0 += 128) {
+      // two pieces per lane and pass: 2 VEC independent update chains under one fetch of the constants
+      for (int j0 = 0; j0 < np; j0 += 128) {
         const int j = j0 + lane;
-        const bool h0 = j < n4, h1 = j + 64 < n4;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-        v4f m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, v0 = {1.f, 1.f, 1.f, 1.f}, v1 = v0;
+        const bool h0 = j < np, h1 = j + 64 < np;
+        Chunk<VEC> p0, p1, m0, m1, r0, r1;
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) { p0.v[t] = p1.v[t] = m0.v[t] = m1.v[t] = 0.f; r0.v[t] = r1.v[t] = 1.f; }
         if (h0) {
-          p0 = reinterpret_cast<float4*>(entity + ro)[j];
-          m0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j);
-          v0 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j);
+          p0 = ld_chunk<VEC>(entity + ro + (size_t)j * VEC);
+          m0 = ld_chunk_nt<VEC>(m_entity + ro + (size_t)j * VEC);
+          r0 = ld_chunk_nt<VEC>(v_entity + ro + (size_t)j * VEC);
         }
         if (h1) {
-          p1 = reinterpret_cast<float4*>(entity + ro)[j + 64];
-          m1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m_entity + ro) + j + 64);
-          v1 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v_entity + ro) + j + 64);
+          p1 = ld_chunk<VEC>(entity + ro + (size_t)(j + 64) * VEC);
+          m1 = ld_chunk_nt<VEC>(m_entity + ro + (size_t)(j + 64) * VEC);
+          r1 = ld_chunk_nt<VEC>(v_entity + ro + (size_t)(j + 64) * VEC);
         }
-        const float r0x = __builtin_amdgcn_sqrtf(v0.x), r0y = __builtin_amdgcn_sqrtf(v0.y);
-        const float r0z = __builtin_amdgcn_sqrtf(v0.z), r0w = __builtin_amdgcn_sqrtf(v0.w);
-        const float r1x = __builtin_amdgcn_sqrtf(v1.x), r1y = __builtin_amdgcn_sqrtf(v1.y);
-        const float r1z = __builtin_amdgcn_sqrtf(v1.z), r1w = __builtin_amdgcn_sqrtf(v1.w);
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) { r0.v[t] = __builtin_amdgcn_sqrtf(r0.v[t]); r1.v[t] = __builtin_amdgcn_sqrtf(r1.v[t]); }
         const bool with_bias = j0 == 0;
         for (int k = k0 + 1; k <= k1; ++k) {
           const float4 c = consts(k);
-          p0.x = catchup_one(p0.x, m0.x, r0x, c, eps); p0.y = catchup_one(p0.y, m0.y, r0y, c, eps);
-          p0.z = catchup_one(p0.z, m0.z, r0z, c, eps); p0.w = catchup_one(p0.w, m0.w, r0w, c, eps);
-          p1.x = catchup_one(p1.x, m1.x, r1x, c, eps); p1.y = catchup_one(p1.y, m1.y, r1y, c, eps);
-          p1.z = catchup_one(p1.z, m1.z, r1z, c, eps); p1.w = catchup_one(p1.w, m1.w, r1w, c, eps);
+#pragma unroll
+          for (int t = 0; t < VEC; ++t) {
+            p0.v[t] = catchup_one(p0.v[t], m0.v[t], r0.v[t], c, eps);
+            p1.v[t] = catchup_one(p1.v[t], m1.v[t], r1.v[t], c, eps);
+          }
           if (with_bias) {                         // (uniform; lanes other than 0 carry zeros)
             pb.x = catchup_one(pb.x, mb.x, rbx, c, eps); pb.y = catchup_one(pb.y, mb.y, rby, c, eps);
           }
         }
-        if (h0) reinterpret_cast<float4*>(entity + ro)[j] = p0;
-        if (h1) reinterpret_cast<float4*>(entity + ro)[j + 64] = p1;
+        if (h0) st_chunk<VEC>(entity + ro + (size_t)j * VEC, p0);
+        if (h1) st_chunk<VEC>(entity + ro + (size_t)(j + 64) * VEC, p1);
       }
       if (lane == 0) *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = pb;
     }
