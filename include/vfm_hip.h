@@ -160,11 +160,13 @@ typedef struct vfm_problem {
  * longer than VFM_HEAVY_MIN) are also listed in `heavy_ids` (sorted) and their lists cut in work items
  * `heavy_items` [n_items,4] = (slot in heavy_ids, begin, end, 0) of at most that many occurrences, in list
  * order (vfm_build_index makes all of this).  Every backward call first reduces the work items (one lane
- * group each, plain stores) and then adds each entity's items in order -- no atomics, a fixed summation order --
+ * group each, plain stores) and then adds each entity's items in a fixed order (entities of more than
+ * VFM_HEAVY_DIRECT items: a kernel of their own; the others: inside the main kernel) -- no atomics --
  * in the scratch table `heavy_acc` [n_samples, n_heavy + n_items, 4 + round4(d)] (overwritten per call).
  * n_heavy == 0: all three may be NULL. */
 #define VFM_HEAVY_LIST 64
 #define VFM_HEAVY_MIN 8
+#define VFM_HEAVY_DIRECT 8      /* an entity of at most this many work items is summed by the main kernel itself */
 typedef struct vfm_index {
   const int32_t* occ_ptr;
   const int32_t* occ_rows;

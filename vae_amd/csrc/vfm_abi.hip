@@ -180,7 +180,7 @@ int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow,
   int64_t nb = ((int64_t)idx->n_items + GPB - 1) / GPB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
-                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec);
+                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec, hacc);
   nb = idx->n_heavy;                                             // one workgroup per heavy entity
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy_sum<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,

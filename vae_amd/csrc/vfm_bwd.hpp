@@ -242,13 +242,30 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
       gs = 0.f;
       int o = beg;
-      if (hslot >= 0) {      // pre-reduced by k_heavy: read the record, skip the walk
+      if (hslot >= 0) {      // pre-reduced by k_heavy: read the record(s), skip the walk
         const float* rec = hacc + (size_t)hslot * xs;
-        gs = rec[0];
+        const int4 hd = *reinterpret_cast<const int4*>(rec);      // (sum grow, count, first item, last item + 1)
+        if (hd.w - hd.z <= VFM_HEAVY_DIRECT) {      // few work items: add their records here, in item order
+          for (int it = hd.z; it < hd.w; ++it) {
+            const float* ir = hacc + ((size_t)b.n_heavy + (size_t)it) * xs;
+            gs += ir[0];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-          const int j = lig + i * LPE;
-          if (j < C) A[i] = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);
+            for (int i = 0; i < CPL; ++i) {
+              const int j = lig + i * LPE;
+              if (j < C) {
+                const Chunk<VEC> t4 = ld_chunk<VEC>(ir + 4 + (size_t)j * VEC);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) A[i].v[t] += t4.v[t];
+              }
+            }
+          }
+        } else {                                    // k_heavy_sum added them into the entity's record
+          gs = __int_as_float(hd.x);
+#pragma unroll
+          for (int i = 0; i < CPL; ++i) {
+            const int j = lig + i * LPE;
+            if (j < C) A[i] = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);
+          }
         }
         o = end;
       }

@@ -6,17 +6,20 @@
 // entity of an ML-100K-shape table sits in ~60 rows of a batch): a list longer than the index's heavy-list
 // length is cut in work items of at most that length (built with the index, vfm_index.hip).  k_heavy walks
 // every work item with its own lane group and STORES the partial record (sum grow, count, 0, 0 | A) of the
-// item; k_heavy_sum then adds the items of each heavy entity IN ITEM ORDER into the entity's record, which
-// the main kernel reads instead of walking the list.  No atomics: the sums have a fixed order, so the step
-// stays bitwise reproducible on skewed data too.  Without the split one lane group serialises the whole
-// list (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
+// item, and into the header of the entity's record the range [first, last) of its items (words 2, 3, as integers).
+// An entity of at most VFM_HEAVY_DIRECT items is finished by the main kernel itself (k_bwd adds the item records
+// in item order); for the others k_heavy_sum adds the items IN A FIXED ORDER into the entity's record, which the
+// main kernel reads instead of walking the list.  No atomics: the sums have a fixed order, so the step stays
+// bitwise reproducible on skewed data too.  Without the split one lane group serialises the whole list
+// (Zipf(1.1) items: 3.1 ms instead of 0.2 ms).
 // Layout of the scratch table per sample: [n_heavy entity records | n_items item records].
 template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ items, int n_items,
                                                  const int32_t* __restrict__ occ_rows,
                                                  const float* __restrict__ sumz, const float* __restrict__ grow,
                                                  float* __restrict__ item_acc, int d,
-                                                 const int32_t* __restrict__ occ_other, const float* __restrict__ zrec) {
+                                                 const int32_t* __restrict__ occ_other, const float* __restrict__ zrec,
+                                                 float* __restrict__ heavy_acc) {
   constexpr int GPB = BLOCK / LPE;
   const int lig = threadIdx.x % LPE;
   const int C = (d + VEC - 1) / VEC;
@@ -55,7 +58,11 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
         }
       }
     }
-    (void)slot;
+    if (lig == 0) {                // the entity's item range, for whoever adds the items up
+      int* hdr = reinterpret_cast<int*>(heavy_acc + (size_t)slot * xs);
+      if (it == 0 || items[4 * (it - 1)] != slot) hdr[2] = it;
+      if (it + 1 == n_items || items[4 * (it + 1)] != slot) hdr[3] = it + 1;
+    }
     float* rec = item_acc + (size_t)it * xs;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -73,26 +80,16 @@ template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__ items, int n_items, int n_heavy,
                                                      const float* __restrict__ item_acc,
                                                      float* __restrict__ heavy_acc, int d) {
+  (void)items; (void)n_items;
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh[BLOCK * CPL * VEC + 2 * GPB];
   const int lig = threadIdx.x % LPE, grp = threadIdx.x / LPE;
   const int C = (d + VEC - 1) / VEC;
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
   for (int slot = blockIdx.x; slot < n_heavy; slot += gridDim.x) {
-    int lo = 0, hi = n_items;                 // first item of this slot
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (items[4 * mid] < slot) lo = mid + 1; else hi = mid;
-    }
-    int end = lo;                             // one past its last item
-    {
-      int l2 = lo, h2 = n_items;
-      while (l2 < h2) {
-        const int mid = (l2 + h2) >> 1;
-        if (items[4 * mid] <= slot) l2 = mid + 1; else h2 = mid;
-      }
-      end = l2;
-    }
+    const int* hdr = reinterpret_cast<const int*>(heavy_acc + (size_t)slot * xs);
+    const int lo = hdr[2], end = hdr[3];      // the slot's work items (written by k_heavy)
+    if (end - lo <= VFM_HEAVY_DIRECT) continue;      // (uniform) few items: the main kernel adds them itself
     Chunk<VEC> A[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__
       if (lig == 0) {
         float tg = 0.f, tc = 0.f;
         for (int g2 = 0; g2 < GPB; ++g2) { tg += sh[BLOCK * CPL * VEC + 2 * g2]; tc += sh[BLOCK * CPL * VEC + 2 * g2 + 1]; }
-        *reinterpret_cast<float4*>(out) = make_float4(tg, tc, 0.f, 0.f);
+        *reinterpret_cast<float2*>(out) = make_float2(tg, tc);      // (words 2, 3 keep the item range)
       }
     }
   }
