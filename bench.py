@@ -298,13 +298,13 @@ def main():
     t0 = time.perf_counter()
     run(args.steps, not args.no_events)
     t_host = time.perf_counter() - t0          # host time to enqueue all steps (before the sync)
+    lazy_kind = model._lazy_kind               # which lazy exact form the timed steps ran in (None: every row every step)
+    model.sync_lazy()                          # rows still lagging get their skipped updates INSIDE the timed region
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     loss = float(model._gflat[model._n_flat].item())
     if world > 1 and model.exchange in ("sharded", "dims"):
         model.sync_params(pg)
-    lazy_kind = model._lazy_kind          # which lazy exact form the timed steps ran in (None: every row every step)
-    model.sync_lazy()
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
