@@ -440,8 +440,9 @@ int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float be
                             void* stream);
 
 /* ELBO variants of the reference's sibling scripts, as one general (any F, d <= 1024, single rank, |.| link,
- * one sample) forward / backward pair -- same access pattern as the fused kernels, a different epilogue; not
- * tuned (csrc/vfm_variants.hip):
+ * one sample) forward / backward pair -- same access pattern as the fused kernels, a different epilogue
+ * (csrc/vfm_variants8.hpp for d % 8 == 0: lane groups, 8 coordinates per lane and Philox call, pipelined gathers;
+ * csrc/vfm_variants.hip: the scalar pair for every other d):
  *   objective VFM_OBJ_SAMPLED      the sampled ELBO of vfm-torch.py:189-324,359
  *             VFM_OBJ_CLOSED_FORM  the closed-form expected log-likelihood of vfm-tomasrch.py:369-451 (no
  *                                  sampling; Normal likelihood): per row 1/2 log|alpha| - |alpha|/2 ((y - y_bar)^2 + T_n)
@@ -454,8 +455,9 @@ int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float be
  *   form) and grow [B] for the backward, partials workspace as vfm_elbo_fwd_f32; with `loss` (3 floats) also the
  *   loss triple (loss, likelihood term, KL term incl. the global bias' KL to ITS prior).  y == NULL: prediction only.
  * vfm_variant_bwd_f32: dense gradients of both tables, the three scalars and (with priors) the priors;
- *   occ_pos_ws = B*F int32 of scratch.  Prior gradients are summed with float atomics (order-dependent in
- *   the last bits). */
+ *   occ_pos_ws = vfm_variant_workspace_elems(B, F, d) 4-byte elements of scratch (16-byte aligned).  Prior
+ *   gradients: d % 8 == 0: per-workgroup partial rows added in a fixed order (reproducible); other d: float
+ *   atomics (order-dependent in the last bits). */
 #define VFM_OBJ_SAMPLED 0
 #define VFM_OBJ_CLOSED_FORM 1
 int vfm_variant_fwd_f32(const vfm_problem_t* p, int32_t objective, const void* x, const float* values, const float* y,
@@ -463,6 +465,7 @@ int vfm_variant_fwd_f32(const vfm_problem_t* p, int32_t objective, const void* x
                         const float* scalars, const double* W, const float* priors, const float* eps_entity,
                         const float* eps_bias, const float* eps_global, float* pred, double* partials, float* state,
                         float* grow, float* loss, void* stream);
+int64_t vfm_variant_workspace_elems(int64_t B, int32_t F, int32_t d);
 int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_index_t* idx, int32_t* occ_pos_ws,
                         const void* x, const float* values, const float* entity_params, const float* bias_params,
                         const float* inv_occ, const float* scalars, const double* W, const float* priors,

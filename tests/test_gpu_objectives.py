@@ -66,17 +66,20 @@ def _random_problem(g, F, d, B, output):
     return sizes, T, x, y, nb_occ, P, hi, gn, spec
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_variants_vs_oracle(seed):
-    """values != 1, learnable priors and both objectives in random combinations (F in 1..5, odd d, both
-    likelihoods) against oracle.variant_elbo (fp64 autograd): loss, predictions, every gradient."""
+    """values != 1, learnable priors and both objectives in random combinations (F in 1..5, both likelihoods)
+    against oracle.variant_elbo (fp64 autograd): loss, predictions, every gradient.  Seeds 0-5 draw embedding sizes
+    that go through the scalar kernels (d % 8 != 0), seeds 6-11 sizes of the lane-group kernels (d % 8 == 0: one
+    partly filled and one two-block-per-lane shape among them)."""
     from oracle import vfm_oracle as O
     from vae_amd import ops
     from vae_amd.variants import variant_forward, variant_backward, priors_len
     dev = torch.device("cuda:0")
     g = np.random.default_rng(100 + seed)
     for _ in range(4):
-        F, d, B = int(g.choice([1, 2, 3, 5])), int(g.choice([5, 20, 70, 130])), int(g.choice([1, 33, 500]))
+        F, B = int(g.choice([1, 2, 3, 5])), int(g.choice([1, 33, 500]))
+        d = int(g.choice([5, 20, 70, 130] if seed < 6 else [8, 16, 64, 136, 520]))
         objective = str(g.choice(["sampled", "closed_form"]))
         output = "reg" if objective == "closed_form" else str(g.choice(["reg", "class"]))
         sizes, T, x, y, nb_occ, P, hi, gn, spec = _random_problem(g, F, d, B, output)
@@ -145,6 +148,57 @@ def test_general_kernels_agree_with_the_fused_ones():
     assert rel_err(g_bias.cpu().numpy(), c.expected("g_bias_params")) < 1e-4
     fs = ops.elbo_forward(plan, ent, bia, scal, inv_occ, eps=eps)
     assert rel_err(st["pred"].cpu().numpy(), fs.pred.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("objective,use_pri,use_val", [("closed_form", True, False), ("sampled", False, True),
+                                                       ("closed_form", True, True), ("sampled", True, False)])
+def test_lane_group_kernels_agree_with_the_scalar_ones(objective, use_pri, use_val, monkeypatch):
+    """d % 8 == 0: the kernels of csrc/vfm_variants8.hpp against the scalar pair of csrc/vfm_variants.hip
+    (VFM_VARIANT_SCALAR=1) on a skewed batch (long occurrence lists, three id groups); the prior gradients of the
+    lane-group kernels are reproducible bit for bit."""
+    from vae_amd import ops, _lib
+    from vae_amd.variants import variant_forward, variant_backward, priors_len
+    dev = torch.device("cuda:0")
+    g = np.random.default_rng(5)
+    sizes, d, B, F = [700, 90, 30], 32, 6000, 3
+    T = sum(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    x = np.stack([off[f] + np.minimum(g.zipf(1.3, B) - 1, sizes[f] - 1) for f in range(F)], 1)
+    y = g.integers(1, 6, B).astype(np.float32)
+    nb_occ = np.bincount(x.reshape(-1), minlength=T) + 1
+    hi = np.cumsum(sizes)
+    spec = ops.Spec(T=T, F=F, d=d, group_hi=tuple(int(v) for v in hi), group_n=tuple(float(v) for v in sizes),
+                    nb_train=7 * B, likelihood=_lib.LIK_NORMAL)
+    ent = torch.tensor((0.5 * g.standard_normal((T, 2 * d))).astype(np.float32), device=dev)
+    bia = torch.tensor((0.6 * g.standard_normal((T, 2))).astype(np.float32), device=dev)
+    scal = torch.tensor([0.8, 0.3, -0.7], dtype=torch.float32, device=dev)
+    inv_occ = ops.inv_occ_from_counts(torch.tensor(nb_occ, device=dev))
+    plan = ops.BatchPlan(spec, torch.tensor(x, device=dev), torch.tensor(y, device=dev), inv_occ)
+    pri = None
+    if use_pri:
+        pri = torch.tensor(np.concatenate([[0.2, -1.1], 0.3 * g.standard_normal(F), g.uniform(0.6, 1.5, F),
+                                           0.3 * g.standard_normal(F * d), g.uniform(0.6, 1.5, F * d) * g.choice([-1, 1], F * d)
+                                           ]).astype(np.float32), device=dev)
+        assert pri.numel() == priors_len(F, d)
+    vals = torch.tensor(g.uniform(0.3, 2.0, (B, F)).astype(np.float32), device=dev) if use_val else None
+    one = torch.ones(1, device=dev)
+
+    def run():
+        st = variant_forward(plan, objective, ent, bia, scal, inv_occ, priors=pri, values=vals, seed=3, step=9)
+        return st, variant_backward(plan, st, ent, bia, scal, inv_occ, one)
+
+    st8, g8 = run()
+    st8b, g8b = run()
+    monkeypatch.setenv("VFM_VARIANT_SCALAR", "1")
+    st1, g1 = run()
+    assert abs(st8["loss3"][0].item() - st1["loss3"][0].item()) <= 2e-6 * abs(st1["loss3"][0].item())
+    assert rel_err(st8["pred"].cpu().numpy(), st1["pred"].cpu().numpy()) < 1e-5
+    for a_, b_, name in zip(g8, g1, ("entity", "bias", "scalars", "priors")):
+        if a_ is not None:
+            assert rel_err(a_.cpu().numpy(), b_.cpu().numpy()) < 2e-5, name
+    for a_, b_ in zip(g8, g8b):
+        if a_ is not None:
+            assert torch.equal(a_, b_)
 
 
 def test_closed_form_fit_learns():

@@ -380,6 +380,56 @@ __global__ void k_positions(const int32_t* __restrict__ occ_ptr, const int32_t* 
   }
 }
 
+#include "vfm_variants8.hpp"
+
+// lane-group shape of the d % 8 == 0 kernels: LPE lanes x CPL blocks of 8 coordinates cover the row
+#define VFM_FOR_VAR_SHAPES(X) X(1, 1) X(2, 1) X(4, 1) X(8, 1) X(16, 1) X(32, 1) X(64, 1) X(64, 2)
+void var_shape(int d, int* lpe, int* cpl) {
+  const int D8 = d >> 3;
+  int l = 1;
+  while (l < D8 && l < 64) l <<= 1;
+  *lpe = l;
+  *cpl = (D8 + l - 1) / l;
+}
+
+template <int LPE, int CPL, bool CF, bool HASV>
+void launch_var_fwd8(const VarArgs& a, float* pred, double* partials, float* state, float* grow, hipStream_t st) {
+  constexpr int GPB = BLOCK / LPE;
+  int64_t nb = (a.B + GPB - 1) / GPB;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  if (a.priors)
+    hipLaunchKernelGGL((k_var_fwd8<LPE, CPL, CF, HASV, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, pred, partials, state, grow);
+  else
+    hipLaunchKernelGGL((k_var_fwd8<LPE, CPL, CF, HASV, false>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, pred, partials, state, grow);
+}
+
+template <int LPE, int CPL, bool CF, bool HASV>
+void launch_var_bwd8(const VarArgs& a, const vfm_index_t* idx, const int32_t* occ_pos, const float* state, const float* grow,
+                     const double* partials, const float* grad_out, float* g_entity, float* g_bias, float* g_scalars,
+                     float* g_priors, float* prows, hipStream_t st) {
+  constexpr int GPB = BLOCK / LPE;
+  int64_t nb = (a.T + GPB - 1) / GPB;
+  if (nb > VAR_BWD_BLOCKS) nb = VAR_BWD_BLOCKS;
+  if (a.priors) {
+    hipLaunchKernelGGL((k_var_bwd8<LPE, CPL, CF, HASV, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, idx->occ_ptr,
+                       idx->occ_rows, occ_pos, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows);
+    int64_t epb = (a.T + nb - 1) / nb;
+    epb = (epb + GPB - 1) / GPB * GPB;
+    hipLaunchKernelGGL(k_var_priors_sum, dim3((unsigned)a.G, (unsigned)((2 * a.d + 2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a,
+                       prows, epb, (int)nb, g_priors);
+  } else {
+    hipLaunchKernelGGL((k_var_bwd8<LPE, CPL, CF, HASV, false>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, idx->occ_ptr,
+                       idx->occ_rows, occ_pos, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows);
+  }
+}
+
+// the kernels of vfm_variants8.hpp serve d % 8 == 0 (env VFM_VARIANT_SCALAR=1 forces the scalar pair: A/B runs, tests)
+// and draw eps in the kernel; eps tables go through the scalar pair
+bool use_var8(const vfm_problem_t* p, const float* eps_entity) {
+  return (p->d & 7) == 0 && p->d <= 1024 && eps_entity == nullptr && env_int("VFM_VARIANT_SCALAR", 0) == 0;
+}
+
 int check_var(const vfm_problem_t* p, int objective) {
   if (!p) return fail(VFM_E_INVALID, "problem is NULL");
   if (p->B < 0 || p->T <= 0 || p->T > 0xFFFFFFFELL || p->F < 1 || p->F > VFM_MAX_FIELDS || p->d < 1 ||
@@ -435,10 +485,29 @@ int vfm_variant_fwd_f32(const vfm_problem_t* p, int32_t objective, const void* x
   int64_t nb = (p->B + BLOCK / 64 - 1) / (BLOCK / 64);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_var_fwd, dim3((unsigned)nb), dim3(BLOCK), 0, st, a, pred, partials, state, grow);
+  if (use_var8(p, eps_entity)) {
+    int lpe, cpl;
+    var_shape(p->d, &lpe, &cpl);
+    const bool cf = objective == VFM_OBJ_CLOSED_FORM, hv = values != nullptr;
+#define X(L_, C_)                                                                                         \
+    if (lpe == L_ && cpl == C_) {                                                                         \
+      if (cf && hv) launch_var_fwd8<L_, C_, true, true>(a, pred, partials, state, grow, st);              \
+      else if (cf) launch_var_fwd8<L_, C_, true, false>(a, pred, partials, state, grow, st);              \
+      else if (hv) launch_var_fwd8<L_, C_, false, true>(a, pred, partials, state, grow, st);              \
+      else launch_var_fwd8<L_, C_, false, false>(a, pred, partials, state, grow, st);                     \
+    }
+    VFM_FOR_VAR_SHAPES(X)
+#undef X
+  } else {
+    hipLaunchKernelGGL(k_var_fwd, dim3((unsigned)nb), dim3(BLOCK), 0, st, a, pred, partials, state, grow);
+  }
   if (train && loss) hipLaunchKernelGGL(k_var_finalize, dim3(1), dim3(BLOCK), 0, st, a, partials, loss);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "vfm_variant_fwd_f32");
+}
+
+int64_t vfm_variant_workspace_elems(int64_t B, int32_t F, int32_t d) {
+  return B * (int64_t)F + (int64_t)(VAR_BWD_BLOCKS + F) * (2 * (int64_t)d + 8);
 }
 
 int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_index_t* idx, int32_t* occ_pos_ws,
@@ -455,6 +524,34 @@ int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_ind
   VarArgs a = make_var(p, objective, x, values, nullptr, entity_params, bias_params, inv_occ, scalars, W, priors,
                        eps_entity, eps_bias, eps_global);
   hipStream_t st = (hipStream_t)stream;
+  if (use_var8(p, eps_entity)) {
+    // ws = [B*F positions (only used with values) | (VAR_BWD_BLOCKS + F) partial rows of the prior gradients]
+    float* prows = reinterpret_cast<float*>(occ_pos_ws + (size_t)p->B * p->F);
+    if (g_priors) {       // row headers = -1 (no group)
+      const hipError_t e = hipMemsetAsync(prows, 0xFF, sizeof(float) * (size_t)(VAR_BWD_BLOCKS + p->F) * (2 * (size_t)p->d + 8), st);
+      if (e != hipSuccess) return fail_hip(e, "vfm_variant_bwd_f32: memset");
+    }
+    if (values) {
+      int64_t nbp = (p->T + 255) / 256;
+      if (nbp > 4096) nbp = 4096;
+      hipLaunchKernelGGL(k_positions, dim3((unsigned)nbp), dim3(256), 0, st, idx->occ_ptr, idx->occ_rows, x,
+                         (int)(p->id_bits == 64), (int)p->F, p->T, occ_pos_ws);
+    }
+    int lpe, cpl;
+    var_shape(p->d, &lpe, &cpl);
+    const bool cf = objective == VFM_OBJ_CLOSED_FORM, hv = values != nullptr;
+#define X(L_, C_)                                                                                                        \
+    if (lpe == L_ && cpl == C_) {                                                                                        \
+      if (cf && hv) launch_var_bwd8<L_, C_, true, true>(a, idx, occ_pos_ws, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows, st);   \
+      else if (cf) launch_var_bwd8<L_, C_, true, false>(a, idx, occ_pos_ws, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows, st);   \
+      else if (hv) launch_var_bwd8<L_, C_, false, true>(a, idx, occ_pos_ws, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows, st);   \
+      else launch_var_bwd8<L_, C_, false, false>(a, idx, occ_pos_ws, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows, st);          \
+    }
+    VFM_FOR_VAR_SHAPES(X)
+#undef X
+    const hipError_t e8 = hipGetLastError();
+    return e8 == hipSuccess ? 0 : fail_hip(e8, "vfm_variant_bwd_f32");
+  }
   if (g_priors) {
     const hipError_t e = hipMemsetAsync(g_priors, 0, sizeof(float) * (size_t)(2 + 2 * p->F + 2 * (size_t)p->F * p->d), st);
     if (e != hipSuccess) return fail_hip(e, "vfm_variant_bwd_f32: memset");

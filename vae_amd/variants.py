@@ -76,7 +76,7 @@ def variant_backward(plan: ops.BatchPlan, st, entity_params, bias_params, scalar
     g_ent, g_bias = torch.empty_like(entity_params), torch.empty_like(bias_params)
     g_sc = torch.empty(3, dtype=torch.float32, device=dev)
     g_pr = torch.empty_like(st["priors"]) if st["priors"] is not None else None
-    ws = torch.empty(max(plan.B * spec.F, 1), dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_lib.load().vfm_variant_workspace_elems(plan.B, spec.F, spec.d)), dtype=torch.int32, device=dev)
     ix = _index_struct(plan)
     e = st["eps"] if st["eps"] is not None else (None, None, None)
     check(_lib.load().vfm_variant_bwd_f32(
@@ -194,7 +194,7 @@ class VFMClosedForm(nn.Module):
                 opt.zero_grad()
                 loss.backward()
                 opt.step()
-                tot += float(loss)
+                tot += float(loss.detach())
             hist.append(tot / len(plans))
             if verbose:
                 print(f"epoch {epoch}: elbo {hist[-1]:.4f}")
