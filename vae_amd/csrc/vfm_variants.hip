@@ -15,9 +15,10 @@
 //              1/2 sum_k [(sum_f v_f z_fk)^2 - sum_f v_f^2 z_fk^2]
 //
 // Same memory-access pattern as the fused kernels (row-parallel gather forward, entity-centric backward over
-// the inverted index, dense gradient rows), a different epilogue -- written for clarity, not tuned: one wave
-// per row / per entity, scalar loads, occurrence lists walked serially.  The hot path of the bench is
-// k_fwd2 / k_fwd / k_bwd; this file is the slow general form next to it.
+// the inverted index, dense gradient rows), a different epilogue.  Two implementations of the same arithmetic:
+// vfm_variants8.hpp (d % 8 == 0: lane groups, 8 coordinates per lane, pipelined gathers -- what runs at the
+// usual embedding sizes) and the scalar pair in this file (any d, eps tables; one wave per row / per entity,
+// scalar loads, occurrence lists walked serially; also the cross-check of the first: VFM_VARIANT_SCALAR=1).
 // gfx950 only, wave = 64.
 #include <math.h>
 #include <string.h>
@@ -416,8 +417,10 @@ void launch_var_bwd8(const VarArgs& a, const vfm_index_t* idx, const int32_t* oc
                        idx->occ_rows, occ_pos, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows);
     int64_t epb = (a.T + nb - 1) / nb;
     epb = (epb + GPB - 1) / GPB * GPB;
-    hipLaunchKernelGGL(k_var_priors_sum, dim3((unsigned)a.G, (unsigned)((2 * a.d + 2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, a,
-                       prows, epb, (int)nb, g_priors);
+    float* parts = prows + (size_t)(VAR_BWD_BLOCKS + a.G) * (2 * (size_t)a.d + 8);
+    const unsigned ky = (unsigned)((2 * a.d + 2 + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_var_priors_part, dim3((unsigned)a.G, ky, VAR_PSUM_CH), dim3(BLOCK), 0, st, a, prows, epb, (int)nb, parts);
+    hipLaunchKernelGGL(k_var_priors_sum, dim3((unsigned)a.G, ky), dim3(BLOCK), 0, st, a, parts, g_priors);
   } else {
     hipLaunchKernelGGL((k_var_bwd8<LPE, CPL, CF, HASV, false>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, idx->occ_ptr,
                        idx->occ_rows, occ_pos, state, grow, partials, grad_out, g_entity, g_bias, g_scalars, g_priors, prows);
@@ -507,7 +510,7 @@ int vfm_variant_fwd_f32(const vfm_problem_t* p, int32_t objective, const void* x
 }
 
 int64_t vfm_variant_workspace_elems(int64_t B, int32_t F, int32_t d) {
-  return B * (int64_t)F + (int64_t)(VAR_BWD_BLOCKS + F) * (2 * (int64_t)d + 8);
+  return B * (int64_t)F + (int64_t)(VAR_BWD_BLOCKS + F + (int64_t)F * VAR_PSUM_CH) * (2 * (int64_t)d + 8);
 }
 
 int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_index_t* idx, int32_t* occ_pos_ws,
@@ -525,7 +528,7 @@ int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_ind
                        eps_entity, eps_bias, eps_global);
   hipStream_t st = (hipStream_t)stream;
   if (use_var8(p, eps_entity)) {
-    // ws = [B*F positions (only used with values) | (VAR_BWD_BLOCKS + F) partial rows of the prior gradients]
+    // ws = [B*F positions (only used with values) | (VAR_BWD_BLOCKS + F) partial rows of the prior gradients | F * VAR_PSUM_CH chunk sums]
     float* prows = reinterpret_cast<float*>(occ_pos_ws + (size_t)p->B * p->F);
     if (g_priors) {       // row headers = -1 (no group)
       const hipError_t e = hipMemsetAsync(prows, 0xFF, sizeof(float) * (size_t)(VAR_BWD_BLOCKS + p->F) * (2 * (size_t)p->d + 8), st);

@@ -460,31 +460,48 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
   }
 }
 
-// g_priors[2 ..] = sum over the partial rows of each group, in row order.  The workgroups whose entity range meets
-// group g are consecutive, so are their rows (workgroup + g); one workgroup per (group, 256 outputs).
-__global__ __launch_bounds__(BLOCK) void k_var_priors_sum(const VarArgs a, const float* __restrict__ prows, int64_t epb,
-                                                          int nblk, float* __restrict__ g_priors) {
-  const int g = blockIdx.x, G = a.G, d = a.d;
+// g_priors[2 ..] = sum over the partial rows of each group, in a fixed order.  The workgroups whose entity range
+// meets group g are consecutive, so are their rows (workgroup + g).  Two launches: VAR_PSUM_CH chunks of the row range
+// each summed by its own workgroup (eight rows in flight), then the chunks (a single pass over ~10^3 rows with four
+// loads in flight took longer than the backward kernel itself).
+constexpr int VAR_PSUM_CH = 32;
+
+__global__ __launch_bounds__(BLOCK) void k_var_priors_part(const VarArgs a, const float* __restrict__ prows, int64_t epb,
+                                                           int nblk, float* __restrict__ parts) {
+  const int g = blockIdx.x, d = a.d, c = blockIdx.z;
   const size_t len = 4 + 2 * (size_t)d + 4;
-  const int64_t lo = g > 0 ? a.group_hi[g - 1] : 0;
-  int64_t hi = (g + 1 < G) ? a.group_hi[g] : a.T;
-  if (hi > a.T) hi = a.T;
-  float* gm = g_priors + 2 + 2 * G;
   const int k = blockIdx.y * BLOCK + threadIdx.x;
   if (k >= 2 * d + 2) return;
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  const int64_t lo = g > 0 ? a.group_hi[g - 1] : 0;
+  int64_t hi = (g + 1 < a.G) ? a.group_hi[g] : a.T;
+  if (hi > a.T) hi = a.T;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (hi > lo) {
-    int64_t b0 = lo / epb, b1 = (hi - 1) / epb;
+    const int64_t b0 = lo / epb;
+    int64_t b1 = (hi - 1) / epb;
     if (b1 > nblk - 1) b1 = nblk - 1;
-    int64_t b = b0;
-    for (; b + 3 <= b1; b += 4) {                 // four rows in flight, a fixed summation tree
-      const float* r0 = prows + (size_t)(b + g) * len;
-      const float x0 = r0[4 + k], x1 = r0[len + 4 + k], x2 = r0[2 * len + 4 + k], x3 = r0[3 * len + 4 + k];
-      t0 += x0; t1 += x1; t2 += x2; t3 += x3;
+    const int64_t per = (b1 - b0 + VAR_PSUM_CH) / VAR_PSUM_CH;          // rows per chunk
+    int64_t b = b0 + c * per;
+    int64_t be = b + per - 1 < b1 ? b + per - 1 : b1;
+    const float* base = prows + (size_t)g * len + 4 + k;
+    for (; b + 7 <= be; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] += base[(size_t)(b + u) * len];
     }
-    for (; b <= b1; ++b) t0 += prows[(size_t)(b + g) * len + 4 + k];
+    for (; b <= be; ++b) t[0] += base[(size_t)b * len];
   }
-  const float t = (t0 + t1) + (t2 + t3);
+  parts[((size_t)g * VAR_PSUM_CH + c) * (2 * (size_t)d + 2) + k] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_var_priors_sum(const VarArgs a, const float* __restrict__ parts,
+                                                          float* __restrict__ g_priors) {
+  const int g = blockIdx.x, G = a.G, d = a.d;
+  const int k = blockIdx.y * BLOCK + threadIdx.x;
+  if (k >= 2 * d + 2) return;
+  float t = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < VAR_PSUM_CH; ++c) t += parts[((size_t)g * VAR_PSUM_CH + c) * (2 * (size_t)d + 2) + k];
+  float* gm = g_priors + 2 + 2 * G;
   if (k < d) gm[(size_t)g * d + k] = t;
   else if (k < 2 * d) gm[(size_t)G * d + (size_t)g * d + (k - d)] = t;
   else if (k == 2 * d) g_priors[2 + g] = t;
