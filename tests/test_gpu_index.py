@@ -32,6 +32,8 @@ CASES = [  # (B, field sizes, zipf exponent or None, id dtype)
     (40000, [5, 4], None, torch.int64),             # 9 entities: every list is heavy, thousands of work items
     (2048, [31250] * 32, None, torch.int64),        # cfg5: F = 32, T = 10^6 (20-bit keys)
     (300, [2 ** 21 + 5, 9], None, torch.int64),     # 22-bit keys, nearly empty table
+    (300000, [138493, 26744], 1.05, torch.int32),   # 293 sort tiles: the per-digit scan kernel (more than 256 tiles)
+    (263000, [90, 26744], None, torch.int64),       # 257 tiles, one column with very long lists
 ]
 
 

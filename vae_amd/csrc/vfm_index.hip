@@ -12,8 +12,9 @@
 //   k_index_keys     ids -> uint32 keys (range-checked; out-of-range ids are counted and clamped to 0
 //                    like the forward does), values = positions r*F + f
 //   per pass:  k_radix_hist     per-tile digit histograms                  hist[digit][tile]
-//              k_radix_scan     exclusive scan over (digit-major, tile-minor) -> global base of each
-//                               (digit, tile)                               one workgroup
+//              k_radix_scan     per digit: exclusive scan of its row over the tiles + the digit's total (one
+//                               workgroup per digit); only with more than RS_FUSE_NB tiles -- below, every
+//                               scatter workgroup adds up the counts it needs itself
 //              k_radix_scatter  stable rank inside the tile (per-wave digit matching with ballots + a
 //                               scan over the tile's 32 sub-tiles in LDS) + base -> scatter
 //   k_index_finish   occ_rows[i] = position / F;  occ_ptr[e] = lower bound of e in the sorted keys
@@ -69,60 +70,44 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
   hist[(size_t)threadIdx.x * NB + blockIdx.x] = sh[threadIdx.x];
 }
 
-// exclusive prefix sum over hist[digit][tile] in (digit-major, tile-minor) order, in place.  One workgroup of
-// 1024 threads: 4 threads per digit, each owning a contiguous quarter of the tiles (a serial walk over a
-// [256 * NB] array by fewer threads is a 30 us latency chain at NB = 98).
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* __restrict__ hist, int NB) {
-  __shared__ uint32_t sh_dig[256];
-  constexpr int CH = 32;                         // tiles held in registers at a time: the loads go out together
-  const int tid = threadIdx.x, dg = tid >> 2, part = tid & 3;
-  const int per = (NB + 3) >> 2;
-  const int b0 = part * per, b1 = (b0 + per < NB) ? b0 + per : NB;
-  uint32_t* row = hist + (size_t)dg * NB;
-  uint32_t s = 0;
-  for (int c0 = b0; c0 < b1; c0 += CH) {
-    uint32_t v[CH];
+// Many tiles (NB > RS_FUSE_NB): one workgroup PER DIGIT scans its row hist[digit][0..NB) in place (exclusive) and
+// leaves the digit's total in tot[digit]; the scatter workgroups add the totals of the smaller digits themselves.
+// (A single workgroup scanning all 256 * NB counts took 383 us per pass at B = 1,048,576: 1.15 of the 1.3 ms build.)
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scan(uint32_t* __restrict__ hist, int NB, uint32_t* __restrict__ tot) {
+  __shared__ uint32_t sh_w[RS_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* row = hist + (size_t)blockIdx.x * NB;
+  uint32_t carry = 0;
+  for (int c0 = 0; c0 < NB; c0 += RS_THREADS * 4) {          // 4 consecutive tiles per thread and round
+    const int i0 = c0 + tid * 4;
+    uint32_t v[4], s = 0;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) v[i] = (c0 + i < b1) ? row[c0 + i] : 0u;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) s += v[i];
-  }
-  // the 4 parts of a digit sit in adjacent lanes: inclusive scan over the quad
-  uint32_t incl = s;
-  {
-    uint32_t t = __shfl_up(incl, 1, 64); if (part >= 1) incl += t;
-    t = __shfl_up(incl, 2, 64);          if (part >= 2) incl += t;
-  }
-  if (part == 3) sh_dig[dg] = incl;              // total of the digit
-  __syncthreads();
-  if (tid < 64) {                                // exclusive scan of the 256 digit totals: 4 per lane + wave scan
-    uint32_t v[4], tot = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = sh_dig[4 * tid + i]; tot += v[i]; }
-    uint32_t inc = tot;
+    for (int i = 0; i < 4; ++i) { v[i] = (i0 + i < NB) ? row[i0 + i] : 0u; s += v[i]; }
+    uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(inc, o, 64);
-      if (tid >= o) inc += t;
+      if (lane >= o) inc += t;
     }
-    uint32_t run = inc - tot;
+    if (lane == 63) sh_w[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sh_dig[4 * tid + i] = run; run += v[i]; }
+    for (int w = 0; w < RS_THREADS / 64; ++w) { const uint32_t t = sh_w[w]; if (w < wave) wbase += t; all += t; }
+    uint32_t run = carry + wbase + inc - s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i0 + i < NB) row[i0 + i] = run; run += v[i]; }
+    carry += all;
+    __syncthreads();
   }
-  __syncthreads();
-  uint32_t run = sh_dig[dg] + incl - s;
-  for (int c0 = b0; c0 < b1; c0 += CH) {
-    uint32_t v[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) v[i] = (c0 + i < b1) ? row[c0 + i] : 0u;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      if (c0 + i < b1) row[c0 + i] = run;
-      run += v[i];
-    }
-  }
+  if (tid == 0) tot[blockIdx.x] = carry;
 }
 
+// FUSED (few tiles: NB <= RS_FUSE_NB): `base` holds the RAW per-tile digit counts of k_radix_hist and every
+// workgroup forms its own offsets -- digit `tid`: the counts of the tiles before this one plus the totals of the
+// smaller digits -- instead of waiting for a one-workgroup scan kernel (26 us per pass at cfg3, most of it latency).
+constexpr int RS_FUSE_NB = 256;
+template <bool FUSED>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ kin,
                                                               const uint32_t* __restrict__ vin, int n, int shift,
                                                               const uint32_t* __restrict__ base, int NB,
@@ -155,8 +140,62 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
     if (valid && lower[k] == 0) sub[k * (RS_THREADS / 64) + wave][dg] = (uint32_t)__popcll(m);
   }
   __syncthreads();
+  uint32_t tile_base;
+  if constexpr (FUSED) {
+    __shared__ uint32_t sh_tot[256];
+    const uint32_t* row = base + (size_t)tid * NB;
+    uint32_t before = 0, total = 0;
+    const int me = blockIdx.x;
+    int t0 = 0;
+    for (; t0 + 8 <= NB; t0 += 8) {
+      uint32_t c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = row[t0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { total += c[u]; before += (t0 + u < me) ? c[u] : 0u; }
+    }
+    for (; t0 < NB; ++t0) { const uint32_t c = row[t0]; total += c; before += (t0 < me) ? c : 0u; }
+    sh_tot[tid] = total;
+    __syncthreads();
+    if (tid < 64) {                              // exclusive scan of the 256 digit totals: 4 per lane + wave scan
+      uint32_t v[4], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = sh_tot[4 * tid + i]; tot += v[i]; }
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += t;
+      }
+      uint32_t run = inc - tot;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sh_tot[4 * tid + i] = run; run += v[i]; }
+    }
+    __syncthreads();
+    tile_base = sh_tot[tid] + before;
+  } else {       // rows scanned by k_radix_scan, digit totals behind the histogram
+    __shared__ uint32_t sh_tot[256];
+    sh_tot[tid] = base[(size_t)256 * NB + tid];
+    __syncthreads();
+    if (tid < 64) {
+      uint32_t v[4], tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = sh_tot[4 * tid + i]; tot += v[i]; }
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += t;
+      }
+      uint32_t run = inc - tot;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sh_tot[4 * tid + i] = run; run += v[i]; }
+    }
+    __syncthreads();
+    tile_base = sh_tot[tid] + base[(size_t)tid * NB + blockIdx.x];
+  }
   {   // digit `tid`: global base of this tile, then the sub-tiles in order
-    uint32_t run = base[(size_t)tid * NB + blockIdx.x];
+    uint32_t run = tile_base;
 #pragma unroll 4
     for (int s = 0; s < RS_SUB; ++s) { const uint32_t c = sub[s][tid]; sub[s][tid] = run; run += c; }
   }
@@ -310,7 +349,7 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
   const int64_t NB = (n + RS_TILE - 1) / RS_TILE;
   const int64_t NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
   // 4 key / value buffers, the radix histogram, the heavy block counts, a few counters
-  return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 4) * 4 + (3 * NBH + 4) * 4 + 64;
+  return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 256) * 4 + (3 * NBH + 4) * 4 + 64;
 }
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
@@ -334,7 +373,7 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
   uint32_t* k1 = v0 + n4;
   uint32_t* v1 = k1 + n4;
   uint32_t* hist = v1 + n4;
-  uint32_t* blk = hist + (size_t)256 * NB + 4;
+  uint32_t* blk = hist + (size_t)256 * NB + 256;       // (256 digit totals behind the histogram)
   unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)3 * NBH + 4);
   hipError_t e = hipMemsetAsync(counters, 0, 16, st);
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index: memset");
@@ -346,8 +385,12 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
     const int passes = (key_bits(T) + 7) / 8;
     for (int p = 0; p < passes; ++p) {
       hipLaunchKernelGGL(k_radix_hist, dim3(NB), dim3(RS_THREADS), 0, st, k0, n, 8 * p, hist, NB);
-      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st, hist, NB);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
+      if (NB <= RS_FUSE_NB) {
+        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
+      } else {
+        hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(RS_THREADS), 0, st, hist, NB, hist + (size_t)256 * NB);
+        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
+      }
       uint32_t* t = k0; k0 = k1; k1 = t;
       t = v0; v0 = v1; v1 = t;
     }
