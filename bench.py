@@ -71,9 +71,10 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="the software-pipelined step (the backward of step n writes the sample records of batch n+1, the "
                          "forward gathers records: no sampling, no sumz); auto: from 2 rows per distinct entity")
-    ap.add_argument("--lookahead", default="on", choices=["on", "off"],
+    ap.add_argument("--lookahead", default="on", choices=["on", "scan", "off"],
                     help="look-ahead lazy exact Adam: the fused step skips the rows that are neither in this batch nor in "
-                         "the next (bitwise the dense trajectory); off = every row every step")
+                         "the next (bitwise the dense trajectory); scan = the kernel classifies all table rows itself instead "
+                         "of walking the pair's row list; off = every row every step")
     ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
     ap.add_argument("--lazy-adam", default="auto", choices=["auto", "on", "off"],
                     help="lazy exact dense Adam (rows outside the batch are skipped and replayed later, bitwise the dense "
@@ -130,7 +131,8 @@ def main():
     model.scaled_moments = not args.plain_moments
     model.lazy_adam = {"auto": "auto", "on": True, "off": False}[args.lazy_adam]
     model.pipeline = {"auto": "auto", "on": True, "off": False}[args.pipeline]
-    model.lookahead = args.lookahead == "on"
+    model.lookahead = args.lookahead != "off"
+    model.lookahead_list = args.lookahead == "on"
     # synthetic data resident on the device: this rank's rows of nbt global batches
     X, y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                              zipf=args.zipf if args.zipf > 0 else None)
@@ -183,6 +185,9 @@ def main():
         t0 = time.perf_counter()
         for xb, yb in batches:         # as fit() does: the index builds are enqueued back to back, their 16-byte
             ps.append(model.plan(xb, yb, B_global=B * world, process_group=pg, defer_readback=True))     # readbacks
+        if world == 1 and model.lookahead and getattr(model, "lookahead_list", False):
+            for i_, p_ in enumerate(ps):   # the look-ahead step's row lists (this batch + the next one), also per batch
+                p_.prepare_lookahead(ps[(i_ + 1) % len(ps)])
         for p_ in ps:                  # are collected afterwards
             p_.U
         torch.cuda.synchronize()

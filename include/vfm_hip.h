@@ -408,7 +408,15 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
  * trajectory.  Requirements: the rows of THIS batch are up to date through step-1 (they are if the previous step was a
  * look-ahead call naming this batch, or after vfm_adam_catchup_f32 on them); `last_step` as in vfm_adam_catchup_f32;
  * not for the last step of a moment period (step % VFM_MOMENT_PERIOD == 0: bring all rows up to date and run the dense
- * call).  Same arguments as vfm_elbo_bwd_adam_f32 otherwise (Philox eps). */
+ * call).  With idx->touched_ids / n_touched set to the list vfm_union_rows makes of the two batches, the kernel walks
+ * that list instead of classifying all T table rows (every lane group then has work in every iteration).  Same
+ * arguments as vfm_elbo_bwd_adam_f32 otherwise (Philox eps). */
+/* rows [count] = the sorted ids of the entities that occur in batch A or in batch B (their inverted indexes' occ_ptr
+ * arrays), count[0] (DEVICE int32) their number; ws = vfm_union_workspace_bytes(T) bytes of scratch.  Room for
+ * min(T, n_occ_A + n_occ_B) ids always suffices.  Launch-only, no atomics: two calls give the same list. */
+int64_t vfm_union_workspace_bytes(int64_t T);
+int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b, void* ws, int32_t* rows, int32_t* count,
+                   void* stream);
 int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                                     float* entity_params, float* bias_params, float* scalars,
                                     const float* inv_occ, const double* W,

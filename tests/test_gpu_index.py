@@ -96,3 +96,23 @@ def test_index_is_deterministic_and_plan_cost_is_one_readback():
     a, b = ops.BatchPlan(spec, X, y, inv_occ), ops.BatchPlan(spec, X, y, inv_occ)
     assert torch.equal(a.occ_ptr, b.occ_ptr) and torch.equal(a.occ_rows, b.occ_rows)
     assert torch.equal(a.heavy[0], b.heavy[0]) and torch.equal(a.heavy[1], b.heavy[1])
+
+
+def test_union_rows_of_two_batches():
+    """vfm_union_rows: the sorted entities of batch A or batch B (the rows of the look-ahead step), via BatchPlan."""
+    from vae_amd import ops
+    from vae_amd.data import synthetic_triples
+    dev = torch.device("cuda:0")
+    sizes = [5000, 300]
+    T = sum(sizes)
+    spec = ops.Spec(T=T, F=2, d=8, group_hi=(5001, T), group_n=(5000.0, 300.0), likelihood=0, nb_train=10 ** 5)
+    Xa, _ = synthetic_triples(sizes, 700, seed=1, device=dev)
+    Xb, _ = synthetic_triples(sizes, 1300, seed=2, device=dev)
+    pa, pb = ops.BatchPlan(spec, Xa, None, None), ops.BatchPlan(spec, Xb, None, None)
+    rows = pa.lookahead_rows(pb)
+    want = np.union1d(Xa.cpu().numpy().reshape(-1), Xb.cpu().numpy().reshape(-1))
+    assert rows.dtype == torch.int32 and np.array_equal(rows.cpu().numpy(), want)
+    assert pa.lookahead_rows(pb) is rows or torch.equal(pa.lookahead_rows(pb), rows)      # cached per pair
+    assert np.array_equal(pb.lookahead_rows(pa).cpu().numpy(), want)
+    empty = ops.BatchPlan(spec, Xa[:0], None, None)
+    assert np.array_equal(pa.lookahead_rows(empty).cpu().numpy(), np.unique(Xa.cpu().numpy().reshape(-1)))

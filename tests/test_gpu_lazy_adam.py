@@ -88,8 +88,9 @@ def test_catchup_argument_checks():
     assert lib.vfm_adam_catchup_f32(None, None, None, None, None, None, None, None, 0, 10, 8, lr, 0.9, 0.999, 1e-8, 1, 1, None) == -1
 
 
+@pytest.mark.parametrize("listed", [True, False])
 @pytest.mark.parametrize("B,F,d", [(48, 3, 16), (700, 2, 128), (48, 2, 5)])
-def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d):
+def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d, listed):
     """The look-ahead form (train_step(plan, next_plan=...): the fused step visits only the rows of this batch and of
     the next) against the dense fused step: bitwise over 300 steps with changing learning rates, an un-announced
     batch in between (its rows are caught up by the separate pass), predictions, and two moment-period boundaries."""
@@ -97,6 +98,7 @@ def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d):
     la, plans_l, _ = _setup(False, F=F, d=d, B=B)
     dense.lookahead = False
     dense.pipeline = la.pipeline = False
+    la.lookahead_list = listed                            # rows as a list per pair of plans / classified by the kernel
     n = len(plans_l)
     f = plans_l[0].U / la.T
     assert (1 - f) ** 2 >= la.lookahead_min_skip

@@ -32,7 +32,7 @@ EXPORTS = (
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
     "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
     "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
-    "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32",
+    "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32", "vfm_union_rows", "vfm_union_workspace_bytes",
     "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
 )
 
@@ -133,6 +133,9 @@ def load():
                                                     [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp, vp, vp, vp])
     lib.vfm_variant_fwd_f32.argtypes = [PP, i32] + [vp] * 18
     lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
+    lib.vfm_union_workspace_bytes.argtypes = [i64]
+    lib.vfm_union_workspace_bytes.restype = i64
+    lib.vfm_union_rows.argtypes = [i64] + [vp] * 6
     lib.vfm_variant_workspace_elems.argtypes = [i64, i32, i32]
     lib.vfm_variant_workspace_elems.restype = i64
     for name in EXPORTS:

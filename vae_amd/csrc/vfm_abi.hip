@@ -637,6 +637,10 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
             nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   b.last_step = last_step; b.next_occ_ptr = next_occ_ptr; b.step_tab = reinterpret_cast<float2*>(step_tab);
+  if (idx->touched_ids && idx->n_touched > 0) {      // the rows to visit, listed (vfm_union_rows): no scan over the table
+    if (idx->n_touched > p->T) return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: more listed rows than table rows");
+    b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
+  }
   b.la_step = (int32_t)step; b.la_k = (int32_t)((step - 1) % VFM_MOMENT_PERIOD + 1);
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);

@@ -322,6 +322,55 @@ __global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restr
   }
 }
 
+// ---- rows of the look-ahead step: the entities of batch A or of batch B, in id order (same three-kernel compaction) ----
+__device__ __forceinline__ bool in_either(const int32_t* a, const int32_t* b, int64_t e, int64_t T) {
+  return e < T && (a[e + 1] != a[e] || b[e + 1] != b[e]);
+}
+__global__ __launch_bounds__(HV_CHUNK) void k_union_count(const int32_t* __restrict__ occ_a, const int32_t* __restrict__ occ_b,
+                                                          int64_t T, uint32_t* __restrict__ blk) {
+  __shared__ uint32_t sh[HV_CHUNK / 64];
+  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + threadIdx.x;
+  const unsigned long long m = __ballot(in_either(occ_a, occ_b, e, T));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < HV_CHUNK / 64; ++w) t += sh[w];
+    blk[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(64) void k_union_scan(uint32_t* __restrict__ blk, int NBH, int32_t* __restrict__ count) {
+  const int lane = threadIdx.x;
+  uint32_t carry = 0;
+  for (int i0 = 0; i0 < NBH; i0 += 64) {
+    const int i = i0 + lane;
+    const uint32_t v = i < NBH ? blk[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (i < NBH) blk[i] = carry + inc - v;
+    carry += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) count[0] = (int32_t)carry;
+}
+__global__ __launch_bounds__(HV_CHUNK) void k_union_write(const int32_t* __restrict__ occ_a, const int32_t* __restrict__ occ_b,
+                                                          int64_t T, const uint32_t* __restrict__ blk, int32_t* __restrict__ rows) {
+  __shared__ uint32_t sh[HV_CHUNK / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
+  const bool in = in_either(occ_a, occ_b, e, T);
+  const unsigned long long m = __ballot(in);
+  if (lane == 0) sh[tid >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < (tid >> 6); ++w) wbase += sh[w];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (in) rows[blk[blockIdx.x] + wbase + (uint32_t)__popcll(m & lt)] = (int32_t)e;
+}
+
 int key_bits(int64_t T) {
   int bits = 1;
   while (bits < 32 && ((int64_t)1 << bits) < T) ++bits;
@@ -350,6 +399,22 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
   const int64_t NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
   // 4 key / value buffers, the radix histogram, the heavy block counts, a few counters
   return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 256) * 4 + (3 * NBH + 4) * 4 + 64;
+}
+
+int64_t vfm_union_workspace_bytes(int64_t T) { return T < 1 ? -1 : 4 * ((T + HV_CHUNK - 1) / HV_CHUNK + 4); }
+
+int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b, void* ws, int32_t* rows, int32_t* count,
+                   void* stream) {
+  if (T < 1 || T > 0x7FFFFFFELL || !occ_ptr_a || !occ_ptr_b || !ws || !rows || !count)
+    return fail(VFM_E_INVALID, "vfm_union_rows: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int NBH = (int)((T + HV_CHUNK - 1) / HV_CHUNK);
+  uint32_t* blk = reinterpret_cast<uint32_t*>(ws);
+  hipLaunchKernelGGL(k_union_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk);
+  hipLaunchKernelGGL(k_union_scan, dim3(1), dim3(64), 0, st, blk, NBH, count);
+  hipLaunchKernelGGL(k_union_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk, rows);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail_hip(e, "vfm_union_rows");
 }
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,

@@ -126,6 +126,7 @@ class VFM(nn.Module):
         # caller names the next batch, the fused dense step skips the rows that are in neither batch -- (1-f)^2 of the
         # table -- and rows of the next batch replay what they skipped inside that kernel (no separate pass).
         self.lookahead = True
+        self.lookahead_list = True         # ... walking a list of those rows made once per pair of plans (else: scan all T)
         self.lookahead_min_skip = 0.05     # ... when at least this share of the rows would be skipped
         self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
         self._la_ready_for = None          # (plan, adam step): rows of that plan are current through that step
@@ -635,7 +636,8 @@ class VFM(nn.Module):
         if fused and la:
             # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
             ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                             self._views(self._adam_v), lr, self._adam_t, loss3, self._lazy_last, self._la_tab)
+                                             self._views(self._adam_v), lr, self._adam_t, loss3, self._lazy_last, self._la_tab,
+                                             listed=self.lookahead_list)
             self._lazy_dirty, self._lazy_kind = True, "la"
             self._la_ready_for = (next_plan, self._adam_t)
             mark("bwd_adam")
@@ -754,6 +756,9 @@ class VFM(nn.Module):
             plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group,
                                    defer_readback=True))      # (the index builds are enqueued back to back)
             spans.append((a, b))
+        if world == 1 and self.lookahead and self.lookahead_list and len(plans) > 1:
+            for i, plan in enumerate(plans):              # row lists of the look-ahead step, once per pair of batches
+                plan.prepare_lookahead(plans[(i + 1) % len(plans)])
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)

@@ -235,6 +235,46 @@ class BatchPlan:
         self._finish()
         return self._touched
 
+    def lookahead_rows(self, next_plan: "BatchPlan") -> torch.Tensor:
+        """Sorted ids of the entities of this batch or of `next_plan`'s (int32): the rows the look-ahead step visits.
+        Made once per pair of plans (`vfm_union_rows`; one 4-byte readback) and kept with this plan -- like the plan
+        itself it depends on the ids only, so a training loop that revisits its batches builds it once."""
+        pairs = self.__dict__.setdefault("_pairs", {})
+        hit = pairs.get(id(next_plan))
+        if hit is not None and hit[0]() is next_plan:
+            if hit[2] is not None:               # deferred count: first use
+                host, done = hit[2]
+                done.synchronize()
+                pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())], None)
+            return pairs[id(next_plan)][1]
+        self.prepare_lookahead(next_plan)
+        return self.lookahead_rows(next_plan)
+
+    def prepare_lookahead(self, next_plan: "BatchPlan") -> None:
+        """Enqueue the build of `lookahead_rows(next_plan)` without waiting for its count."""
+        import weakref
+        pairs = self.__dict__.setdefault("_pairs", {})
+        hit = pairs.get(id(next_plan))
+        if hit is not None and hit[0]() is next_plan:
+            return
+        dev, T = self.x.device, self.spec.T
+        for q in (self, next_plan):
+            if q.occ_ptr is None:
+                q.build_index(defer=True)
+        lib = _lib.load()
+        ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev)
+        rows = torch.empty(min(T, (self.B + next_plan.B) * self.spec.F) or 1, dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
+                                 current_stream_ptr(dev)), "vfm_union_rows")
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(count, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done))
+        if len(pairs) > 4:
+            pairs.pop(next(iter(pairs)))
+
     def index_tensors(self, with_touched: bool = False):
         """What the backward-family ops take as `index` (with_touched: + the batch's entities as a list, for the
         touched-rows step of the lazy exact Adam mode)."""
@@ -407,11 +447,16 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
 
 def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: BatchPlan, entity_params, bias_params,
                                  scalars, inv_occ, m_views, v_views, lr, step, loss_out, last_step, step_tab,
-                                 beta1=0.9, beta2=0.999, eps_adam=1e-8):
-    """vfm_elbo_bwd_adam_lookahead_f32: the fused dense step visiting only the rows of this batch and of the next."""
+                                 beta1=0.9, beta2=0.999, eps_adam=1e-8, listed=True):
+    """vfm_elbo_bwd_adam_lookahead_f32: the fused dense step visiting only the rows of this batch and of the next
+    (listed: as a list made once per pair of plans; else the kernel classifies all T rows itself)."""
     t = plan.index_tensors()
     ix = _lib.Index()
     ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
+    if listed:
+        rows = plan.lookahead_rows(next_plan)
+        if rows.numel() > 0:
+            ix.touched_ids, ix.n_touched = rows.data_ptr(), rows.numel()
     if len(t) == 5:
         ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
         ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
