@@ -464,8 +464,9 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                "sample_a2a": U * (8 * d + 8) + 2 * 4.0 * U * (d + 4), "acc_a2a": B * F * (4 * d + 8) + 2 * 4.0 * U * (d + 4),
                "apply_adam": 24.0 * n_params / max(world, 1) + 4.0 * U * (d + 4)}
         alg["allreduce"] = 4.0 * n_params
+        forced = os.environ.get("VFM_FWD_KERNEL", "0")        # (use_fwd2 in csrc/vfm_abi.hip: k_fwd2 from d = 20 on)
         fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and not dims_mode and \
-            os.environ.get("VFM_FWD_KERNEL", "2") != "1"
+            forced != "1" and (d >= 20 or forced == "2")
         names = {"fwd": ("k_fwd2<ZREC> (pipelined step: gather of this step's sample records -> FM -> ELBO; the records were "
                          "written by the previous step's fused backward)") if piped else
                         ("k_fwd2 (task stream: gather->reparam->FM->ELBO, a repeated id of the sorted column sampled "

@@ -153,7 +153,12 @@ bool use_fwd2(const vfm_problem_t* p, int eps, bool multi = false) {
   if (multi ? (p->n_samples < 2 || p->n_samples > 4 || eps == EPS_ZERO) : p->n_samples != 1) return false;
   if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS)) return false;
   if (eps == EPS_ZPRE) return false;
-  return env_int("VFM_FWD_KERNEL", 2) != 1;
+  // below d = 20 a lane group is two lanes wide and the row-parallel k_fwd is the faster kernel (d = 16, 800 K rows:
+  // 46.6 vs 60.1 us; from d = 20 on k_fwd2 wins: 17.7 vs 20.8 at d = 20, 40.2 vs 43.2 at d = 128).  VFM_FWD_KERNEL=2
+  // forces k_fwd2 wherever it is defined, =1 k_fwd (A/B runs, tests); the record gather always runs in k_fwd2.
+  const int forced = env_int("VFM_FWD_KERNEL", 0);
+  if (forced == 1) return false;
+  return forced == 2 || eps == EPS_ZREC || multi || p->d >= 20;
 }
 
 int dispatch_fwd(const vfm_problem_t* p, const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,

@@ -110,9 +110,13 @@ class VFM(nn.Module):
         # backward's extra work -- sampling + writing one record per entity of the next batch -- with the entities):
         # ML-100K shape, any real data set at the reference's B = 100,000, B = 1 M rows at ML-20M shape.  With
         # uniform-random ids over 165 K entities and B = 100 K (U ~ B) it is a wash (measured: forward -20 us,
-        # backward +46 us), so "auto" turns it on from `pipeline_ratio` rows per entity of the next batch.
+        # backward +46 us), so "auto" turns it on from `pipeline_ratio` rows per entity of the next batch -- and only
+        # from `pipeline_min_d` coordinates on: the records save bytes in proportion to d, the extra sampling in the
+        # backward does not shrink with it (800 K rows over 165 K entities: d = 16 0.143 vs 0.125 ms plain, d = 32 a
+        # tie, d = 128 at B = 1 M 0.56 vs 0.78).
         self.pipeline = "auto"
         self.pipeline_ratio = 2.0
+        self.pipeline_min_d = 20
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"
@@ -579,7 +583,8 @@ class VFM(nn.Module):
             self._adam_t += 1
             lazy = scaled and self.n_samples >= 1 and self._use_lazy(plan)
             if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
-                    and out_pred is None and ops.pipeline_supported(plan.spec)):
+                    and out_pred is None and ops.pipeline_supported(plan.spec)
+                    and (self.pipeline is True or self.d >= self.pipeline_min_d)):
                 ready = self._records_ready(plan, step)
                 nxt = next_plan
                 if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
