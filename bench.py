@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the global batch stays at --batch rows and is split over the ranks "
                          "(SURVEY cfg4); default is weak scaling, --batch rows per rank")
+    ap.add_argument("--dim", type=int, default=0, help="embedding size instead of the workload's (shape sweeps)")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
@@ -118,6 +119,8 @@ def main():
     from vae_amd.data import synthetic_triples
 
     sizes, d, B, nb_train, output = WORKLOADS[args.workload]
+    if args.dim:
+        d = args.dim
     if args.batch:
         B = args.batch
     if args.strong:
@@ -495,7 +498,7 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
         dom = max(cand, key=lambda k: kern[k]["avg_us"])
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        same_cmd = (args.workload == "ml20m_d128" and B == 100000 and not args.no_sort and world == 1 and not piped
+        same_cmd = (args.workload == "ml20m_d128" and not args.dim and B == 100000 and not args.no_sort and world == 1 and not piped
                     and look and not getattr(args, "zipf", None) and args.fwd_eps == "philox"
                     and not os.environ.get("VFM_FWD_KERNEL") and not os.environ.get("VFM_FWD_AB_NORNG"))
         if os.path.exists(tpath) and same_cmd:
