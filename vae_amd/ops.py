@@ -110,6 +110,29 @@ def _index_workspace(n_int32: int, dev) -> torch.Tensor:
     return t
 
 
+_PINNED = {"chunk": None, "used": 0}
+
+
+def _pinned_ints(n: int) -> torch.Tensor:
+    """n int32 of pinned host memory for a small asynchronous readback.  Slices of 4 KiB chunks: one pinned allocation
+    (a driver call of ~0.1 ms) serves a thousand plans instead of one each; a chunk lives as long as a slice of it."""
+    if _PINNED["chunk"] is None or _PINNED["used"] + n > _PINNED["chunk"].numel():
+        _PINNED["chunk"] = torch.empty(max(1024, n), dtype=torch.int32, pin_memory=True)
+        _PINNED["used"] = 0
+    t = _PINNED["chunk"][_PINNED["used"]:_PINNED["used"] + n]
+    _PINNED["used"] += n
+    return t
+
+
+def _carve(total_dev, sizes):
+    """Views of the given int32 sizes into one allocation (each 16-byte aligned)."""
+    out, off = [], 0
+    for n in sizes:
+        out.append(total_dev[off:off + n])
+        off += (n + 3) & ~3
+    return out
+
+
 class BatchPlan:
     """Parameter-independent state of one batch (or one rank's row shard of it)."""
 
@@ -170,21 +193,21 @@ class BatchPlan:
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
         ws = _index_workspace(nbytes // 4 + 4, dev)       # scratch of the build only: shared by all plans of a device
-        occ_ptr = torch.empty(spec.T + 1, dtype=torch.int32, device=dev)
-        occ_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
-        hid = torch.empty(cap_h, dtype=torch.int32, device=dev)
-        items = torch.empty(cap_i, 4, dtype=torch.int32, device=dev)
-        counts = torch.empty(4, dtype=torch.int32, device=dev)
-        touched = torch.empty(max(min(n, spec.T), 1), dtype=torch.int32, device=dev)
+        # ONE device allocation per plan, carved into the index's arrays (seven allocations per plan made the first
+        # build of a training set's plans twice as long as the kernels themselves)
+        sizes = [spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 4, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0]
+        arena = torch.empty(sum((v + 3) & ~3 for v in sizes), dtype=torch.int32, device=dev)
+        occ_ptr, occ_rows, hid, items, counts, touched, other = _carve(arena, sizes)
+        items = items.view(cap_i, 4)
         # two fields: also the entity in the other column of every occurrence (the pipelined step gathers its sample)
-        self.occ_other = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if spec.F == 2 else None
+        self.occ_other = other if spec.F == 2 else None
         check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
                                   ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched),
                                   ptr(self.occ_other), ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
         self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
         # the plan build's one readback: 16 bytes into pinned host memory, asynchronously
-        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host = _pinned_ints(4)
         host.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
@@ -267,7 +290,7 @@ class BatchPlan:
         count = torch.empty(1, dtype=torch.int32, device=dev)
         check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
                                  current_stream_ptr(dev)), "vfm_union_rows")
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host = _pinned_ints(1)
         host.copy_(count, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
