@@ -514,12 +514,17 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
             for k in kern:
                 if k in tj:
                     kern[k]["hbm_bytes_pmc"] = tj[k]["hbm_bytes_per_launch"]
+        def on_traffic(k):       # fraction of peak on the bytes the PMC passes counted (not the algorithmic ones)
+            t = kern[k].get("hbm_bytes_pmc")
+            return round(t / (kern[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t and kern[k]["avg_us"] > 0 else None
         roof = {"kernel": kern[dom]["kernel"], "bound": "hbm", "achieved": kern[dom]["achieved_GBs"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac_hbm_peak"], "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_us": kern[dom]["avg_us"], "alg_bytes": kern[dom]["alg_bytes"],
+                "frac_on_traffic": on_traffic(dom),
                 "elbo_fwd_kernel": {"achieved": kern["fwd"]["achieved_GBs"], "frac": kern["fwd"]["frac_hbm_peak"],
-                                    "avg_us": kern["fwd"]["avg_us"], "alg_bytes": kern["fwd"]["alg_bytes"]}}
+                                    "avg_us": kern["fwd"]["avg_us"], "alg_bytes": kern["fwd"]["alg_bytes"],
+                                    "traffic": kern["fwd"].get("hbm_bytes_pmc"), "frac_on_traffic": on_traffic("fwd")}}
     return kern, roof
 
 
