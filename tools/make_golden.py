@@ -324,6 +324,53 @@ def trajectory_case(ns, CF, name, N, M, d, X, Y, batch, output, n_epochs=2,
     print(f"{name}: steps={step} lr={lr:.4f} losses={losses}")
 
 
+def long_trajectory_case(ns, CF, name, N, M, d, X, Y, batch, n_steps, checkpoints, seed=42, eps_seed=13):
+    """The same loop (vfm-torch.py:347-370) for MANY steps on a small problem -- past a 128-step boundary, where the
+    build's scaled-moment Adam re-normalises its buffers -- recording the draws of every step, the losses and the
+    weights + Adam moments at a few checkpoints: pins the optimiser form the bench times against torch.optim.Adam
+    as the reference runs it."""
+    if not wanted(name):
+        return
+    X = torch.as_tensor(X, dtype=torch.int64)
+    Y = torch.as_tensor(Y, dtype=torch.float32)
+    nb_train = len(Y)
+    nb_occ = torch.bincount(X.flatten(), minlength=N + M)
+    lr = 1 / (1 + nb_train // batch)
+    model = make_model(ns, CF, N, M, d, nb_occ, "reg", torch.float32, seed)
+    rec = {"N": N, "M": M, "d": d, "nb_train": nb_train, "batch": batch, "lr": lr, "n_steps": n_steps,
+           "x": X.numpy(), "y": Y.numpy(), "nb_occ": nb_occ.numpy(), "checkpoints": np.array(checkpoints)}
+    for k, v in param_dict(model).items():
+        rec[f"p0_{k}"] = v
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    torch.manual_seed(eps_seed)
+    losses, step = [], 0
+    while step < n_steps:
+        for lo in range(0, nb_train, batch):
+            if step >= n_steps:
+                break
+            x, y = X[lo:lo + batch], Y[lo:lo + batch]
+            with EpsRecorder() as r:
+                lik, _, _, kl = model(x)
+            loss = -lik.log_prob(y).mean() * nb_train + kl
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            e0, ew, ev = r.draws
+            uniq = torch.unique(x)
+            rec[f"s{step}_uniq"] = uniq.numpy().astype(np.int32)
+            rec[f"s{step}_eps0"] = e0.numpy().reshape(-1)
+            rec[f"s{step}_eps_w"] = ew.numpy().reshape(-1)
+            rec[f"s{step}_eps_v"] = ev.numpy().reshape(len(uniq), -1)
+            losses.append(float(loss))
+            step += 1
+            if step in checkpoints:
+                for k, v in param_dict(model).items():
+                    rec[f"p{step}_{k}"] = v
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: steps={step} lr={lr:.4f} first/last loss {losses[0]:.2f} {losses[-1]:.2f}")
+
+
 def main():
     global ONLY
     if "--only" in sys.argv:
@@ -407,6 +454,13 @@ def main():
     Y = g.integers(1, 6, nb).astype(np.float32)
     trajectory_case(ns, CF, "traj_reg_d16", N, M, d, X, Y, 1000, "reg")
     trajectory_case(ns, CF, "traj_softplus_s2_reg_d16", N, M, d, X, Y, 1000, "reg", n_samples=2, link="softplus")
+
+    # (5b) 140 Adam steps on a small problem (4 batches per epoch): across a 128-step boundary
+    g = np.random.default_rng(8)
+    Nl, Ml, dl, nbl = 40, 60, 8, 1000
+    Xl = np.stack([g.integers(0, Nl, nbl), Nl + g.integers(0, Ml, nbl)], 1)
+    Yl = g.integers(1, 6, nbl).astype(np.float32)
+    long_trajectory_case(ns, CF, "longtraj_reg_d8", Nl, Ml, dl, Xl, Yl, 250, 140, (64, 127, 128, 129, 140))
 
     # (6) the evaluation block (vfm-torch.py:378-406): 3 epochs x 3 batches + save_weights() + model(X_test)
     g = np.random.default_rng(5)
