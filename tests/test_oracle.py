@@ -195,6 +195,28 @@ def test_trajectory_fixture_reference_shaped(name):
         assert rel_err(P[k].detach().numpy(), z["pT_" + k]) < 1e-4, k
 
 
+def test_long_trajectory_fixture_reference_shaped():
+    """The reference's 140-step Adam run (tests/golden/longtraj_reg_d8.npz) replayed with the reference-shaped
+    restatement: every loss and the weights at the recorded checkpoints."""
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "longtraj_reg_d8.npz"))
+    N, M = int(z["N"]), int(z["M"])
+    P = {k: torch.tensor(z["p0_" + k], requires_grad=True) for k in PARAM_KEYS}
+    opt = torch.optim.Adam(list(P.values()), lr=float(z["lr"]))
+    X, Y, occ = torch.tensor(z["x"]), torch.tensor(z["y"]), torch.tensor(z["nb_occ"])
+    nb, B = int(z["nb_train"]), int(z["batch"])
+    checkpoints = set(int(c) for c in z["checkpoints"])
+    for step in range(int(z["n_steps"])):
+        lo = (step * B) % nb
+        eps = (z[f"s{step}_eps0"], z[f"s{step}_eps_w"], z[f"s{step}_eps_v"])
+        loss, _ = O.reference_shaped_step(P, opt, X[lo:lo + B], Y[lo:lo + B], occ, N, M, nb, "reg", eps)
+        assert abs(loss.item() - z["losses"][step]) / abs(z["losses"][step]) < 1e-5, step
+        if step + 1 in checkpoints:
+            for k in PARAM_KEYS:
+                assert rel_err(P[k].detach().numpy(), z[f"p{step + 1}_{k}"]) < 1e-4, (step + 1, k)
+
+
 @pytest.mark.parametrize("name", ["eval_reg_d16", "eval_class_d16_s2"])
 def test_eval_block_fixture_reference_shaped(name):
     """The evaluation block (vfm-torch.py:378-406) replayed with the reference-shaped restatement: after each
