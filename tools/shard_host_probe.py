@@ -60,4 +60,15 @@ th = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(m.exchange, "ms/step", round(dt / n * 1e3, 4), "host enqueue ms/step", round(th / n * 1e3, 4))
+if os.environ.get("HOST_PROFILE"):
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    for s in range(n):
+        m.train_step(plans[s % 4], process_group=dist.group.WORLD)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = io.StringIO()
+    pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(18)
+    print(st.getvalue()[:4000])
 dist.destroy_process_group()
