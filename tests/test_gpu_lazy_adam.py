@@ -118,3 +118,27 @@ def test_lookahead_lazy_adam_is_bitwise_the_dense_trajectory(B, F, d, listed):
     la.sync_lazy()
     assert torch.equal(dense._flat, la._flat)
     assert torch.equal(dense._adam_m, la._adam_m) and torch.equal(dense._adam_v, la._adam_v)
+
+
+@pytest.mark.parametrize("form", ["lookahead_list", "lookahead_scan", "lazy_list"])
+def test_lazy_forms_with_heavy_lists_are_bitwise_the_dense_trajectory(form):
+    """The same on a batch shape with LONG occurrence lists (40 items in 600 rows: every item's list is cut in work
+    items and pre-reduced by k_heavy; short ones are summed inside k_bwd, long ones by k_heavy_sum) next to a sparse
+    user column: the heavy path and the lazy forms together, bit for bit the dense trajectory over 150 steps."""
+    sizes, B, nb = (3000, 40), 600, 6
+    dense, plans_d, X = _setup(False, F=2, d=32, T_sizes=sizes, B=B, nb=nb)
+    lz, plans_l, _ = _setup(form == "lazy_list", F=2, d=32, T_sizes=sizes, B=B, nb=nb)
+    dense.lookahead = False
+    lz.lookahead = form != "lazy_list"
+    lz.lookahead_list = form == "lookahead_list"
+    assert plans_l[0].heavy is not None and plans_l[0].U < 0.4 * lz.T
+    for s in range(150):
+        lr = 0.05 if s % 5 else 0.03
+        ld, _ = dense.train_step(plans_d[s % nb], lr=lr)
+        ll, _ = lz.train_step(plans_l[s % nb], lr=lr, next_plan=plans_l[(s + 1) % nb])
+        if s % 40 == 7:
+            assert torch.equal(ld, ll), s
+    assert lz._lazy_dirty and lz._lazy_kind == ("list" if form == "lazy_list" else "la")
+    lz.sync_lazy()
+    assert torch.equal(dense._flat, lz._flat)
+    assert torch.equal(dense._adam_m, lz._adam_m) and torch.equal(dense._adam_v, lz._adam_v)
