@@ -10,7 +10,10 @@
  *  - plain pointers and sizes only; every pointer except `vfm_problem_t*` is DEVICE memory
  *    owned by the caller; the library never allocates, frees or keeps a pointer past return.
  *  - launch-only: no host synchronisation inside, safe under hipGraph capture, re-entrant
- *    (the only state is a thread-local error string).
+ *    (the only state is a thread-local error string -- and, per device, ONE side stream with two events,
+ *    created the first time a fused backward meets an index with heavy lists in a large table: the
+ *    pre-reduction of those lists then runs beside the main kernel, fork / join by events on the caller's
+ *    stream; env VFM_HEAVY_OVERLAP=0 keeps everything on the caller's stream).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - return 0 on success, otherwise a negative VFM_E_* code or a positive hipError_t;
  *    `vfm_last_error()` describes the last failure on the calling thread.

@@ -23,6 +23,7 @@
 #include <string.h>
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "vfm_args.hpp"
 
@@ -215,6 +216,56 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
   b->heavy_ids = idx->heavy_ids; b->heavy_acc = idx->heavy_acc; b->n_heavy = idx->n_heavy;
   b->heavy_stride = idx->n_heavy + idx->n_items;
   return 0;
+}
+
+// ---- overlap of the long-list pre-reduction with the main kernel (skewed data, large tables) ----
+// k_heavy -> k_heavy_sum are two small latency-bound kernels the main kernel would otherwise wait for (Zipf(1.1) items
+// at cfg3: 20 + 14 us in front of a 150 us kernel).  They run on a side stream of the library's own (one per device,
+// created on first use, never destroyed) while the main kernel handles every entity BUT the heavy ones on the
+// caller's stream; the heavy entities follow in a second, listed launch once the pre-reduction has finished.
+// Ordering is by events only; the caller's stream stays the only thing the caller has to synchronise with.
+struct Side { hipStream_t s = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false, tried = false; };
+Side* side_of_device() {
+  static Side sides[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  Side& sd = sides[dev];
+  if (!sd.tried) {
+    sd.tried = true;
+    sd.ok = hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&sd.e1, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&sd.e2, hipEventDisableTiming) == hipSuccess;
+  }
+  return sd.ok ? &sd : nullptr;
+}
+// worth it when the heavy entities are a small part of the rows the main kernel visits (otherwise nothing is hidden)
+bool heavy_overlap(const vfm_problem_t* p, const vfm_index_t* idx) {
+  return idx->n_heavy > 0 && idx->n_items > 0 && (int64_t)idx->n_heavy * 16 < p->T && p->n_samples == 1 &&
+         env_int("VFM_HEAVY_OVERLAP", 1) != 0;
+}
+
+// fused backward + Adam with the pre-reduction overlapped: `b` without heavy fields yet; rows = b.row_ids (or all)
+int bwd_adam_overlapped(const vfm_problem_t* p, const vfm_index_t* idx, const Shape& s, int eps, int adam, KArgs& a, BwdArgs& b,
+                        const AdamArgs& ad, const float* sumz, const float* grow, hipStream_t st, Side* sd) {
+  hipError_t e = hipEventRecord(sd->e1, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(sd->s, sd->e1, 0);
+  if (e != hipSuccess) return fail_hip(e, "heavy-list overlap: events");
+  if (int rc = run_heavy(p, idx, sumz, grow, sd->s, &b)) return rc;
+  e = hipEventRecord(sd->e2, sd->s);
+  if (e != hipSuccess) return fail_hip(e, "heavy-list overlap: events");
+  const int32_t keep = a.row_filter;
+  a.row_filter = 4;                                   // everything but the heavy entities (+ loss, scalars)
+  if (int rc = dispatch_bwd(p, s, eps, adam, a, b, ad, st)) return rc;
+  e = hipStreamWaitEvent(st, sd->e2, 0);
+  if (e != hipSuccess) return fail_hip(e, "heavy-list overlap: events");
+  BwdArgs bh = b;
+  bh.row_ids = idx->heavy_ids; bh.n_rows = idx->n_heavy;
+  a.row_filter = 3;                                   // the heavy entities, listed
+  const int rc = dispatch_bwd(p, s, eps, adam, a, bh, ad, st);
+  a.row_filter = keep;
+  return rc;
 }
 
 int check_index(const vfm_problem_t* p, const vfm_index_t* idx, const char* who) {
@@ -420,7 +471,8 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
             nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
-  if (!untouched_only)
+  Side* sd = (!untouched_only && !(p->flags & VFM_FLAG_SPARSE_ADAM) && heavy_overlap(p, idx)) ? side_of_device() : nullptr;
+  if (!untouched_only && !sd)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
@@ -434,6 +486,12 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
     b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
     a.row_filter = 0;
   }
+  if (sd && a.row_filter == 0) {
+    if (int rc = bwd_adam_overlapped(p, idx, s, eps, adam, a, b, ad, sumz, grow, (hipStream_t)stream, sd)) return rc;
+    return after_launch("vfm_elbo_bwd_adam_f32");
+  }
+  if (sd)       // (a row filter of the caller's: the plain order)
+    if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   if (int rc = dispatch_bwd(p, s, eps, adam, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_adam_f32");
 }
@@ -640,7 +698,9 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
             nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
-  if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
+  Side* sd = heavy_overlap(p, idx) ? side_of_device() : nullptr;
+  if (!sd)
+    if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   b.last_step = last_step; b.next_occ_ptr = next_occ_ptr; b.step_tab = reinterpret_cast<float2*>(step_tab);
   if (idx->touched_ids && idx->n_touched > 0) {      // the rows to visit, listed (vfm_union_rows): no scan over the table
     if (idx->n_touched > p->T) return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: more listed rows than table rows");
@@ -652,6 +712,10 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
   if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
   Shape s;
   pick_shape(p->d, &s);
+  if (sd) {
+    if (int rc = bwd_adam_overlapped(p, idx, s, EPS_PHILOX, 1, a, b, ad, sumz, grow, (hipStream_t)stream, sd)) return rc;
+    return after_launch("vfm_elbo_bwd_adam_lookahead_f32");
+  }
   if (int rc = dispatch_bwd(p, s, EPS_PHILOX, 1, a, b, ad, (hipStream_t)stream)) return rc;
   return after_launch("vfm_elbo_bwd_adam_lookahead_f32");
 }

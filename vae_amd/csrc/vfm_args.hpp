@@ -34,7 +34,8 @@ struct KArgs {
   int32_t own_mod, own_rank;   // entity-sharded apply: this rank owns e = own_rank (mod own_mod)
   int32_t F, d, lik, id64, G, flags;
   int32_t S, sample;    // variational samples: S of them; the forward runs one launch per sample
-  int32_t row_filter;   // fused backward+Adam: 0 all rows, 1 rows not in the batch only, 2 rows in the batch only
+  int32_t row_filter;   // fused backward+Adam: 0 all rows, 1 rows not in the batch only, 2 rows in the batch only,
+                        // 3 heavy entities only (listed), 4 all but the heavy entities
   float inv_S;
   float ll_scale;  // nb_train / (B_global * S)
   double ll_scale_d;

@@ -94,7 +94,10 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   // a.row_filter (fused Adam, STAGE_FULL): 0 = every row; 1 = only the rows the batch does NOT touch (pure Adam
   // decay, independent of this step's forward: the caller runs it concurrently with the forward kernel on
   // another stream); 2 = only the touched rows (+ the scalars and the loss)
-  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr && a.row_filter != 1;   // uniform: fold vfm_elbo_finalize_f32 in
+  // 3 / 4 (the long-list pre-reduction overlapped with this kernel, vfm_abi.hip): 4 = every row but the heavy
+  // entities (+ the scalars and the loss), 3 = the heavy entities only, listed
+  const bool duty = a.row_filter != 1 && a.row_filter != 3;      // this launch forms the loss and moves the scalars
+  const bool fold = STAGE == STAGE_FULL && b.loss != nullptr && duty;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
   if (STAGE == STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_lo == 0) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     b.sums[0] = reduced ? (float)b.partials[VFM_P_G] : __builtin_nanf("");   // this rank's row sums, to be summed over ranks
     b.sums[1] = reduced ? (float)b.partials[VFM_P_ALPHA] : __builtin_nanf("");
   }
-  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T && a.row_filter != 1) {   // (last chunk of a chunked run)
+  if (STAGE != STAGE_ACC && blockIdx.x == 0 && tid == 0 && a.e_hi == a.T && duty) {   // (last chunk of a chunked run)
     const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
     // (no fold and the forward's slots never reduced -- vfm_elbo_finalize_f32 skipped --: NaN, not stale sums)
     const bool stale = STAGE == STAGE_FULL && !fold && b.partials[VFM_P_REDUCED] != 1.0;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       la_gap = (b.la_step - 1) - b.last_step[e];
     }
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
-    if (ADAM == 1 && STAGE == STAGE_FULL && a.row_filter != 0 && (a.row_filter == 1) == touched) continue;
+    if (ADAM == 1 && STAGE == STAGE_FULL && (a.row_filter == 1 || a.row_filter == 2) && (a.row_filter == 1) == touched) continue;
 
     // loads that do not depend on the index chain
     Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     int hslot = -1;
     if (STAGE != STAGE_APPLY && b.n_heavy > 0 && end - beg > VFM_HEAVY_MIN)
       hslot = heavy_slot_of(b.heavy_ids, b.n_heavy, (int)e);
+    if (ADAM == 1 && STAGE == STAGE_FULL && a.row_filter == 4 && hslot >= 0) continue;   // (the heavy-only launch takes it)
     auto walk = [&](const float* __restrict__ sz, const float* __restrict__ hacc, Chunk<VEC>(&A)[CPL], float& gs) {
 #pragma unroll
       for (int i = 0; i < CPL; ++i)
