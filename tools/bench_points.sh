@@ -23,7 +23,7 @@ run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30
 run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6
 run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --pipeline off
 run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions
-run cfg2_ml100k_d20_plain_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline off
+run cfg2_ml100k_d20_pipelined_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline on
 run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
 run cfg5_criteo_d256_lazy_auto "" --workload criteo_d256 --steps 200 --warmup 20
 run cfg5_criteo_d256_lookahead_only "" --workload criteo_d256 --lazy-adam off --steps 100 --warmup 10

@@ -117,6 +117,8 @@ class VFM(nn.Module):
         self.pipeline = "auto"
         self.pipeline_ratio = 2.0
         self.pipeline_min_d = 20
+        self.pipeline_min_T = 8192         # small tables: every list is cut in work items and the plain step is faster
+                                           # (ML-100K shape: 0.056 vs 0.063 ms)
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"
@@ -584,7 +586,7 @@ class VFM(nn.Module):
             lazy = scaled and self.n_samples >= 1 and self._use_lazy(plan)
             if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
                     and out_pred is None and ops.pipeline_supported(plan.spec)
-                    and (self.pipeline is True or self.d >= self.pipeline_min_d)):
+                    and (self.pipeline is True or (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T))):
                 ready = self._records_ready(plan, step)
                 nxt = next_plan
                 if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
