@@ -605,3 +605,53 @@ def test_untouched_rows_split_equals_single_launch():
     (a, la), (b, lb) = run(True), run(False)
     assert torch.equal(la, lb)
     assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)
+
+
+def test_step_is_capturable_in_a_hip_graph():
+    """include/vfm_hip.h: launch-only, safe under hipGraph capture.  The forward + fused backward of a skewed batch in a
+    large table (the long-list pre-reduction forks to the library's side stream and joins again by events) captured
+    once in a graph and replayed twice == the same two calls made eagerly twice, bit for bit."""
+    from vae_amd import ops
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    dev = torch.device("cuda:0")
+    sizes = [20000, 3000]
+    X, y = synthetic_triples(sizes, 30000, seed=2, device=dev, zipf=1.2)
+
+    def fresh():
+        torch.manual_seed(1)
+        m = VFM(field_sizes=sizes, embedding_size=32, device=dev, rng_seed=5)
+        m.set_training_data(X, nb_train=30000)
+        m._ensure_opt_state()
+        m._set_moment_form(True)
+        return m
+
+    def one_step(m, plan, bufs):
+        sumz, grow, pred, loss3 = bufs
+        ent, bia, scal = m._views(m._flat)
+        st = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, seed=5, step=3, train=True, out_pred=pred, out_sumz=sumz,
+                              out_grow=grow, out_partials=m._partials)
+        ops.elbo_backward_adam(plan, st, ent, bia, scal, m.inv_occ, m._views(m._adam_m), m._views(m._adam_v), 0.01, 1,
+                               loss_out=loss3, scaled_moments=True)
+
+    def buffers(m, B):
+        return (torch.empty(B, m.d, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev),
+                torch.empty(3, device=dev))
+
+    a, b = fresh(), fresh()
+    pa, pb = a.plan(X, y), b.plan(X, y)
+    assert pa.heavy is not None and pa.heavy[0].numel() * 16 < a.T        # the overlapped path
+    ba, bb = buffers(a, 30000), buffers(b, 30000)
+    one_step(a, pa, ba)
+    one_step(a, pa, ba)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        pb.index_tensors()                      # (nothing but launches inside the capture)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            one_step(b, pb, bb)
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(ba[3], bb[3])
