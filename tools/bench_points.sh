@@ -25,8 +25,9 @@ run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmu
 run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions
 run cfg2_ml100k_d20_pipelined_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline on
 run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
-run cfg5_criteo_d256_lazy_auto "" --workload criteo_d256 --steps 200 --warmup 20
-run cfg5_criteo_d256_lookahead_only "" --workload criteo_d256 --lazy-adam off --steps 100 --warmup 10
+run cfg5_criteo_d256_auto "" --workload criteo_d256 --steps 200 --warmup 20
+run cfg5_criteo_d256_row_list_form "" --workload criteo_d256 --lazy-adam on --steps 200 --warmup 20
+run cfg3_B5000_auto "" --batch 5000 --steps 300 --warmup 20 --no-regions
 run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --lookahead off --steps 40 --warmup 4
 run cfg3_lookahead_off "" --lookahead off --steps 200 --warmup 20 --no-regions
 run cfg3_fwd_ab_k_fwd "VFM_FWD_KERNEL=1" --steps 200 --warmup 20 --no-regions
