@@ -13,7 +13,8 @@
  *    (the only state is a thread-local error string -- and, per device, ONE side stream with two events,
  *    created the first time a fused backward meets an index with heavy lists in a large table: the
  *    pre-reduction of those lists then runs beside the main kernel, fork / join by events on the caller's
- *    stream; env VFM_HEAVY_OVERLAP=0 keeps everything on the caller's stream).
+ *    stream -- that enqueue is serialised per device by a mutex, so host threads driving different streams of one
+ *    device may call concurrently; env VFM_HEAVY_OVERLAP=0 keeps everything on the caller's stream).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - return 0 on success, otherwise a negative VFM_E_* code or a positive hipError_t;
  *    `vfm_last_error()` describes the last failure on the calling thread.
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define VFM_ABI_VERSION 3
+#define VFM_ABI_VERSION 4
 #define VFM_MAX_FIELDS 64
 
 #define VFM_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported size)   */
@@ -117,6 +118,44 @@ extern "C" {
 #define VFM_MAX_FWD_BLOCKS 4096
 #define VFM_PARTIALS_LEN (VFM_N_PARTIALS * (1 + VFM_MAX_FWD_BLOCKS))
 
+/* ---- Device-resident step state: what makes a captured training step REPLAYABLE --------------------------------
+ * Everything that changes from one training step to the next -- the Philox step of the eps stream, the Adam step count
+ * and the constants derived from it (bias corrections, the scaled-moment factors, the learning rate) -- normally
+ * arrives as host-side arguments, which a captured HIP graph would freeze.  With `vfm_problem_t.dev_step` set, the
+ * forward and the fused backward+Adam entry points read all of it from DEVICE memory instead and advance it themselves
+ * (the host-side `step`, `lr`, `beta*`, `seed`-independent arguments of those calls are then ignored; `p->step` too):
+ *   forward   : eps stream step = dev_step->philox_step; hands (philox_step, adam_step) over to the backward
+ *   backward  : constants = dev_step->tab[adam_step - tab_first]; after the last read of the step, the launch that
+ *               forms the loss sets philox_step += 1, adam_step += 1 -- the next replay runs the next step.
+ * So one graph captured per (batch, next batch) pair replays for every epoch (vfm-torch.py:351-370 is the loop).
+ * The table is made on the HOST by vfm_step_consts (the same arithmetic the host-argument path uses: a replayed
+ * trajectory is bitwise the eager one) and uploaded by the caller; `error` becomes non-zero when a step found no
+ * table entry (the step then runs with the nearest entry: results are wrong, the flag says so). */
+typedef struct vfm_step_consts {      /* constants of ONE Adam step (64 bytes) */
+  float step_size, bc2_sqrt;          /* lr / (1 - beta1^t), sqrt(1 - beta2^t)                                   */
+  float a1, q2, c1, c2, s1, s2;       /* scaled-moment form (VFM_FLAG_SCALED_MOMENTS), see csrc/vfm_args.hpp      */
+  int32_t store_true;                 /* this step ends a moment period: the plain moments are written back       */
+  int32_t k;                          /* position of the step in its moment period, 1..VFM_MOMENT_PERIOD          */
+  int32_t scaled;                     /* the entry was made for the scaled-moment form                            */
+  int32_t reserved;
+  float lr, beta1, beta2, eps;
+} vfm_step_consts_t;
+typedef struct vfm_dev_step {         /* DEVICE memory, caller-owned, 64 bytes, 16-byte aligned */
+  uint64_t philox_step;               /* eps stream step of the NEXT forward                                      */
+  int64_t adam_step;                  /* 1-based count of the NEXT Adam update                                    */
+  uint64_t philox_step_bwd;           /* hand-over written by the forward of the running step                     */
+  int64_t adam_step_bwd;
+  int64_t tab_first, tab_len;         /* tab[i] holds the constants of Adam step tab_first + i                    */
+  const vfm_step_consts_t* tab;       /* DEVICE pointer                                                           */
+  int64_t error;
+} vfm_dev_step_t;
+/* HOST helper: the constants of Adam step `step` (1-based) as every fused entry point forms them from its host
+ * arguments.  scaled != 0: for VFM_FLAG_SCALED_MOMENTS.  Returns 0, or VFM_E_* (beta^k underflow). */
+int vfm_step_consts(float lr, float beta1, float beta2, float eps_adam, int64_t step, int32_t scaled,
+                    vfm_step_consts_t* out);
+/* Sets (philox_step, adam_step) of a device step state (one tiny launch; stream-ordered). */
+int vfm_dev_step_set(vfm_dev_step_t* dev_step, uint64_t philox_step, int64_t adam_step, void* stream);
+
 /* Problem description shared by all kernels of one step (host memory). */
 typedef struct vfm_problem {
   int64_t B;          /* rows handled by THIS call (this rank's shard of the batch)       */
@@ -153,7 +192,19 @@ typedef struct vfm_problem {
    * [coord_off, coord_off + d) of a wider model; only the Philox coordinate index is shifted by it
    * (eps tables, if given, are local like the parameter tables).  Multiple of 8; 0 otherwise. */
   int32_t coord_off, reserved0;
+  /* optional device-side extensions (NULL = off) */
+  vfm_dev_step_t* dev_step;   /* replayable step: see vfm_dev_step_t above.  Honoured by vfm_elbo_fwd_f32 (training, Philox
+                                 eps), vfm_elbo_bwd_adam_f32, _lookahead_f32 and _pipe_f32; other entry points reject it.  */
+  float* wrec;                /* [T,4] packed first-order records (mu_w, s_w, 1/occ, 0) per entity -- a CACHE of
+                                 bias_params and inv_occ (vfm_wrec_build_f32 fills it).  The two-field training forward
+                                 reads ONE 16-byte record per sampling task instead of an 8-byte row of bias_params and a
+                                 4-byte entry of inv_occ (two cache lines for 12 bytes); every fused backward+Adam form and
+                                 vfm_adam_catchup_f32 given the pointer refresh (mu_w, s_w) of the rows they update, so the
+                                 cache stays coherent across fused steps.  Any other writer of bias_params invalidates it:
+                                 the caller rebuilds (or passes NULL).  bias_params stays the parameter (state_dict layout
+                                 of vfm-torch.py:152 unchanged).                                                          */
 } vfm_problem_t;
+int vfm_wrec_build_f32(const float* bias_params, const float* inv_occ, int64_t T, float* wrec, void* stream);
 
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
  *   occ_ptr [T+1] offsets into occ_rows [B*F] (row numbers sorted by entity id, stable).
@@ -391,15 +442,17 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
  *   for every listed row e (ids [n] int32, or NULL = all T rows, n == T): apply the updates of Adam steps
  *   last_step[e]+1 .. upto, then last_step[e] = mark (>= upto: `mark = upto + 1` when the caller is about to
  *   apply step upto+1 to exactly these rows).
- * lr_of_step (HOST memory): the learning rate of the 1st, 2nd, ... step of the moment period containing `upto`
- * (steps P+1 .. upto, P = floor((upto-1) / VFM_MOMENT_PERIOD) * VFM_MOMENT_PERIOD).  A row must not lag across
+ * lr_of_step (HOST memory, n_lr entries): the learning rate of the 1st, 2nd, ... step of the moment period containing
+ * `upto` (steps P+1 .. upto, P = floor((upto-1) / VFM_MOMENT_PERIOD) * VFM_MOMENT_PERIOD); n_lr >= upto - P, fewer is
+ * VFM_E_INVALID (the table is never read past n_lr).  wrec: NULL, or the packed first-order records to refresh
+ * (vfm_problem_t.wrec).  A row must not lag across
  * a period boundary: at the last step of every period (step % VFM_MOMENT_PERIOD == 0) the caller brings ALL
  * rows up to date and runs the dense call (which writes the plain moments for all rows).
  * Call it on a batch's rows before the forward of a step, and on all rows before predicting / saving. */
 int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,
                          const float* m_bias, const float* v_bias, int32_t* last_step, const int32_t* ids, int64_t n,
-                         int64_t T, int32_t d, const float* lr_of_step, float beta1, float beta2, float eps_adam,
-                         int64_t upto, int64_t mark, void* stream);
+                         int64_t T, int32_t d, const float* lr_of_step, int64_t n_lr, float beta1, float beta2,
+                         float eps_adam, int64_t upto, int64_t mark, float* wrec, void* stream);
 
 /* Look-ahead form of the lazy exact Adam (mid-range touch fractions, e.g. ML-20M shape at B = 100 K: 59 % of the
  * rows per batch): the fused dense step visits a row only if it is in THIS batch (gradient update) or in the NEXT one

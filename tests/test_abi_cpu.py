@@ -35,13 +35,62 @@ def test_problem_struct_layout_matches_header(tmp_path):
                    'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_problem_t), offsetof(vfm_problem_t, F),'
                    'offsetof(vfm_problem_t, group_hi), offsetof(vfm_problem_t, group_n), offsetof(vfm_problem_t, seed),'
                    'offsetof(vfm_problem_t, e_lo), offsetof(vfm_problem_t, flags), offsetof(vfm_problem_t, n_samples),'
-                   'offsetof(vfm_problem_t, coord_off));return 0;}\n')
+                   'offsetof(vfm_problem_t, coord_off));'
+                   'printf("%zu %zu\\n", offsetof(vfm_problem_t, dev_step), offsetof(vfm_problem_t, wrec));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert got == [C.sizeof(Problem), Problem.F.offset, Problem.group_hi.offset, Problem.group_n.offset,
                    Problem.seed.offset, Problem.e_lo.offset, Problem.flags.offset, Problem.n_samples.offset,
-                   Problem.coord_off.offset]
+                   Problem.coord_off.offset, Problem.dev_step.offset, Problem.wrec.offset]
+
+
+def test_step_state_struct_layouts_match_header(tmp_path):
+    """vfm_step_consts_t (64 bytes, 16 floats per table row) and vfm_dev_step_t (64 bytes = the int64[8] device tensor)."""
+    import subprocess
+    from vae_amd._lib import StepConsts, DevStep
+    src = tmp_path / "st.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_step_consts_t), offsetof(vfm_step_consts_t, store_true),'
+                   'offsetof(vfm_step_consts_t, k), offsetof(vfm_step_consts_t, lr), sizeof(vfm_dev_step_t),'
+                   'offsetof(vfm_dev_step_t, adam_step_bwd), offsetof(vfm_dev_step_t, tab), offsetof(vfm_dev_step_t, error));return 0;}\n')
+    exe = tmp_path / "st"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(StepConsts), StepConsts.store_true.offset, StepConsts.k.offset, StepConsts.lr.offset,
+                   C.sizeof(DevStep), DevStep.adam_step_bwd.offset, DevStep.tab.offset, DevStep.error.offset]
+    assert C.sizeof(StepConsts) == 64 and C.sizeof(DevStep) == 64
+
+
+def test_step_consts_host_helper_and_dev_step_rejections():
+    """vfm_step_consts is pure host arithmetic (runs here): bias corrections, the scaled-moment factors, the period
+    position; entry points that do not read the step from device memory reject a dev_step pointer."""
+    from vae_amd import _lib
+    lib = _lib.load()
+    c = _lib.StepConsts()
+    assert lib.vfm_step_consts(0.01, 0.9, 0.999, 1e-8, 128, 1, C.byref(c)) == 0
+    assert c.k == 128 and c.store_true == 1 and c.scaled == 1
+    b1, b2, lr_ = C.c_float(0.9).value, C.c_float(0.999).value, C.c_float(0.01).value      # (the fp32 values the C side sees)
+    assert abs(c.step_size - lr_ / (1 - b1 ** 128)) < 1e-9 and abs(c.bc2_sqrt - (1 - b2 ** 128) ** 0.5) < 1e-7
+    assert abs(c.s1 - b1 ** 128) < 1e-12 and abs(c.a1 - c.step_size * b1 ** 128) < 1e-12
+    assert lib.vfm_step_consts(0.01, 0.9, 0.999, 1e-8, 129, 0, C.byref(c)) == 0
+    assert c.k == 1 and c.store_true == 0 and c.scaled == 0 and abs(c.c1 - (1 - b1)) < 1e-7
+    assert lib.vfm_step_consts(0.01, 0.9, 0.999, 1e-8, 0, 1, C.byref(c)) == -1
+    p = _lib.Problem()
+    p.B, p.B_global, p.T, p.F, p.d, p.id_bits, p.n_samples = 4, 4, 10, 2, 8, 64, 1
+    p.dev_step = 0x1000
+    assert lib.vfm_elbo_finalize_f32(C.byref(p), None, None, None, None) == -2 and b"dev_step" in lib.vfm_last_error()
+    assert lib.vfm_elbo_bwd_f32(C.byref(p), *([None] * 17)) == -2
+    p.dev_step = 0x1008
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1 and b"16-byte" in lib.vfm_last_error()
+    p.dev_step, p.wrec = None, 0x1004
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1 and b"wrec" in lib.vfm_last_error()
+    # the catch-up call never reads its learning-rate table past n_lr
+    lr = (C.c_float * 1)(0.1)
+    one = 0x1000
+    assert lib.vfm_adam_catchup_f32(one, one, one, one, one, one, one, None, 10, 10, 8, lr, 1, 0.9, 0.999, 1e-8, 200, 200,
+                                    None, None) == -1
+    assert b"n_lr" in lib.vfm_last_error()
 
 
 def test_index_struct_layout_matches_header(tmp_path):
@@ -68,7 +117,7 @@ def test_problem_mirror_has_every_header_field_and_rejects_unknown_names():
     body = hdr[hdr.index("typedef struct vfm_problem {"): hdr.index("} vfm_problem_t;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     members = []
-    for decl in re.findall(r"\b(?:u?int(?:32|64)_t|double)\s+([^;]+);", body):
+    for decl in re.findall(r"\b(?:u?int(?:32|64)_t\s|double\s|float\s*\*|vfm_dev_step_t\s*\*)\s*([^;]+);", body):
         members += [re.sub(r"\[.*\]", "", m).strip() for m in decl.split(",")]
     assert members == [n for n, _ in _lib.Problem._fields_]
     p = _lib.Problem()

@@ -85,7 +85,7 @@ def test_catchup_argument_checks():
     from vae_amd import _lib
     lib = _lib.load()
     lr = (C.c_float * 1)(0.1)
-    assert lib.vfm_adam_catchup_f32(None, None, None, None, None, None, None, None, 0, 10, 8, lr, 0.9, 0.999, 1e-8, 1, 1, None) == -1
+    assert lib.vfm_adam_catchup_f32(None, None, None, None, None, None, None, None, 0, 10, 8, lr, 1, 0.9, 0.999, 1e-8, 1, 1, None, None) == -1
 
 
 @pytest.mark.parametrize("listed", [True, False])

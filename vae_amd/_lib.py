@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
 OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_FWD_BLOCKS = 4096
 MAX_FIELDS = 64
 N_PARTIALS = 8
@@ -34,6 +34,7 @@ EXPORTS = (
     "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32", "vfm_union_rows", "vfm_union_workspace_bytes",
     "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
+    "vfm_step_consts", "vfm_dev_step_set", "vfm_wrec_build_f32",
 )
 
 
@@ -47,6 +48,7 @@ class Problem(C.Structure):
         ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
         ("own_mod", C.c_int32), ("own_rank", C.c_int32),
         ("coord_off", C.c_int32), ("reserved0", C.c_int32),
+        ("dev_step", C.c_void_p), ("wrec", C.c_void_p),
     ]
 
     def __setattr__(self, name, value):
@@ -66,6 +68,21 @@ class Index(C.Structure):
                 ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
                 ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64),
                 ("occ_other", C.c_void_p)]
+
+
+class StepConsts(C.Structure):
+    """Mirror of `vfm_step_consts_t` (64 bytes: the constants of one Adam step, made by vfm_step_consts)."""
+    _fields_ = [("step_size", C.c_float), ("bc2_sqrt", C.c_float), ("a1", C.c_float), ("q2", C.c_float),
+                ("c1", C.c_float), ("c2", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
+                ("store_true", C.c_int32), ("k", C.c_int32), ("scaled", C.c_int32), ("reserved", C.c_int32),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+class DevStep(C.Structure):
+    """Mirror of `vfm_dev_step_t` (64 bytes, lives in DEVICE memory: an int64[8] tensor)."""
+    _fields_ = [("philox_step", C.c_uint64), ("adam_step", C.c_int64), ("philox_step_bwd", C.c_uint64),
+                ("adam_step_bwd", C.c_int64), ("tab_first", C.c_int64), ("tab_len", C.c_int64), ("tab", C.c_void_p),
+                ("error", C.c_int64)]
 
 
 class Pipe(C.Structure):
@@ -124,8 +141,11 @@ def load():
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_heavy_list_for.argtypes = [i64, i64]
     lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp]
-    lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float,
-                                         i64, i64, vp]
+    lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), i64, C.c_float, C.c_float, C.c_float,
+                                         i64, i64, vp, vp]
+    lib.vfm_step_consts.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i64, i32, C.POINTER(StepConsts)]
+    lib.vfm_dev_step_set.argtypes = [vp, C.c_uint64, i64, vp]
+    lib.vfm_wrec_build_f32.argtypes = [vp, vp, i64, vp, vp]
     lib.vfm_sample_records_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.vfm_elbo_bwd_adam_pipe_f32.argtypes = ([PP, C.POINTER(Index), C.POINTER(Pipe)] + [vp] * 13 +
                                                [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp])

@@ -43,6 +43,7 @@ _UNITS = [("vfm_abi.hip", "", _EXACT), ("vfm_index.hip", "", []), ("vfm_variants
           ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_fwd2m.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2m.hip", "_softplus", ["-DVFM_LINK=1"]),
+          ("vfm_fwdg.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwdg.hip", "_softplus", ["-DVFM_LINK=1"]),
           ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"] + _EXACT), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"] + _EXACT)]
 
 

@@ -76,8 +76,13 @@ bool pick_shape(int d, Shape* s) {
   return d <= 256;
 }
 
-int check_problem(const vfm_problem_t* p) {
+int check_problem(const vfm_problem_t* p, bool dev_ok = false) {
   if (!p) return fail(VFM_E_INVALID, "problem is NULL");
+  if (p->dev_step && !dev_ok)
+    return fail(VFM_E_UNSUPPORTED, "vfm_problem_t.dev_step: only the training forward and the fused backward+Adam entry points read the step from device memory");
+  if (p->dev_step && p->n_samples != 1) return fail(VFM_E_UNSUPPORTED, "vfm_problem_t.dev_step: one variational sample");
+  if (p->dev_step && (((uintptr_t)p->dev_step) & 15) != 0) return fail(VFM_E_INVALID, "vfm_problem_t.dev_step must be 16-byte aligned");
+  if (p->wrec && (((uintptr_t)p->wrec) & 15) != 0) return fail(VFM_E_INVALID, "vfm_problem_t.wrec must be 16-byte aligned");
   if (p->B < 0 || p->T <= 0 || p->T > 0xFFFFFFFELL) return fail(VFM_E_INVALID, "bad B or T");
   if (p->F < 1 || p->F > VFM_MAX_FIELDS) return fail(VFM_E_INVALID, "F out of range [1,64]");
   if (p->d < 1) return fail(VFM_E_INVALID, "d < 1");
@@ -141,6 +146,7 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   a.key.chunk_off = (uint32_t)(p->coord_off / 4);
   a.x = x; a.y = y; a.entity = entity; a.bias = bias; a.inv_occ = inv_occ; a.scalars = scalars;
   a.W = W; a.eps_entity = ee; a.eps_bias = eb; a.eps_global = eg;
+  a.dev = p->dev_step; a.wrec = p->wrec;
   for (int g = 0; g < p->F; ++g) { a.group_hi[g] = p->group_hi[g]; a.group_n[g] = p->group_n[g]; }
   return a;
 }
@@ -162,8 +168,20 @@ bool use_fwd2(const vfm_problem_t* p, int eps, bool multi = false) {
   return forced == 2 || eps == EPS_ZREC || multi || p->d >= 20;
 }
 
+// General number of fields (F != 2), one sample, d % 4 == 0, 16 <= d <= 512, eps from Philox (or zero, predictions):
+// k_fwdg -- the fields of a row split over lane groups, 8 coordinates per lane (vfm_fwdg.hpp).  Table eps, S > 1 and
+// the multi-rank forms (slots / partial row values / no first-order weights) stay with k_fwd; VFM_FWD_KERNEL=1 forces it.
+bool use_fwdg(const vfm_problem_t* p, int eps, int mode) {
+  if (p->F == 2 || (p->d & 3) != 0 || p->d < 16 || p->d > 512 || p->n_samples != 1) return false;
+  if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS | VFM_FLAG_ZREC)) return false;
+  if (!(eps == EPS_PHILOX || (eps == EPS_ZERO && mode == MODE_PREDICT))) return false;
+  if (p->coord_off != 0) return false;
+  return env_int("VFM_FWD_KERNEL", 0) != 1;
+}
+
 int dispatch_fwd(const vfm_problem_t* p, const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,
                  hipStream_t st) {
+  if (use_fwdg(p, eps, mode)) return softplus(p) ? launch_fwdg_softplus(eps, mode, a, o, st) : launch_fwdg_abs(eps, mode, a, o, st);
   if (use_fwd2(p, eps)) {
     // VFM_FWD_AB_NORNG=1 (profiling only, wrong results): eps = 0 in the training forward, i.e. the kernel
     // without its Philox / Box-Muller arithmetic
@@ -224,7 +242,10 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
 // created on first use, never destroyed) while the main kernel handles every entity BUT the heavy ones on the
 // caller's stream; the heavy entities follow in a second, listed launch once the pre-reduction has finished.
 // Ordering is by events only; the caller's stream stays the only thing the caller has to synchronise with.
-struct Side { hipStream_t s = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false, tried = false; };
+// Thread safety: the side stream and its event pair are shared by every caller of a device, so the whole fork / join
+// enqueue (record e1 .. wait e2) runs under `mu` -- two host threads driving different streams of one device cannot
+// interleave their records and waits (an event waited on always carries the record of the same call).
+struct Side { hipStream_t s = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr; bool ok = false, tried = false; std::mutex mu; };
 Side* side_of_device() {
   static Side sides[64];
   static std::mutex mu;
@@ -249,6 +270,7 @@ bool heavy_overlap(const vfm_problem_t* p, const vfm_index_t* idx) {
 // fused backward + Adam with the pre-reduction overlapped: `b` without heavy fields yet; rows = b.row_ids (or all)
 int bwd_adam_overlapped(const vfm_problem_t* p, const vfm_index_t* idx, const Shape& s, int eps, int adam, KArgs& a, BwdArgs& b,
                         const AdamArgs& ad, const float* sumz, const float* grow, hipStream_t st, Side* sd) {
+  std::lock_guard<std::mutex> lk(sd->mu);
   hipError_t e = hipEventRecord(sd->e1, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(sd->s, sd->e1, 0);
   if (e != hipSuccess) return fail_hip(e, "heavy-list overlap: events");
@@ -324,6 +346,39 @@ extern "C" {
 int vfm_abi_version(void) { return VFM_ABI_VERSION; }
 const char* vfm_last_error(void) { return g_err; }
 
+int vfm_step_consts(float lr, float beta1, float beta2, float eps_adam, int64_t step, int32_t scaled,
+                    vfm_step_consts_t* out) {
+  if (!out || step < 1) return fail(VFM_E_INVALID, "vfm_step_consts: bad argument");
+  vfm_problem_t p;
+  memset(&p, 0, sizeof(p));
+  p.flags = scaled ? VFM_FLAG_SCALED_MOMENTS : 0;
+  AdamArgs ad;
+  memset(&ad, 0, sizeof(ad));
+  ad.b1 = beta1; ad.b2 = beta2; ad.eps = eps_adam;
+  adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);         // (exactly what the host-argument path does)
+  if (int rc = scaled_moment_consts(&p, beta1, beta2, step, &ad)) return rc;
+  memset(out, 0, sizeof(*out));
+  out->step_size = ad.step_size; out->bc2_sqrt = ad.bc2_sqrt; out->a1 = ad.a1; out->q2 = ad.q2;
+  out->c1 = ad.c1; out->c2 = ad.c2; out->s1 = ad.s1; out->s2 = ad.s2;
+  out->store_true = ad.store_true; out->k = (int32_t)((step - 1) % VFM_MOMENT_PERIOD + 1); out->scaled = ad.scaled;
+  out->lr = lr; out->beta1 = beta1; out->beta2 = beta2; out->eps = eps_adam;
+  return 0;
+}
+
+int vfm_dev_step_set(vfm_dev_step_t* dev_step, uint64_t philox_step, int64_t adam_step, void* stream) {
+  if (!dev_step || adam_step < 1) return fail(VFM_E_INVALID, "vfm_dev_step_set: bad argument");
+  hipLaunchKernelGGL(k_dev_step_set, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_step, philox_step, adam_step);
+  return after_launch("vfm_dev_step_set");
+}
+
+int vfm_wrec_build_f32(const float* bias_params, const float* inv_occ, int64_t T, float* wrec, void* stream) {
+  if (!bias_params || !inv_occ || !wrec || T <= 0 || (((uintptr_t)wrec) & 15) != 0)
+    return fail(VFM_E_INVALID, "vfm_wrec_build_f32: bad argument");
+  const int grid = (int)((T + 255) / 256 < 2048 ? (T + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_wrec_build, dim3(grid), dim3(256), 0, (hipStream_t)stream, bias_params, inv_occ, T, wrec);
+  return after_launch("vfm_wrec_build_f32");
+}
+
 int vfm_inv_occ_f32(const int64_t* nb_occ, float* inv_occ, int64_t T, void* stream) {
   if (!nb_occ || !inv_occ || T <= 0) return fail(VFM_E_INVALID, "vfm_inv_occ_f32: bad argument");
   const int grid = (int)((T + 255) / 256 < 2048 ? (T + 255) / 256 : 2048);
@@ -351,8 +406,10 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      const float* inv_occ, const float* scalars, const double* W,
                      const float* eps_entity, const float* eps_bias, const float* eps_global,
                      float* pred, double* partials, float* sumz, float* grow, void* stream) {
-  if (int rc = check_problem(p)) return rc;
+  if (int rc = check_problem(p, true)) return rc;
   if (!partials) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: partials is NULL");
+  if (p->dev_step && (eps_entity || eps_bias || eps_global || (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_EPS_ZERO))))
+    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: dev_step goes with the in-kernel Philox eps stream only");
   hipStream_t st0 = (hipStream_t)stream;
   if (p->B == 0) {  // empty shard (a rank without rows): zero sums, zero blocks; buffers may be NULL
     hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st0, partials, (int)VFM_N_PARTIALS);
@@ -449,8 +506,13 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                           float* m_scalars, float* v_scalars,
                           float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
                           void* stream) {
-  if (int rc = check_problem(p)) return rc;
+  if (int rc = check_problem(p, true)) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_f32")) return rc;
+  if (p->dev_step) {      // replayable step: lr / betas / step come from the device table (the host values are ignored)
+    if (p->flags & (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_SPARSE_ADAM) || eps_entity || eps_bias || eps_global)
+      return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: dev_step excludes VFM_FLAG_ROWS_UNTOUCHED, VFM_FLAG_SPARSE_ADAM and eps tables");
+    step = 1; lr = 0.f;
+  }
   const int rows_flags = p->flags & (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED);
   if (rows_flags == (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: VFM_FLAG_ROWS_UNTOUCHED and VFM_FLAG_ROWS_TOUCHED exclude each other");
@@ -645,7 +707,8 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
                                float* m_scalars, float* v_scalars,
                                float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
                                void* stream) {
-  if (int rc = check_problem(p)) return rc;
+  if (int rc = check_problem(p, true)) return rc;
+  if (p->dev_step) { step = 1; lr = 0.f; }      // (replayable step: the device table carries them; pipe->next_step too)
   if (int rc = single_sample_only(p, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
   if (p->F != 2 || (p->d & 3) != 0 || p->d > 512)
@@ -683,7 +746,8 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
                                     float* m_scalars, float* v_scalars,
                                     float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
                                     int32_t* last_step, const int32_t* next_occ_ptr, float* step_tab, void* stream) {
-  if (int rc = check_problem(p)) return rc;
+  if (int rc = check_problem(p, true)) return rc;
+  if (p->dev_step) { step = 1; lr = 0.f; }      // (replayable step: the caller keeps period-ending steps out of its graphs)
   if (int rc = single_sample_only(p, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
   if ((p->flags & ~VFM_FLAG_LINK_SOFTPLUS) != VFM_FLAG_SCALED_MOMENTS)
@@ -722,8 +786,8 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
 
 int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* m_entity, const float* v_entity,
                          const float* m_bias, const float* v_bias, int32_t* last_step, const int32_t* ids, int64_t n,
-                         int64_t T, int32_t d, const float* lr_of_step, float beta1, float beta2, float eps_adam,
-                         int64_t upto, int64_t mark, void* stream) {
+                         int64_t T, int32_t d, const float* lr_of_step, int64_t n_lr, float beta1, float beta2,
+                         float eps_adam, int64_t upto, int64_t mark, float* wrec, void* stream) {
   if (!entity_params || !bias_params || !m_entity || !v_entity || !m_bias || !v_bias || !last_step || n < 0 || T < 1 ||
       d < 1 || upto < 0 || mark < upto || mark > 0x7FFFFFFFLL || (ids == nullptr && n != T))
     return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: bad argument (ids == NULL means all T rows: n == T)");
@@ -733,7 +797,9 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
   // the steps of the moment period that contains `upto`: period_start + 1 .. upto
   const int64_t pstart = upto > 0 ? ((upto - 1) / VFM_MOMENT_PERIOD) * VFM_MOMENT_PERIOD : 0;
   const int kmax = (int)(upto - pstart);
-  if (kmax > 0 && !lr_of_step) return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: lr_of_step (host, one per step of the period) is NULL");
+  if (kmax > 0 && (!lr_of_step || n_lr < kmax))
+    return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: lr_of_step (host) needs one entry per step of the period up to `upto` (n_lr too small)");
+  if (wrec && (((uintptr_t)wrec) & 15) != 0) return fail(VFM_E_INVALID, "vfm_adam_catchup_f32: wrec must be 16-byte aligned");
   CatchTab tab;
   memset(&tab, 0, sizeof(tab));
   for (int k = 1; k <= kmax; ++k) {   // exactly the constants vfm_elbo_bwd_adam_f32 forms for that step
@@ -750,11 +816,11 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
   if ((d & 1) == 0)
     hipLaunchKernelGGL(k_adam_catchup<4>, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
                        m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
-                       (int32_t)mark, eps_adam, tab);
+                       (int32_t)mark, eps_adam, tab, wrec);
   else
     hipLaunchKernelGGL(k_adam_catchup<1>, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, entity_params, bias_params,
                        m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
-                       (int32_t)mark, eps_adam, tab);
+                       (int32_t)mark, eps_adam, tab, wrec);
   return after_launch("vfm_adam_catchup_f32");
 }
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
                                                         const float* __restrict__ m_bias, const float* __restrict__ v_bias,
                                                         int32_t* __restrict__ last_step, const int32_t* __restrict__ ids,
                                                         int64_t n, int d, int32_t pstart, int32_t upto, int32_t mark,
-                                                        float eps, const CatchTab tab) {
+                                                        float eps, const CatchTab tab, float* __restrict__ wrec) {
   const int lane = threadIdx.x & 63;
   // The period's step constants live in REGISTERS, two entries per lane (k = 1 + lane, 65 + lane); a replayed step
   // fetches its pair with v_readlane (k is wave-uniform).  Indexing the by-value table with k inside the loop made
@@ -135,7 +135,10 @@ __global__ __launch_bounds__(BLOCK) void k_adam_catchup(float* __restrict__ enti
         if (h0) st_chunk<VEC>(entity + ro + (size_t)j * VEC, p0);
         if (h1) st_chunk<VEC>(entity + ro + (size_t)(j + 64) * VEC, p1);
       }
-      if (lane == 0) *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = pb;
+      if (lane == 0) {
+        *reinterpret_cast<float2*>(bias + 2 * (size_t)e) = pb;
+        if (wrec) *reinterpret_cast<float2*>(wrec + 4 * (size_t)e) = pb;       // the packed first-order record follows
+      }
     }
     if (lane == 0) last_step[e] = mark;
   }

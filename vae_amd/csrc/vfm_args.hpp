@@ -4,6 +4,7 @@
 //   vfm_fwd.hip  k_fwd instances + dispatch            (compiled once per link function, -DVFM_LINK=0|1)
 //   vfm_fwd2.hip k_fwd2 instances + dispatch           (two fields, task-stream form; once per link function)
 //   vfm_fwd2m.hip k_fwd2m instances + dispatch         (the same with 2..4 variational samples inside the kernel)
+//   vfm_fwdg.hip k_fwdg instances + dispatch           (general F, a row's fields split over lane groups; once per link)
 //   vfm_bwd.hip  k_bwd, k_sample instances + dispatch  (compiled once per link function)
 // Splitting keeps every kernel family in its own object (built in parallel by vae_amd/build.py); a
 // kernel is always launched from the unit that defines it, so no relocatable device code is needed.
@@ -50,6 +51,8 @@ struct KArgs {
   const float* eps_entity;
   const float* eps_bias;
   const float* eps_global;
+  vfm_dev_step_t* dev;  // non-NULL: the step-dependent values (Philox step, Adam constants) live in device memory (replayable step)
+  float* wrec;          // non-NULL: packed first-order records [T,4] = (mu_w, s_w, 1/occ, 0) (vfm_problem_t.wrec)
   int64_t group_hi[VFM_MAX_FIELDS];
   double group_n[VFM_MAX_FIELDS];
 };
@@ -115,6 +118,41 @@ struct AdamArgs {
   float a1, q2;
 };
 
+// ---- replayable step (vfm_dev_step_t): device-side reads of what the host arguments otherwise carry ----
+// forward: the eps stream step; block 0 hands (philox_step, adam_step) over to the backward launches of the same step
+__device__ __forceinline__ RngKey key_of_step(const KArgs& a, bool writer) {
+  RngKey key = a.key;
+  if (a.dev) {
+    const uint64_t s = a.dev->philox_step;
+    key.step_lo = (uint32_t)s; key.step_hi = (uint32_t)(s >> 32);
+    if (writer) { a.dev->philox_step_bwd = s; a.dev->adam_step_bwd = a.dev->adam_step; }
+  }
+  return key;
+}
+// backward: eps step + the Adam constants of the step from the device table; `bump`: this thread advances the state
+// (the launch that forms the loss, after which nothing of this step reads philox_step / adam_step again)
+__device__ __forceinline__ void load_dev_step(const KArgs& a, RngKey& key, AdamArgs& ad, int32_t& la_step, int32_t& la_k,
+                                              RngKey& next_key, bool bump) {
+  if (!a.dev) return;
+  const uint64_t s = a.dev->philox_step_bwd;
+  const int64_t t = a.dev->adam_step_bwd;
+  key.step_lo = (uint32_t)s; key.step_hi = (uint32_t)(s >> 32);
+  next_key.step_lo = (uint32_t)(s + 1); next_key.step_hi = (uint32_t)((s + 1) >> 32);
+  int64_t i = t - a.dev->tab_first;
+  const bool miss = i < 0 || i >= a.dev->tab_len;
+  if (miss) i = i < 0 ? 0 : a.dev->tab_len - 1;
+  const vfm_step_consts_t c = a.dev->tab[i];
+  ad.step_size = c.step_size; ad.bc2_sqrt = c.bc2_sqrt; ad.inv_bc2_sqrt = 1.0f / c.bc2_sqrt;
+  ad.a1 = c.a1; ad.q2 = c.q2; ad.c1 = c.c1; ad.c2 = c.c2; ad.s1 = c.s1; ad.s2 = c.s2;
+  ad.store_true = c.store_true; ad.scaled = c.scaled;
+  ad.b1 = c.beta1; ad.b2 = c.beta2; ad.eps = c.eps;
+  la_step = (int32_t)t; la_k = c.k;
+  if (bump) {
+    a.dev->philox_step = s + 1; a.dev->adam_step = t + 1;
+    if (miss) a.dev->error = 1;
+  }
+}
+
 // lane-group shape of the row kernels for an embedding size (see pick_shape in vfm_abi.hip)
 struct Shape {
   int lpe, cpl, vec;
@@ -137,6 +175,7 @@ VFM_INTERNAL int env_int(const char* name, int dflt);
                                        hipStream_t st);                                                        \
   VFM_INTERNAL int launch_fwd2_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
   VFM_INTERNAL int launch_fwd2m_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);         \
+  VFM_INTERNAL int launch_fwdg_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
   VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
                                        const AdamArgs& ad, hipStream_t st);                                    \
   VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \

@@ -62,8 +62,15 @@ __device__ __forceinline__ float replay_one(float p, float m, float r, float2 c,
 }
 
 template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE, int LINK, bool MULTI, bool PIPE = false, bool LA = false>
-__global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad) {
+__global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const KArgs a, const BwdArgs b, const AdamArgs ad_in) {
   constexpr int GPB = BLOCK / LPE;
+  // step-dependent values: from the kernel arguments, or (replayable step, a.dev) from device memory
+  AdamArgs ad = ad_in;
+  RngKey key = a.key, next_key = b.next_key;
+  int32_t la_step = b.la_step, la_k = b.la_k;
+  if constexpr (ADAM == 1 && STAGE == STAGE_FULL)
+    load_dev_step(a, key, ad, la_step, la_k, next_key,
+                  blockIdx.x == 0 && threadIdx.x == 0 && a.row_filter != 1 && a.row_filter != 3 && a.e_hi == a.T);
   static_assert(!PIPE || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "the pipelined step is the fused single-sample one");
   static_assert(!LA || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI && !PIPE), "look-ahead lazy Adam is a form of the fused dense step");
   __shared__ float sh_cs[VFM_MAX_FIELDS];
@@ -81,11 +88,11 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     if constexpr (PIPE) sh_cs_next[tid] = b.zrec_next ? (float)(a.group_n[tid] / b.next_W[tid]) : 0.f;
   }
   if constexpr (LA) {
-    for (int k = tid; k < b.la_k; k += BLOCK) sh_tab[k] = b.step_tab[k];
+    for (int k = tid; k < la_k; k += BLOCK) sh_tab[k] = b.step_tab[k];
   }
   __syncthreads();
   if constexpr (LA) {
-    if (blockIdx.x == 0 && tid == 0) b.step_tab[b.la_k] = make_float2(ad.a1, ad.q2);     // for later replays of this step
+    if (blockIdx.x == 0 && tid == 0) b.step_tab[la_k] = make_float2(ad.a1, ad.q2);     // for later replays of this step
   }
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
   const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);     // (dimension-sharded mode: one rank carries bias_params)
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
     if constexpr (EPS == EPS_PHILOX) {
       float n[8], nb;
-      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
       e0 = n[0];
     }
     const float as0 = link_f<LINK>(s0);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     int la_gap = 0;                        // LA: skipped zero-gradient steps this row applies before this step's update
     if constexpr (LA) {
       if (!touched && b.next_occ_ptr[e + 1] == b.next_occ_ptr[e]) continue;     // in neither batch: the row waits
-      la_gap = (b.la_step - 1) - b.last_step[e];
+      la_gap = (la_step - 1) - b.last_step[e];
     }
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
     if (ADAM == 1 && STAGE == STAGE_FULL && (a.row_filter == 1 || a.row_filter == 2) && (a.row_filter == 1) == touched) continue;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       for (int sm = 0; sm < a.S; ++sm) {
         if (sm > 0)
           walk(b.sumz + (size_t)sm * (size_t)a.B * d, b.heavy_acc + (size_t)sm * (size_t)b.heavy_stride * xs, A, gs);
-        const RngKey ks = key_of_sample(a.key, sm);
+        const RngKey ks = key_of_sample(key, sm);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
           const int j = lig + i * LPE;
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
             for (int t = 0; t < VEC; ++t) epc.v[t] = 0.f;
           } else {
             float nb;
-            eps_of_chunk<VEC>(a.key, (uint32_t)e, j, epc.v, nb);
+            eps_of_chunk<VEC>(key, (uint32_t)e, j, epc.v, nb);
             if (i == 0) nb_eps = nb;
           }
 #pragma unroll
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
             float rm[VEC], rs[VEC];
 #pragma unroll
             for (int t = 0; t < VEC; ++t) { rm[t] = __builtin_amdgcn_sqrtf(vm[i].v[t]); rs[t] = __builtin_amdgcn_sqrtf(vs[i].v[t]); }
-            for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
+            for (int k = la_k - la_gap; k < la_k; ++k) {
               const float2 c = sh_tab[k];
 #pragma unroll
               for (int t = 0; t < VEC; ++t) {
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
             if (in_next) {     // the updated row is in registers: sample it for the next step right here
               Chunk<VEC> ep2, zn;
               float nb2;
-              eps_of_chunk<VEC>(b.next_key, (uint32_t)e, j, ep2.v, nb2);
+              eps_of_chunk<VEC>(next_key, (uint32_t)e, j, ep2.v, nb2);
               if (i == 0) nb_next = nb2;
 #pragma unroll
               for (int t = 0; t < VEC; ++t) {
@@ -519,19 +526,20 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       if constexpr (LA) {
         if (la_gap > 0) {
           const float r0 = __builtin_amdgcn_sqrtf(vb.x), r1 = __builtin_amdgcn_sqrtf(vb.y);
-          for (int k = b.la_k - la_gap; k < b.la_k; ++k) {
+          for (int k = la_k - la_gap; k < la_k; ++k) {
             const float2 c = sh_tab[k];
             th.x = replay_one(th.x, mb.x, r0, c, ad.eps);
             th.y = replay_one(th.y, mb.y, r1, c, ad.eps);
           }
         }
-        b.last_step[e] = b.la_step;
+        b.last_step[e] = la_step;
       }
       if constexpr (ADAM) {
         float2 pn;
         pn.x = adam_update(th.x, g0, mb.x, vb.x, ad);
         pn.y = adam_update(th.y, g1, mb.y, vb.y, ad);
         *reinterpret_cast<float2*>(const_cast<float*>(a.bias) + 2 * (size_t)e) = pn;
+        if (a.wrec) *reinterpret_cast<float2*>(a.wrec + 4 * (size_t)e) = pn;      // packed first-order record: (mu_w, s_w | 1/occ, 0)
         if constexpr (PIPE) {
           if (in_next) {
             const float sgw2 = link_f<LINK>(pn.y);

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
   }
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = link_f<LINK>(alpha);
-  const RngKey key = key_of_sample(a.key, a.sample);   // this launch's sample (a.key: sample 0)
+  const RngKey key0 = key_of_step(a, blockIdx.x == 0 && tid == 0);     // (replayable step: the step lives in device memory)
+  const RngKey key = key_of_sample(key0, a.sample);   // this launch's sample (key0: sample 0)
   const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
     if constexpr (EPS == EPS_TABLE) es = a.eps_global[tid];
     if constexpr (EPS == EPS_PHILOX) {
       float n[8], nb;
-      normal8b(key_of_sample(a.key, tid), 0xFFFFFFFFu, 0u, n, nb);
+      normal8b(key_of_sample(key0, tid), 0xFFFFFFFFu, 0u, n, nb);
       es = n[0];
     }
     sh_e0[tid] = es;

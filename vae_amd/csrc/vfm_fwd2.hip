@@ -29,6 +29,15 @@ int launch_fwd2_t(KArgs& a, const FwdOut& o, hipStream_t st) {
   if (cap > VFM_MAX_FWD_BLOCKS) cap = VFM_MAX_FWD_BLOCKS;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
+  if constexpr (EPS == EPS_PHILOX && MODE == MODE_TRAIN) {
+    if (a.wrec) {       // the packed first-order records are given: one 16-byte record per task (vfm_problem_t.wrec)
+      if (a.id64)
+        hipLaunchKernelGGL((k_fwd2<LPE, FULL, EPS, MODE, true, LINK, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
+      else
+        hipLaunchKernelGGL((k_fwd2<LPE, FULL, EPS, MODE, false, LINK, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
+      return 0;
+    }
+  }
   if (a.id64)
     hipLaunchKernelGGL((k_fwd2<LPE, FULL, EPS, MODE, true, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, o);
   else

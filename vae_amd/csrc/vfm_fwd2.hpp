@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t entity_of(uint32_t id, bool live, float& bad
   return ok ? id : 0u;
 }
 
-template <int EPS, int MODE>
+template <int EPS, int MODE, bool WREC = false>
 __device__ __forceinline__ void load_ent(const KArgs& a, uint32_t e, int off0, int off1, EntRegs<EPS>& R) {
   const size_t d = (size_t)a.d;
   R.e = e;
@@ -102,8 +102,16 @@ __device__ __forceinline__ void load_ent(const KArgs& a, uint32_t e, int off0, i
     R.ep[1] = ld_chunk<4>(er + off1);
     R.epw = a.eps_bias[e];
   }
-  R.th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
-  if constexpr (MODE == MODE_TRAIN) R.io = a.inv_occ[e];
+  if constexpr (WREC) {
+    // packed first-order record (mu_w, s_w, 1/occ, 0): ONE 16-byte load = one cache line per task, instead of an
+    // 8-byte row of bias_params and a 4-byte entry of inv_occ in two different lines (vfm_problem_t.wrec)
+    const float4 h = *reinterpret_cast<const float4*>(a.wrec + 4 * (size_t)e);
+    R.th = make_float2(h.x, h.y);
+    R.io = h.z;
+  } else {
+    R.th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
+    if constexpr (MODE == MODE_TRAIN) R.io = a.inv_occ[e];
+  }
 }
 
 // the arithmetic of one task: z (8 coordinates of this lane), sampled first-order weight (lane 0 of the
@@ -164,7 +172,7 @@ __device__ __forceinline__ void sample_ent(const RngKey& key, const EntRegs<EPS>
   }
 }
 
-template <int LPE, bool FULL, int EPS, int MODE, bool ID64, int LINK>
+template <int LPE, bool FULL, int EPS, int MODE, bool ID64, int LINK, bool WREC = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut out) {
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh_cs[2];
@@ -175,6 +183,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int C = a.d >> 2;                       // chunks of 4 coordinates (d % 4 == 0 here)
+  // eps stream step: the kernel argument, or (replayable step) device memory -- thread 0 of block 0 hands it on
+  const RngKey key = key_of_step(a, blockIdx.x == 0 && tid == 0);
 
   if (MODE == MODE_TRAIN && EPS != EPS_ZREC && tid < 2) {
     sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZREC) {
     if (tid < 64) {
       float n[8], nb;
-      normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
+      normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
       if (tid == 0) sh_e0 = n[0];
     }
   } else if (tid == 0) {
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const int j0 = 2 * lig, j1 = 2 * lig + 1;
   const bool v0 = j0 < C, v1 = j1 < C;
   const int off0 = 4 * (v0 ? j0 : C - 1), off1 = 4 * (v1 ? j1 : C - 1);
-  const uint32_t pg = (uint32_t)lig + (a.key.chunk_off >> 1);      // Philox counter word 0 of this lane
+  const uint32_t pg = (uint32_t)lig + (key.chunk_off >> 1);      // Philox counter word 0 of this lane
 
   // rows of this group: the batch is dealt in contiguous ranges over all groups of the grid (B * 2 < 2^31)
   const int NG = (int)gridDim.x * GPB;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
     RawIds<ID64> id2 = load_row_ids<ID64>(a, r0 + 2 < gend ? r0 + 2 : glast);
     bool cur_item = true;                    // the first task of a range is always an item task
     EntRegs<EPS> A, Bq;
-    load_ent<EPS, MODE>(a, entity_of(id0.i, true, tot[4]), off0, off1, A);
+    load_ent<EPS, MODE, WREC>(a, entity_of(id0.i, true, tot[4]), off0, off1, A);
     float ycur = 0.f;                        // target of the row the current task belongs to
     if constexpr (MODE == MODE_TRAIN) ycur = a.y[r0];
     // the cached item
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
       // younger, so the wait is a counted one (as the last load it would be a drain of everything in flight)
       const Ids f2 = fold_ids<ID64>(id2, T32);
       id2 = load_row_ids<ID64>(a, r_next + 2 < gend ? r_next + 2 : glast);
-      load_ent<EPS, MODE>(a, e_next, off0, off1, nx);
+      load_ent<EPS, MODE, WREC>(a, e_next, off0, off1, nx);
       if constexpr (MODE == MODE_TRAIN) ycur = a.y[live_next ? r_next : glast];
       id0.u = n_u; id0.i = n_i;
       id1.u = adv ? f2.u : id1.u;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
       // ---- current task ----
       float z[8], w, klw;
       const float cs = (cu.e < hi0) ? cs0 : cs1;
-      sample_ent<FULL, EPS, MODE, LINK>(a.key, cu, pg, v0, v1, owns_bias, cs, z, w, klw);
+      sample_ent<FULL, EPS, MODE, LINK>(key, cu, pg, v0, v1, owns_bias, cs, z, w, klw);
       if (item_now) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) zi[t] = z[t];

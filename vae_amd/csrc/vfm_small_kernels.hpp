@@ -130,3 +130,20 @@ __global__ __launch_bounds__(BLOCK) void k_sum_slots(double* __restrict__ ws) {
     ws[0] = t;
   }
 }
+
+// replayable step: set the device-resident counters (vfm_dev_step_set)
+__global__ void k_dev_step_set(vfm_dev_step_t* dev, uint64_t philox_step, int64_t adam_step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dev->philox_step = philox_step; dev->adam_step = adam_step;
+    dev->philox_step_bwd = philox_step; dev->adam_step_bwd = adam_step;
+  }
+}
+
+// packed first-order records (mu_w, s_w, 1/occ, 0) per entity (vfm_problem_t.wrec)
+__global__ __launch_bounds__(256) void k_wrec_build(const float* __restrict__ bias, const float* __restrict__ inv_occ, int64_t T,
+                                                    float* __restrict__ wrec) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < T; e += (int64_t)gridDim.x * blockDim.x) {
+    const float2 th = *reinterpret_cast<const float2*>(bias + 2 * e);
+    *reinterpret_cast<float4*>(wrec + 4 * e) = make_float4(th.x, th.y, inv_occ[e], 0.f);
+  }
+}

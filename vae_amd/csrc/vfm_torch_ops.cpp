@@ -47,6 +47,18 @@ vfm_problem_t problem(const Tensor& x_like, int64_t B, int64_t B_global, int64_t
   return p;
 }
 
+// optional device-side extensions of vfm_problem_t: packed first-order records [T,4], device step state (64 bytes)
+void extensions(vfm_problem_t& p, const optional<Tensor>& wrec, const optional<Tensor>& dev_step, int64_t T) {
+  if (wrec.has_value() && wrec->defined()) {
+    TORCH_CHECK(dev_tensor(*wrec, at::kFloat, "wrec").numel() >= 4 * T, "wrec needs [T,4] floats");
+    p.wrec = wrec->data_ptr<float>();
+  }
+  if (dev_step.has_value() && dev_step->defined()) {
+    TORCH_CHECK(dev_tensor(*dev_step, at::kLong, "dev_step").numel() >= 8, "dev_step needs 8 int64 (vfm_dev_step_t)");
+    p.dev_step = reinterpret_cast<vfm_dev_step_t*>(dev_step->data_ptr<int64_t>());
+  }
+}
+
 struct Ids {
   const void* ptr; int64_t B, F; int id_bits;
 };
@@ -64,7 +76,8 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
               const optional<Tensor>& eps_global, Tensor pred, Tensor partials,
               const optional<Tensor>& sumz, const optional<Tensor>& grow, at::IntArrayRef group_hi,
               at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
-              int64_t flags, int64_t seed, int64_t step, int64_t n_samples, int64_t coord_off) {
+              int64_t flags, int64_t seed, int64_t step, int64_t n_samples, int64_t coord_off,
+              const optional<Tensor>& wrec, const optional<Tensor>& dev_step) {
   const Ids id = ids_of(x);
   dev_tensor(entity, at::kFloat, "entity_params"); dev_tensor(bias, at::kFloat, "bias_params");
   dev_tensor(scalars, at::kFloat, "scalars"); dev_tensor(pred, at::kFloat, "pred");
@@ -84,6 +97,7 @@ void elbo_fwd(const Tensor& x, const optional<Tensor>& y, const Tensor& entity, 
   c10::hip::HIPGuard guard(x.get_device());
   vfm_problem_t p = problem(x, id.B, B_global, T, id.F, d, nb_train, likelihood, id.id_bits, flags, group_hi,
                             group_n, seed, step, n_samples, coord_off);
+  extensions(p, wrec, dev_step, T);
   const double* Wp = (W.has_value() && W->defined()) ? dev_tensor(*W, at::kDouble, "W").data_ptr<double>() : nullptr;
   check(vfm_elbo_fwd_f32(&p, id.ptr, fptr(y, "y"), entity.data_ptr<float>(), bias.data_ptr<float>(),
                          fptr(inv_occ, "inv_occ"), scalars.data_ptr<float>(), Wp, fptr(eps_entity, "eps_entity"),
@@ -195,10 +209,11 @@ void elbo_bwd_adam(at::TensorList index, Tensor entity, Tensor bias, Tensor scal
                    at::ArrayRef<double> group_n, int64_t nb_train, int64_t B_global, int64_t likelihood,
                    int64_t flags, int64_t seed, int64_t step, double lr, double beta1, double beta2,
                    double eps_adam, int64_t adam_step, const optional<Tensor>& loss, int64_t n_samples,
-                   int64_t coord_off) {
+                   int64_t coord_off, const optional<Tensor>& wrec, const optional<Tensor>& dev_step) {
   const int64_t B = grow.numel();
   BwdCommon c = bwd_common(index, entity, bias, B, F, B_global, nb_train, likelihood, flags, group_hi,
                            group_n, seed, step, n_samples, sumz, eps_entity, eps_bias, eps_global, coord_off);
+  extensions(c.p, wrec, dev_step, entity.size(0));
   TORCH_CHECK(m_entity.numel() == entity.numel() && v_entity.numel() == entity.numel() &&
               m_bias.numel() == bias.numel() && v_bias.numel() == bias.numel() && m_scalars.numel() >= 3 &&
               v_scalars.numel() >= 3, "Adam moment shapes");
@@ -400,7 +415,8 @@ TORCH_LIBRARY(vfm_hip, m) {
   m.def("elbo_fwd(Tensor x, Tensor? y, Tensor entity_params, Tensor bias_params, Tensor? inv_occ, Tensor scalars, "
         "Tensor? W, Tensor? eps_entity, Tensor? eps_bias, Tensor? eps_global, Tensor(a!) pred, Tensor(b!) partials, "
         "Tensor(c!)? sumz, Tensor(d!)? grow, int[] group_hi, float[] group_n, int nb_train, int B_global, "
-        "int likelihood, int flags, int seed, int step, int n_samples=1, int coord_off=0) -> ()", &elbo_fwd);
+        "int likelihood, int flags, int seed, int step, int n_samples=1, int coord_off=0, Tensor(e!)? wrec=None, "
+        "Tensor(f!)? dev_step=None) -> ()", &elbo_fwd);
   m.def("elbo_finalize(Tensor(a!) partials, Tensor scalars, Tensor(b!) loss, int nb_train, int B_global, int flags, "
         "int n_samples=1) -> ()",
         &elbo_finalize);
@@ -415,7 +431,8 @@ TORCH_LIBRARY(vfm_hip, m) {
         "Tensor sumz, Tensor grow, Tensor partials, Tensor(d!) m_entity, Tensor(e!) v_entity, Tensor(f!) m_bias, "
         "Tensor(g!) v_bias, Tensor(h!) m_scalars, Tensor(i!) v_scalars, int F, int[] group_hi, float[] group_n, "
         "int nb_train, int B_global, int likelihood, int flags, int seed, int step, float lr, float beta1, "
-        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss, int n_samples=1, int coord_off=0) -> ()",
+        "float beta2, float eps_adam, int adam_step, Tensor(j!)? loss, int n_samples=1, int coord_off=0, "
+        "Tensor(k!)? wrec=None, Tensor(l!)? dev_step=None) -> ()",
         &elbo_bwd_adam);
   m.def("elbo_bwd_acc(Tensor[] index, Tensor sumz, Tensor grow, Tensor partials, Tensor(a!) acc, "
         "Tensor(c!) sums, int T, int F, int d, int e_lo, int e_hi) -> ()", &elbo_bwd_acc);

@@ -441,6 +441,7 @@ int check_var(const vfm_problem_t* p, int objective) {
   if (p->d > 64 * MAXKB) return fail(VFM_E_UNSUPPORTED, "variant: d above 1024");
   if (p->n_samples != 1) return fail(VFM_E_UNSUPPORTED, "variant: one variational sample");
   if (p->flags != 0) return fail(VFM_E_UNSUPPORTED, "variant: no flags (|.| link, single rank)");
+  if (p->dev_step || p->wrec) return fail(VFM_E_UNSUPPORTED, "variant: no device-side step state / packed first-order records");
   if (objective != VFM_OBJ_SAMPLED && objective != VFM_OBJ_CLOSED_FORM) return fail(VFM_E_INVALID, "variant: unknown objective");
   if (objective == VFM_OBJ_CLOSED_FORM && p->likelihood != VFM_LIK_NORMAL)
     return fail(VFM_E_UNSUPPORTED, "variant: the closed-form expected log-likelihood is the Normal one (vfm-tomasrch.py:446-449)");

@@ -46,6 +46,9 @@ class LikelihoodResult:
         return y * self.logits - torch.nn.functional.softplus(self.logits)
 
 
+_CHECK_WREC = bool(int(__import__("os").environ.get("VFM_CHECK_WREC", "0")))
+
+
 def _round4(n):
     return (n + 3) // 4 * 4
 
@@ -135,6 +138,18 @@ class VFM(nn.Module):
         self.lookahead = True
         self.lookahead_list = True         # ... walking a list of those rows made once per pair of plans (else: scan all T)
         self.lookahead_min_skip = 0.05     # ... when at least this share of the rows would be skipped
+        # Packed first-order records [T,4] = (mu_w, s_w, 1/occ, 0): a cache of bias_params + inv_occ the fused step's
+        # forward reads with ONE 16-byte load per sampling task (vfm_problem_t.wrec); the fused backward forms and the
+        # catch-up kernel refresh the rows they update, anything else that writes bias_params drops it (_wrec_ok).
+        self.use_wrec = True
+        self._wrec, self._wrec_ok = None, False
+        # Replayable step: with the step-dependent constants in device memory (ops.StepState), the launches of a fused
+        # step are captured ONCE per (batch, next batch, step form) in a HIP graph and replayed -- the host then spends
+        # one graph launch per step instead of two library calls (ML-100K shape, B = 5,000: the host was the limiter).
+        # "auto": fit() replays, a bare train_step() loop does when `replay = True`.  Bitwise the eager trajectory.
+        self.replay = "auto"
+        self._graphs = {}
+        self._step_state = None
         self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
         self._la_ready_for = None          # (plan, adam step): rows of that plan are current through that step
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
@@ -249,6 +264,8 @@ class VFM(nn.Module):
         self.__dict__.pop("_view_cache", None)
         self._xflat = None
         self._la_tab = self._la_ready_for = None          # (look-ahead step table: no row lags after sync_lazy above)
+        self._wrec, self._wrec_ok = None, False
+        self._graphs, self._step_state = {}, None         # (captured steps hold pointers of the old device's buffers)
         self._zrec = self._zrec_for = None                # (sample records of the pipelined step: re-made on demand)
         self._shard_acc = self._shard_small = self._shard_klws = None
         if getattr(self, "_state_bufs", None) is not None:
@@ -256,9 +273,25 @@ class VFM(nn.Module):
         return out
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Loaded weights are CURRENT by definition: whatever the lazy / look-ahead step forms still owed the old rows
+        (skipped zero-gradient updates) is dropped, not replayed on top of the restored values; derived caches
+        (sample records of the pipelined step, the packed first-order records) are re-made on demand."""
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
         self._tie()
+        self._forget_derived_state()
         return out
+
+    def _forget_derived_state(self):
+        """The parameters were written from outside the step kernels (load_state_dict, a checkpoint, a direct write the
+        caller announces with `params_changed()`): no row lags any more and nothing derived from the old values is valid."""
+        self._lazy_dirty, self._lazy_kind, self._la_ready_for, self._zrec_for = False, None, None, None
+        self._wrec_ok = False
+
+    def params_changed(self):
+        """Call after writing `entity_params.weight` / `bias_params.weight` / the scalars directly (e.g. through `.data`).
+        Between steps of the lazy step forms the tables LAG (rows a batch skipped have not had their zero-gradient
+        updates yet): read them through `state_dict()` / `sync_lazy()` first, which bring every row up to date."""
+        self._forget_derived_state()
 
     # ------------------------------------------------------------------ checkpoint / resume
     def training_state_dict(self, sync: bool = True):
@@ -294,8 +327,8 @@ class VFM(nn.Module):
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
-            self._lazy_last, self._lazy_dirty, self._lazy_lr = None, False, {}
-            self._lazy_kind = self._la_ready_for = None
+            self._lazy_last, self._lazy_lr = None, {}
+        self._forget_derived_state()          # (with or without optimiser state: the restored rows are current)
         if getattr(self, "_dims", None) is not None:
             self._dims.scatter(self)
         if state.get("snapshots") is not None:
@@ -324,6 +357,8 @@ class VFM(nn.Module):
         if self.nb_occ.numel() != self.T:
             raise ValueError("nb_occ must have one entry per entity")
         self.inv_occ = ops.inv_occ_from_counts(self.nb_occ)
+        self._wrec_ok = False
+        self._graphs = {}                  # (captured steps hold the old inv_occ pointer)
 
     def plan(self, x, y=None, B_global=None, build_index=True, process_group=None, defer_readback=False) -> ops.BatchPlan:
         x = torch.as_tensor(x).to(self.device)
@@ -364,6 +399,7 @@ class VFM(nn.Module):
         """Differentiable ELBO loss of one batch: `-log_prob(y).mean()*nb_train + kl`
         (vfm-torch.py:353-359).  Returns (loss[1], pred[B], detail[3] = loss, nll, kl)."""
         self._fresh_params()      # sharded training modes: collective, every rank calls it
+        self._wrec_ok = False     # (the caller's optimiser writes the parameters: the packed records go stale)
         if plan is None:
             plan = self.plan(x, y)
         step = self.global_step
@@ -442,7 +478,7 @@ class VFM(nn.Module):
             ent, bia, _ = self._views(self._flat)
             k = (upto - 1) % ops.MOMENT_PERIOD + 1 if upto > 0 else 0
             ops.adam_catchup(ent, bia, self._views(self._adam_m), self._views(self._adam_v), self._lazy_last, None,
-                             self._lazy_lrs(k), upto=upto, mark=upto)
+                             self._lazy_lrs(k), upto=upto, mark=upto, wrec=self._wrec if self._wrec_ok else None)
             self._lazy_dirty, self._lazy_kind, self._la_ready_for = False, None, None
 
     def _lazy_lrs(self, kmax):
@@ -458,6 +494,15 @@ class VFM(nn.Module):
         if not self.lookahead:
             return False
         return (1.0 - plan.U / self.T) * (1.0 - next_plan.U / self.T) >= self.lookahead_min_skip
+
+    def _will_pipeline(self, plan, next_plan) -> bool:
+        """The rule train_step applies for the software-pipelined step form in steady state."""
+        if not self.pipeline or self.sparse_adam or not ops.pipeline_supported(plan.spec):
+            return False
+        if self.pipeline is True:
+            return True
+        return (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T
+                and next_plan.B >= self.pipeline_ratio * next_plan.U and plan.B >= self.pipeline_ratio * plan.U)
 
     def _use_lazy(self, plan) -> bool:
         if self.lazy_adam is True:
@@ -498,6 +543,8 @@ class VFM(nn.Module):
     def _set_moment_form(self, scaled: bool):
         """Bring _adam_m / _adam_v into the scaled / plain form (a no-op unless the form changes)."""
         if self._adam_m is not None and scaled != self._moments_scaled:
+            if self._lazy_dirty:          # lagging rows replay with the constants of the form they were skipped in
+                self.sync_lazy()
             ops.moments_rescale(self._adam_m, self._adam_v, self._adam_t, to_scaled=scaled)
         self._moments_scaled = bool(scaled)
 
@@ -572,6 +619,7 @@ class VFM(nn.Module):
         flags = prior_terms_flag(rank)
         step = self.global_step
         self.global_step += 1
+        marking = mark is not None
         mark = mark or (lambda name: None)      # bench.py records HIP events at these points
         mark("start")
         sumz, grow, pred = self._step_buffers(plan.B)
@@ -580,6 +628,8 @@ class VFM(nn.Module):
         fused = fused and adam and process_group is None
         lazy = rows = None
         la = False
+        # the packed first-order records: kept coherent by the fused single-rank step alone (every other step form drops them)
+        wrec = self._wrec_for_step(fused and eps is None and self.n_samples == 1 and not self.sparse_adam)
         if fused:
             scaled = self.scaled_moments and not self.sparse_adam
             self._set_moment_form(scaled)
@@ -592,6 +642,9 @@ class VFM(nn.Module):
                   and next_plan is not None and next_plan.y is not None and next_plan.spec.T == self.T
                   and self._lookahead_pays(plan, next_plan))
             lazy = scaled and not la and self.n_samples >= 1 and self._use_lazy(plan)
+            # may this step be a replayed graph?  (no per-kernel events, no caller-owned buffers, Philox eps)
+            may_replay = (self.replay is True and not marking and eps is None and out_pred is None and self.n_samples == 1
+                          and not self.sparse_adam)
             if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
                     and out_pred is None and ops.pipeline_supported(plan.spec)
                     and (self.pipeline is True or (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T))):
@@ -600,11 +653,12 @@ class VFM(nn.Module):
                 if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
                     nxt = None                # too few rows per entity for the records to pay: do not prepare them
                 if ready or (nxt is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
-                    return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark)
+                    return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay)
             if k == 1:
                 self._lazy_lr = {}
             self._lazy_lr[k] = float(lr)
             kind = "list" if lazy else ("la" if la else None)
+            caught_up = False                # a catch-up pass ran in front of this step: not a replayable launch sequence
             if self._lazy_dirty and kind != self._lazy_kind:
                 self.sync_lazy(self._adam_t - 1)      # another step form than the one that let rows lag: all rows current first
             if kind is not None:
@@ -616,8 +670,9 @@ class VFM(nn.Module):
                 if lazy and k < ops.MOMENT_PERIOD:
                     # rows of this batch: replay what they skipped, they get step _adam_t below; the others wait
                     ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
-                                     upto=self._adam_t - 1, mark=self._adam_t)
+                                     upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
                     rows, self._lazy_dirty, self._lazy_kind = "touched", True, "list"
+                    caught_up = True
                     mark("catchup")
                 elif la:
                     if self._la_tab is None:
@@ -626,39 +681,59 @@ class VFM(nn.Module):
                     if self._lazy_dirty and not (ready is not None and ready[0] is plan and ready[1] == self._adam_t - 1):
                         # this batch was not the one announced to the previous step: bring its rows up to date now
                         ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
-                                         upto=self._adam_t - 1, mark=self._adam_t - 1)
+                                         upto=self._adam_t - 1, mark=self._adam_t - 1, wrec=wrec)
                         mark("catchup")
                 else:
                     # last step of a moment period (the dense kernel rewrites every row's moments): every row up to
                     # date first, then the ordinary dense step
                     ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, None, self._lazy_lrs(k - 1),
-                                     upto=self._adam_t - 1, mark=self._adam_t)
+                                     upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
                     self._lazy_dirty = False
                     mark("catchup")
             elif self._lazy_dirty:
                 self.sync_lazy(self._adam_t - 1)
+
+            def launch(dev):
+                """The launches of the fused step (forward, then loss + backward + dense Adam in ONE kernel: the gradient
+                rows never reach HBM).  dev: None = step-dependent values as host arguments; else the device step state."""
+                st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
+                                      train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
+                                      out_sumz=sumz, out_grow=grow, out_partials=self._partials, wrec=wrec, dev_step=dev)
+                mark("fwd")
+                if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
+                    ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
+                                                     self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
+                                                     loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list,
+                                                     wrec=wrec, dev_step=dev)
+                else:
+                    ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                           self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
+                                           sparse=self.sparse_adam, scaled_moments=scaled, rows=rows, wrec=wrec, dev_step=dev)
+                mark("bwd_adam")
+                return st.pred
+
+            if may_replay and not caught_up and not lazy:
+                plan.index_tensors()                  # (deferred index readbacks: not inside a capture)
+                if la:
+                    next_plan.index_tensors()
+                    if self.lookahead_list:
+                        plan.lookahead_rows(next_plan)
+                key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled), wrec is not None,
+                       self.lookahead_list if la else None)
+                out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, sumz, grow, pred))
+            else:
+                self._eager_step_ran()
+                out = launch(None)
+            if la:
+                self._lazy_dirty, self._lazy_kind = True, "la"
+                self._la_ready_for = (next_plan, self._adam_t)
+            return loss3, out
         elif self._lazy_dirty:
             self.sync_lazy()
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
                               train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
         mark("fwd")
-        if fused and la:
-            # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
-            ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                             self._views(self._adam_v), lr, self._adam_t, loss3, self._lazy_last, self._la_tab,
-                                             listed=self.lookahead_list)
-            self._lazy_dirty, self._lazy_kind = True, "la"
-            self._la_ready_for = (next_plan, self._adam_t)
-            mark("bwd_adam")
-            return loss3, st.pred
-        if fused:
-            # loss + backward + dense Adam in ONE kernel: the gradient rows never reach HBM
-            ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                   self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                   sparse=self.sparse_adam, scaled_moments=scaled, rows=rows)
-            mark("bwd_adam")
-            return loss3, st.pred
         stats = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
         self._set_moment_form(self.scaled_moments and stats)     # (the flat k_adam of the other paths: plain form)
         if stats:
@@ -701,11 +776,58 @@ class VFM(nn.Module):
             mark("adam")
         return loss3, st.pred
 
+    def _wrec_for_step(self, keep: bool):
+        """The packed first-order records for a step that keeps them coherent (None: this step form does not -- they are
+        dropped and rebuilt by the next step that does)."""
+        if not (keep and self.use_wrec and self.d % 4 == 0 and 16 <= self.d <= 512):
+            self._wrec_ok = False
+            return None
+        _, bia, _ = self._views(self._flat)
+        if self._wrec is None:
+            self._wrec = torch.empty(self.T, 4, dtype=torch.float32, device=self.device)
+            self._wrec_ok = False
+        if not self._wrec_ok:
+            ops.wrec_build(bia, self.inv_occ, self._wrec)
+            self._wrec_ok = True
+        elif _CHECK_WREC:          # debug (VFM_CHECK_WREC=1, the state-machine fuzz): the cache IS the two tables
+            assert torch.equal(self._wrec[:, :2], bia) and torch.equal(self._wrec[:, 2], self.inv_occ), "stale packed records"
+        return self._wrec
+
+    def _eager_step_ran(self):
+        """A step with host-side constants ran: the device-resident counters (if any) no longer match."""
+        if self._step_state is not None:
+            self._step_state.counters = None
+
+    def _replay(self, key, launch, step, lr, scaled, keep=()):
+        """Run `launch(dev_step)` as a captured HIP graph: captured the first time `key` is seen (the launches then read
+        the Philox step and the Adam constants from device memory), replayed afterwards.  The device counters are set to
+        this step's (Philox step, Adam step) whenever something else ran in between."""
+        st8 = self._step_state
+        if st8 is None:
+            st8 = self._step_state = ops.StepState(self.device)
+        st8.cover(self._adam_t, lr, 0.9, 0.999, 1e-8, scaled)
+        hit = self._graphs.get(key, 0)
+        if hit == 0:                # first sight of this launch sequence: run it eagerly (warm-up: lazily made buffers,
+            if len(self._graphs) >= 4096:                                  # streams, the allocator), capture it next time
+                self._graphs.clear()
+            self._graphs[key] = None
+            self._eager_step_ran()
+            return launch(None)
+        if hit is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = launch(st8.dev)
+            hit = self._graphs[key] = (g, out, keep)          # (keep: whatever the captured pointers belong to)
+        st8.set(step, self._adam_t)
+        hit[0].replay()
+        st8.advanced()
+        return hit[1]
+
     def _records_ready(self, plan, step) -> bool:
         f = self._zrec_for
         return f is not None and f[0] is plan and f[1] == step and f[2] == self._flat._version
 
-    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark):
+    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark, wrec=None, may_replay=False):
         """The fused step with the sampling of the NEXT batch moved into this step's backward (see __init__)."""
         ent, bia, scal = self._views(self._flat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
@@ -713,24 +835,39 @@ class VFM(nn.Module):
             rl = ops.record_len(self.d)
             self._zrec = [torch.zeros(self.T, rl, dtype=torch.float32, device=self.device) for _ in range(2)]
         cur, nxt = self._zrec
-        if not self._records_ready(plan, step):       # first step of a run (or the tables changed since): from the tables
+        fresh = not self._records_ready(plan, step)
+        if fresh:                                     # first step of a run (or the tables changed since): from the tables
             ops.sample_records(plan, ent, bia, self.inv_occ, cur, self.rng_seed, step)
             mark("sample_rec")
         _, grow, pred = self._step_buffers(plan.B)
-        st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials)
-        mark("fwd")
         if next_plan is not None and (next_plan.spec.T != self.T or next_plan.y is None):
             next_plan = None
-        ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
-                                    self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
-                                    scaled_moments=scaled)
-        mark("bwd_adam")
+
+        def launch(dev):
+            st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials, dev_step=dev)
+            mark("fwd")
+            ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
+                                        self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
+                                        scaled_moments=scaled, wrec=wrec, dev_step=dev)
+            mark("bwd_adam")
+            return st.pred
+
+        if may_replay and not fresh:
+            plan.index_tensors()                      # (deferred index readbacks: not inside a capture)
+            if next_plan is not None:
+                next_plan.index_tensors()
+            key = ("pipe", id(plan), id(next_plan) if next_plan is not None else 0, cur.data_ptr(), bool(scaled),
+                   wrec is not None)
+            out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, cur, nxt, grow, pred))
+        else:
+            self._eager_step_ran()
+            out = launch(None)
         if next_plan is not None:
             self._zrec = [nxt, cur]
             self._zrec_for = (next_plan, step + 1, self._flat._version)
         else:
             self._zrec_for = None
-        return loss3, st.pred
+        return loss3, out
 
     def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,
             y_test=None, display_every: int = 1, lr: Optional[float] = None, verbose: bool = True,
@@ -766,10 +903,15 @@ class VFM(nn.Module):
             plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group,
                                    defer_readback=True))      # (the index builds are enqueued back to back)
             spans.append((a, b))
-        if world == 1 and self.lookahead and self.lookahead_list and len(plans) > 1:
-            for i, plan in enumerate(plans):              # row lists of the look-ahead step, once per pair of batches
-                plan.prepare_lookahead(plans[(i + 1) % len(plans)])
+        if world == 1 and self.lookahead and self.lookahead_list and len(plans) > 1 and self.n_samples == 1:
+            for i, plan in enumerate(plans):              # row lists of the look-ahead step, once per pair of batches --
+                nxt = plans[(i + 1) % len(plans)]         # only where that step form will run (U: one deferred readback)
+                if self._lookahead_pays(plan, nxt) and not self._will_pipeline(plan, nxt):
+                    plan.prepare_lookahead(nxt)
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
+        replay_before = self.replay
+        if self.replay == "auto":
+            self.replay = world == 1          # one captured graph per (batch, next batch) pair, replayed every epoch
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
         for epoch in range(n_epochs):
@@ -811,6 +953,9 @@ class VFM(nn.Module):
                           (f"Minibatch train RMSE {rec['train_rmse']:.4f}" if self.output == "reg" else
                            f"Minibatch train AUC {rec['train_auc']:.4f} Minibatch train MAP {rec['train_map']:.4f}"),
                           rec.get("test", ""))
+        self.replay = replay_before
+        if self._step_state is not None and self._step_state.error():
+            raise RuntimeError("a replayed training step found no entry for its Adam step in the device table")
         self.sync_lazy()          # (lazy Adam mode: every row up to date before the caller looks at the tables)
         return hist
 

@@ -66,8 +66,12 @@ class Spec:
 
 
 def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, step: int = 0,
-             flags: int = 0) -> Problem:
+             flags: int = 0, wrec=None, dev_step=None) -> Problem:
     p = Problem()
+    if wrec is not None:
+        p.wrec = wrec.data_ptr()
+    if dev_step is not None:
+        p.dev_step = dev_step.data_ptr()
     p.B, p.B_global, p.T, p.nb_train = B, B_global, spec.T, spec.nb_train
     p.F, p.d, p.likelihood, p.id_bits = spec.F, spec.d, spec.likelihood, id_bits
     p.n_samples, p.flags = int(spec.n_samples), flags | spec.link_flag
@@ -268,7 +272,7 @@ class BatchPlan:
             if hit[2] is not None:               # deferred count: first use
                 host, done = hit[2]
                 done.synchronize()
-                pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())], None)
+                pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())].clone(), None)      # (frees the upper-bound buffer)
             return pairs[id(next_plan)][1]
         self.prepare_lookahead(next_plan)
         return self.lookahead_rows(next_plan)
@@ -322,7 +326,7 @@ class FwdState:
 
 def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, *, eps=None,
                  seed=0, step=0, train=True, flags=0, out_pred=None, out_sumz=None,
-                 out_grow=None, out_partials=None) -> FwdState:
+                 out_grow=None, out_partials=None, wrec=None, dev_step=None) -> FwdState:
     """Launch vfm_elbo_fwd_f32 on the current stream.  `eps` = (eps_entity[T,d], eps_bias[T],
     eps_global[1]) tables indexed by entity id ([S,T,d], [S,T], [S] with S = spec.n_samples > 1), or
     None for the in-kernel Philox stream."""
@@ -348,7 +352,8 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
     _lib.ops().elbo_fwd(plan.x, plan.y, entity_params, bias_params, inv_occ if have_y else None, scalars,
                         plan.W if have_y else None, e[0], e[1], e[2], pred, partials, sumz, grow,
                         list(spec.group_hi), list(spec.group_n), spec.nb_train, plan.B_global,
-                        spec.likelihood, p.flags, p.seed & _I63, p.step, S, spec.coord_off)
+                        spec.likelihood, p.flags, p.seed & _I63, p.step, S, spec.coord_off,
+                        wrec if (train and eps is None) else None, dev_step)
     return FwdState(pred, partials, sumz, grow, p, eps)
 
 
@@ -383,7 +388,7 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
 
 def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params, scalars, inv_occ,
                        m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, loss_out=None,
-                       sparse=False, scaled_moments=False, rows=None):
+                       sparse=False, scaled_moments=False, rows=None, wrec=None, dev_step=None):
     """Launch vfm_elbo_bwd_adam_f32: backward + dense Adam in one kernel (single rank).
     m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
     work of elbo_finalize in the same launch.  `scaled_moments`: the buffers are in the scaled form of
@@ -404,7 +409,7 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              p.flags | (FLAG_SPARSE_ADAM if sparse else 0) |
                              (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples,
-                             p.coord_off)
+                             p.coord_off, wrec, dev_step)
 
 
 FLAG_ZREC = 1024
@@ -429,10 +434,10 @@ def sample_records(plan: BatchPlan, entity_params, bias_params, inv_occ, zrec, s
           "vfm_sample_records_f32")
 
 
-def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, out_grow, out_partials) -> FwdState:
+def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, out_grow, out_partials, dev_step=None) -> FwdState:
     """The forward of the pipelined step (VFM_FLAG_ZREC): a gather of this step's sample records; no sumz."""
     spec = plan.spec
-    p = _problem(spec, plan.B, plan.B_global, plan.id_bits, seed, step, FLAG_ZREC)
+    p = _problem(spec, plan.B, plan.B_global, plan.id_bits, seed, step, FLAG_ZREC, dev_step=dev_step)
     check(_lib.load().vfm_elbo_fwd_f32(C.byref(p), ptr(plan.x), ptr(plan.y), ptr(zrec), None, None, ptr(scalars), None,
                                        None, None, None, ptr(out_pred), ptr(out_partials), None, ptr(out_grow),
                                        current_stream_ptr(zrec.device)), "vfm_elbo_fwd_f32 (records)")
@@ -442,7 +447,7 @@ def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, o
 
 def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next_plan, next_step, entity_params,
                             bias_params, scalars, inv_occ, m_views, v_views, lr, step, loss_out, beta1=0.9, beta2=0.999,
-                            eps_adam=1e-8, scaled_moments=True):
+                            eps_adam=1e-8, scaled_moments=True, wrec=None, dev_step=None):
     """vfm_elbo_bwd_adam_pipe_f32: loss + backward + dense Adam, gathering samples from `zrec`, and (next_plan given)
     writing the records of `next_plan`'s entities for Philox step `next_step` into `zrec_next`."""
     t = plan.index_tensors()
@@ -461,6 +466,8 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
         pipe.next_step = int(next_step)
     p = st.problem
     p.flags = plan.spec.link_flag | (FLAG_SCALED_MOMENTS if scaled_moments else 0)
+    p.wrec = wrec.data_ptr() if wrec is not None else None
+    p.dev_step = dev_step.data_ptr() if dev_step is not None else None
     check(_lib.load().vfm_elbo_bwd_adam_pipe_f32(
         C.byref(p), C.byref(ix), C.byref(pipe), ptr(entity_params), ptr(bias_params), ptr(scalars), ptr(inv_occ),
         ptr(plan.W), ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
@@ -470,7 +477,7 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
 
 def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: BatchPlan, entity_params, bias_params,
                                  scalars, inv_occ, m_views, v_views, lr, step, loss_out, last_step, step_tab,
-                                 beta1=0.9, beta2=0.999, eps_adam=1e-8, listed=True):
+                                 beta1=0.9, beta2=0.999, eps_adam=1e-8, listed=True, wrec=None, dev_step=None):
     """vfm_elbo_bwd_adam_lookahead_f32: the fused dense step visiting only the rows of this batch and of the next
     (listed: as a list made once per pair of plans; else the kernel classifies all T rows itself)."""
     t = plan.index_tensors()
@@ -487,6 +494,8 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
         next_plan.build_index()
     p = st.problem
     p.flags = plan.spec.link_flag | FLAG_SCALED_MOMENTS
+    p.wrec = wrec.data_ptr() if wrec is not None else None
+    p.dev_step = dev_step.data_ptr() if dev_step is not None else None
     check(_lib.load().vfm_elbo_bwd_adam_lookahead_f32(
         C.byref(p), C.byref(ix), ptr(entity_params), ptr(bias_params), ptr(scalars), ptr(inv_occ), ptr(plan.W),
         ptr(st.sumz), ptr(st.grow), ptr(st.partials), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]),
@@ -497,16 +506,68 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
 
 
 def adam_catchup(entity_params, bias_params, m_views, v_views, last_step, ids, lr_of_step, upto, mark,
-                 beta1=0.9, beta2=0.999, eps_adam=1e-8):
+                 beta1=0.9, beta2=0.999, eps_adam=1e-8, wrec=None):
     """Launch vfm_adam_catchup_f32 (lazy exact dense Adam): replay the skipped zero-gradient updates of steps
     last_step[e]+1 .. upto on the rows `ids` (int32 tensor; None = all rows), then stamp them with `mark`."""
     T, d = entity_params.shape[0], entity_params.shape[1] // 2
     n = T if ids is None else ids.numel()
-    lrs = (C.c_float * max(len(lr_of_step), 1))(*[float(v) for v in lr_of_step])
+    need = (int(upto) - 1) % MOMENT_PERIOD + 1 if upto > 0 else 0     # steps of upto's moment period, up to upto
+    vals = [float(v) for v in lr_of_step] + [0.0] * max(0, need - len(lr_of_step))    # (placeholders: never replayed --
+    lrs = (C.c_float * max(len(vals), 1))(*vals)                                        #  every row is past those steps)
     check(_lib.load().vfm_adam_catchup_f32(ptr(entity_params), ptr(bias_params), ptr(m_views[0]), ptr(v_views[0]),
                                            ptr(m_views[1]), ptr(v_views[1]), ptr(last_step), ptr(ids), n, T, d, lrs,
-                                           beta1, beta2, eps_adam, int(upto), int(mark),
+                                           len(vals), beta1, beta2, eps_adam, int(upto), int(mark), ptr(wrec),
                                            current_stream_ptr(entity_params.device)), "vfm_adam_catchup_f32")
+
+
+def wrec_build(bias_params, inv_occ, wrec):
+    """vfm_wrec_build_f32: the packed first-order records (mu_w, s_w, 1/occ, 0) of every entity (vfm_problem_t.wrec)."""
+    check(_lib.load().vfm_wrec_build_f32(ptr(bias_params), ptr(inv_occ), bias_params.shape[0], ptr(wrec),
+                                         current_stream_ptr(wrec.device)), "vfm_wrec_build_f32")
+
+
+class StepState:
+    """Device-resident step state (`vfm_dev_step_t` + its table of per-step Adam constants): what lets a captured HIP
+    graph of a training step be REPLAYED -- the kernels read the Philox step and the Adam constants from here and
+    advance the counters themselves (include/vfm_hip.h).  The table is filled on the host by `vfm_step_consts` (the
+    arithmetic of the host-argument path, so a replayed trajectory is bitwise the eager one)."""
+    WINDOW = 4096          # Adam steps per table fill
+
+    def __init__(self, device):
+        self.dev = torch.zeros(8, dtype=torch.int64, device=device)                   # vfm_dev_step_t
+        self.tab = torch.zeros(self.WINDOW, 16, dtype=torch.float32, device=device)   # vfm_step_consts_t [WINDOW]
+        self.first, self.length, self.key = 0, 0, None
+        self.counters = None             # (philox_step, adam_step) the device holds if every launch since was a replay
+
+    def cover(self, adam_step: int, lr: float, beta1: float, beta2: float, eps: float, scaled: bool):
+        """Make sure the table holds the constants of `adam_step` (the next update) for these hyper-parameters."""
+        key = (float(lr), float(beta1), float(beta2), float(eps), bool(scaled))
+        if key == self.key and self.first <= adam_step < self.first + self.length:
+            return
+        lib = _lib.load()
+        host = (_lib.StepConsts * self.WINDOW)()
+        for i in range(self.WINDOW):
+            check(lib.vfm_step_consts(key[0], key[1], key[2], key[3], adam_step + i, int(scaled), C.byref(host[i])),
+                  "vfm_step_consts")
+        raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.float32).view(self.WINDOW, 16)
+        self.tab.copy_(raw)               # (synchronous copy from pageable memory: the host buffer may go right after)
+        hdr = _lib.DevStep()
+        hdr.tab_first, hdr.tab_len, hdr.tab = adam_step, self.WINDOW, self.tab.data_ptr()
+        self.dev.copy_(torch.frombuffer(bytearray(bytes(hdr)), dtype=torch.int64))
+        self.first, self.length, self.key, self.counters = adam_step, self.WINDOW, key, None
+
+    def set(self, philox_step: int, adam_step: int):
+        if self.counters != (philox_step, adam_step):
+            check(_lib.load().vfm_dev_step_set(ptr(self.dev), int(philox_step), int(adam_step),
+                                               current_stream_ptr(self.dev.device)), "vfm_dev_step_set")
+            self.counters = (philox_step, adam_step)
+
+    def advanced(self):
+        """A replayed step ran: the kernels moved both counters on by one."""
+        self.counters = (self.counters[0] + 1, self.counters[1] + 1)
+
+    def error(self) -> bool:
+        return bool(int(self.dev[7].item()))
 
 
 def exchange_record_len(d: int) -> int:
