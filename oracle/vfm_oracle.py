@@ -58,15 +58,20 @@ def make_params(T, d, dtype=torch.float32, seed=42, alpha=None):
 TORCH_LINKS = {"abs": torch.abs, "softplus": torch.nn.functional.softplus}     # vfm-torch.py:126 / :125
 
 
-def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None, n_samples=1, link="abs"):
+def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None, n_samples=1, link="abs", dead_gathers=False):
     """One `CF.forward` (vfm-torch.py:189-324) with S = n_samples variational samples
     (the reference's global N_VARIATIONAL_SAMPLES, :19) and `link` = its global LINK (:125-126).
 
     eps: None -> draw with rsample exactly like the reference (RNG order eps0[S,1],
     eps_w[S,U], eps_v[S,U,d] over the SORTED unique ids); or a tuple
     (eps0[S], eps_w[S,U], eps_v[S,U,d]) (S = 1: the leading axis may be absent) to replay
-    recorded draws.  Returns (likelihood distribution with batch shape [S,B], kl_term[1])."""
+    recorded draws.  dead_gathers: also perform the reference's two unused per-row lookups (`bias_batch`,
+    `entity_batch`, vfm-torch.py:204-205: [B,2,2] and [B,2,2d], never read) -- the timing baseline pays what the
+    reference pays.  Returns (likelihood distribution with batch shape [S,B], kl_term[1])."""
     LINK, S = TORCH_LINKS[link], int(n_samples)
+    if dead_gathers:
+        _bias_batch = torch.nn.functional.embedding(x, P["bias_params"])        # noqa: F841  (as the reference: unused)
+        _entity_batch = torch.nn.functional.embedding(x, P["entity_params"])    # noqa: F841
     uniq, pos, cnt = torch.unique(x, return_inverse=True, return_counts=True)
     users, cnt_u = torch.unique(x[:, 0], return_counts=True)
     items, cnt_i = torch.unique(x[:, 1], return_counts=True)
@@ -103,16 +108,17 @@ def reference_shaped_forward(P, x, nb_occ, N, M, output="reg", eps=None, n_sampl
     return lik, distributions.kl_divergence(q0, prior) + kl
 
 
-def reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output="reg", eps=None, n_samples=1, link="abs"):
-    lik, kl = reference_shaped_forward(P, x, nb_occ, N, M, output, eps, n_samples, link)
+def reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output="reg", eps=None, n_samples=1, link="abs",
+                          dead_gathers=False):
+    lik, kl = reference_shaped_forward(P, x, nb_occ, N, M, output, eps, n_samples, link, dead_gathers)
     loss = -lik.log_prob(y.to(kl.dtype)).mean() * nb_train + kl          # vfm-torch.py:359
     return loss, lik, kl
 
 
 def reference_shaped_step(P, opt, x, y, nb_occ, N, M, nb_train, output="reg", eps=None, n_samples=1,
-                          link="abs"):
+                          link="abs", dead_gathers=False):
     """forward + loss + backward + optimiser step (vfm-torch.py:353-370)."""
-    loss, lik, _ = reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output, eps, n_samples, link)
+    loss, lik, _ = reference_shaped_loss(P, x, y, nb_occ, N, M, nb_train, output, eps, n_samples, link, dead_gathers)
     opt.zero_grad()
     loss.backward()
     opt.step()

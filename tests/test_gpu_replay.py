@@ -101,15 +101,15 @@ def test_packed_first_order_records_do_not_change_the_trajectory(monkeypatch):
 
 
 def test_fit_replays_and_matches_the_eager_fit():
-    """VFM.fit with replay (the default: one graph per (batch, next batch) pair, replayed every epoch) == the same fit
-    with replay off: history, parameters, the epoch-averaged snapshots, the predictors."""
+    """VFM.fit with replay on (one graph per (batch, next batch) pair, replayed every epoch) == the same fit with
+    replay off (the default): history, parameters, the epoch-averaged snapshots, the predictors."""
     from vae_amd.model import VFM
     from vae_amd.data import synthetic_triples
     sizes = (943, 1682)
     X, y = synthetic_triples(list(sizes), 6000, seed=9, device="cuda")
     Xt, yt = synthetic_triples(list(sizes), 500, seed=10, device="cuda")
     runs = []
-    for replay in (False, "auto"):
+    for replay in (False, True):
         torch.manual_seed(5)
         m = VFM(sizes[0], sizes[1], 20, device="cuda", rng_seed=3)
         m.replay = replay
@@ -119,7 +119,7 @@ def test_fit_replays_and_matches_the_eager_fit():
     assert [k for k, v in m1._graphs.items() if v is not None] and not m0._graphs
     assert h0["elbo"] == h1["elbo"] and h0["train_rmse"] == h1["train_rmse"] and h0["test"] == h1["test"]
     assert torch.equal(m0._flat, m1._flat) and torch.equal(m0._mean_flat, m1._mean_flat)
-    assert m1.replay == "auto"
+    assert m1.replay is True and m0.replay is False
 
 
 def test_replay_survives_a_checkpoint_round_trip():

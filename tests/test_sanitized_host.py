@@ -1,0 +1,91 @@
+"""CPU: the HOST side of the native code under AddressSanitizer + UndefinedBehaviorSanitizer ("ASan
+build of the CPU launcher tests").  `vae_amd.build.build_sanitized()` compiles csrc/*.hip with `-Xarch_host
+-fsanitize=address,undefined` (device code objects as usual: GPU sanitizers are not available on this pool) and the
+TORCH_LIBRARY shim with the same runtime; the ABI tests of tests/test_abi_cpu.py -- every entry point's argument checks,
+the struct mirrors, the host-side step-constant tables -- then run against those libraries in a child python with the
+ASan runtime preloaded.  A second child proves the harness is live: a caller that lies about the length of a host table
+makes the library read past it, and the sanitizer must say so."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(outdir, rt):
+    env = dict(os.environ)
+    env.update(VFM_LIB_DIR=outdir, LD_PRELOAD=rt, PYTHONMALLOC="malloc",      # (ctypes buffers become real heap blocks)
+               ASAN_OPTIONS="detect_leaks=0:exitcode=77:abort_on_error=0:detect_odr_violation=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    return env
+
+
+@pytest.fixture(scope="module")
+def sanitized():
+    if os.environ.get("VFM_SKIP_SANITIZER"):
+        pytest.skip("VFM_SKIP_SANITIZER set")
+    from vae_amd import build as B
+    rt = B.sanitizer_runtime()
+    if rt is None:
+        pytest.skip("no shared ASan runtime next to hipcc")
+    return B.build_sanitized(), rt
+
+
+def test_abi_tests_run_clean_under_asan_and_ubsan(sanitized):
+    outdir, rt = sanitized
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_abi_cpu.py"), "-q", "-x",
+                        "-p", "no:cacheprovider"], env=_env(outdir, rt), capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, r.stderr[-4000:]
+
+
+HOST_EXERCISE = r"""
+import ctypes as C
+from vae_amd import _lib
+lib = _lib.load()
+assert "build/san" in _lib.LIB_PATH
+# host-only arithmetic with valid arguments: the step-constant table as ops.StepState fills it, the size helpers
+tab = (_lib.StepConsts * 4096)()
+for i in range(4096):
+    assert lib.vfm_step_consts(0.01, 0.9, 0.999, 1e-8, 1 + i, 1, C.byref(tab[i])) == 0
+assert tab[127].store_true == 1 and tab[128].k == 1
+assert lib.vfm_index_workspace_bytes(100000, 2, 165237) > 0 and lib.vfm_union_workspace_bytes(165237) > 0
+assert lib.vfm_variant_workspace_elems(1000, 3, 16) > 0 and lib.vfm_heavy_list_for(200000, 165237) == 64
+p = _lib.Problem()
+p.B, p.B_global, p.T, p.F, p.d, p.id_bits, p.n_samples = 8, 8, 100, 64, 256, 64, 1
+for g in range(64):
+    p.group_hi[g], p.group_n[g] = g + 1, 1.0
+# every entry point that takes the problem: argument errors, never a crash
+for name, n in (("vfm_elbo_fwd_f32", 15), ("vfm_elbo_bwd_f32", 17), ("vfm_elbo_finalize_f32", 4), ("vfm_batch_norms", 4),
+                ("vfm_elbo_bwd_acc_f32", 7), ("vfm_elbo_lik_f32", 7), ("vfm_philox_eps_f32", 4)):
+    assert getattr(lib, name)(C.byref(p), *([None] * n)) != 0, name
+    assert len(lib.vfm_last_error()) > 0
+print("host exercise ok")
+"""
+
+LYING_CALLER = r"""
+import ctypes as C
+from vae_amd import _lib
+lib = _lib.load()
+lr = (C.c_float * 1)(0.1)                 # ONE learning rate ...
+one = 0x1000
+# ... and a caller that claims 200: the library trusts n_lr and reads lr[1..71] -- a heap over-read ASan must report
+lib.vfm_adam_catchup_f32(one, one, one, one, one, one, one, None, 10, 10, 8, lr, 200, 0.9, 0.999, 1e-8, 200, 200, None, None)
+print("not detected")
+"""
+
+
+def test_host_arithmetic_and_error_paths_under_the_sanitizers(sanitized):
+    outdir, rt = sanitized
+    r = subprocess.run([sys.executable, "-c", HOST_EXERCISE], env=_env(outdir, rt), capture_output=True, text=True, cwd=ROOT,
+                       timeout=600)
+    assert r.returncode == 0 and "host exercise ok" in r.stdout, (r.stdout[-1000:], r.stderr[-4000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr
+
+
+def test_the_sanitizer_harness_detects_a_host_over_read(sanitized):
+    outdir, rt = sanitized
+    r = subprocess.run([sys.executable, "-c", LYING_CALLER], env=_env(outdir, rt), capture_output=True, text=True, cwd=ROOT,
+                       timeout=600)
+    assert "not detected" not in r.stdout and "AddressSanitizer" in r.stderr and "vfm_adam_catchup_f32" in r.stderr, r.stderr[-3000:]

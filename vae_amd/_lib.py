@@ -13,8 +13,10 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvfm_hip.so")
-OPS_PATH = os.path.join(HERE, "libvfm_torch_ops.so")
+# VFM_LIB_DIR: another build of the two libraries (the host-sanitizer build of vae_amd.build.build_sanitized)
+LIB_DIR = os.environ.get("VFM_LIB_DIR") or HERE
+LIB_PATH = os.path.join(LIB_DIR, "libvfm_hip.so")
+OPS_PATH = os.path.join(LIB_DIR, "libvfm_torch_ops.so")
 
 ABI_VERSION = 4
 MAX_FWD_BLOCKS = 4096

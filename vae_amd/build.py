@@ -102,6 +102,70 @@ def build_torch_ops(force=False, verbose=False):
     return out
 
 
+def sanitizer_runtime():
+    """ROCm clang's shared ASan runtime (LD_PRELOAD it into an uninstrumented python to load the sanitized libraries)."""
+    out = subprocess.run([HIPCC, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def build_sanitized(force=False, verbose=False):
+    """The HOST side of both libraries under AddressSanitizer + UndefinedBehaviorSanitizer (`-Xarch_host
+    -fsanitize=address,undefined`: the device code objects are the ordinary ones -- GPU sanitizers are not available on
+    this pool), into vae_amd/build/san/.  What it covers: the argument checks, struct handling, host-side tables and
+    launch set-up of csrc/vfm_abi.hip / vfm_index.hip / vfm_variants.hip and the TORCH_LIBRARY shim.  Load it with
+    VFM_LIB_DIR=<returned dir> and LD_PRELOAD=sanitizer_runtime() (tests/test_sanitized_host.py does)."""
+    import torch
+    csrc = os.path.join(HERE, "csrc")
+    outdir = os.path.join(HERE, "build", "san")
+    os.makedirs(outdir, exist_ok=True)
+    stamp = os.path.join(outdir, "digest.txt")
+    digest = sources_digest()
+    out = os.path.join(outdir, "libvfm_hip.so")
+    out_ops = os.path.join(outdir, "libvfm_torch_ops.so")
+    if (not force and os.path.exists(out) and os.path.exists(out_ops) and os.path.exists(stamp)
+            and open(stamp).read().strip() == digest):
+        return outdir
+    san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer",
+           "-Xarch_host", "-fno-sanitize-recover=undefined", "-Xarch_device", "-O0"]     # (device code: never run from here)
+    common = [HIPCC, "-O1", "-g", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden",
+              "-I" + os.path.join(ROOT, "include"), "-I" + csrc] + san
+    jobs, objs = [], []
+    for src, suffix, extra in _UNITS:
+        obj = os.path.join(outdir, os.path.splitext(src)[0] + suffix + ".o")
+        cmd = common + extra + ["-c", os.path.join(csrc, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan",
+                    "-o", out] + objs, check=True)
+    ti = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_HOME", "/opt/rocm")
+    clangxx = os.path.join(rocm, "lib", "llvm", "bin", "clang++")
+    cmd = [clangxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-shared-libsan",
+           "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-fno-sanitize=vptr",
+           "-mllvm", "-asan-globals=0",    # (libstdc++'s merged string literals trip the globals check: "not properly aligned")
+           "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ti, "include"),
+           "-I" + os.path.join(ti, "include", "torch", "csrc", "api", "include"),
+           "-I" + os.path.join(rocm, "include"), "-o", out_ops, os.path.join(csrc, "vfm_torch_ops.cpp"),
+           "-L" + os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-L" + outdir, "-lvfm_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ti, "lib")]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    # the native example: compiled (not run: it needs a GPU) under the same sanitizers -- its host code is UB-checked
+    # by the compiler's diagnostics at least
+    subprocess.run([HIPCC, "-O1", "-g", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include")] + san +
+                   ["-c", os.path.join(ROOT, "examples", "c_abi_step.cpp"), "-o", os.path.join(outdir, "c_abi_step.o")], check=True)
+    open(stamp, "w").write(digest)
+    return outdir
+
+
 def build_all(force=False, verbose=False):
     return [build_hip_library(force, verbose), build_torch_ops(force, verbose)]
 

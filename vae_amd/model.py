@@ -143,11 +143,13 @@ class VFM(nn.Module):
         # catch-up kernel refresh the rows they update, anything else that writes bias_params drops it (_wrec_ok).
         self.use_wrec = True
         self._wrec, self._wrec_ok = None, False
-        # Replayable step: with the step-dependent constants in device memory (ops.StepState), the launches of a fused
-        # step are captured ONCE per (batch, next batch, step form) in a HIP graph and replayed -- the host then spends
-        # one graph launch per step instead of two library calls (ML-100K shape, B = 5,000: the host was the limiter).
-        # "auto": fit() replays, a bare train_step() loop does when `replay = True`.  Bitwise the eager trajectory.
-        self.replay = "auto"
+        # Replayable step (OPT-IN, `replay = True`): with the step-dependent constants in device memory (ops.StepState), the
+        # launches of a fused step are captured ONCE per (batch, next batch, step form) in a HIP graph and replayed; bitwise
+        # the eager trajectory (tests/test_gpu_replay.py).  Off by default because on this stack (ROCm 7.2) it measures
+        # SLOWER than the eager launches at every shape tried: a graph launch costs 22-46 us of host time (two direct
+        # launches: ~10) and ~6 us on the GPU (cfg3 0.1966 vs 0.1902 ms per step, ML-100K shape 50.9 vs 44.9 us, B = 5,000
+        # 63.2 vs 57.0, Criteo shape 0.3651 vs 0.3585: profiles/r03_points.jsonl, keys `sustained` / `replayed`).
+        self.replay = False
         self._graphs = {}
         self._step_state = None
         self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
@@ -910,8 +912,8 @@ class VFM(nn.Module):
                     plan.prepare_lookahead(nxt)
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
         replay_before = self.replay
-        if self.replay == "auto":
-            self.replay = world == 1          # one captured graph per (batch, next batch) pair, replayed every epoch
+        if world > 1:
+            self.replay = False               # (the multi-rank steps interleave collectives with their launches)
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
         for epoch in range(n_epochs):

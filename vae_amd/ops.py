@@ -103,6 +103,11 @@ def inv_occ_from_counts(nb_occ: torch.Tensor) -> torch.Tensor:
 
 
 _WS = {}
+# The scratch buffer below is shared by every plan built on a (device, stream): safe because a build's launches are
+# stream-ordered -- as long as they are enqueued as ONE uninterrupted sequence.  ctypes releases the GIL inside the C call,
+# so two host threads building plans on the same stream could interleave their launches (and their pinned readback
+# slices): every enqueue that uses the shared scratch / the pinned chunk runs under this lock.
+_ENQUEUE_LOCK = __import__("threading").RLock()
 
 
 def _index_workspace(n_int32: int, dev) -> torch.Tensor:
@@ -196,6 +201,13 @@ class BatchPlan:
         nbytes = int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T))
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
+        with _ENQUEUE_LOCK:
+            self._build_index_locked(lib, n, L, nbytes, validate)
+        if not defer:
+            self._finish()
+
+    def _build_index_locked(self, lib, n, L, nbytes, validate):
+        spec, dev = self.spec, self.x.device
         ws = _index_workspace(nbytes // 4 + 4, dev)       # scratch of the build only: shared by all plans of a device
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
         # ONE device allocation per plan, carved into the index's arrays (seven allocations per plan made the first
@@ -216,8 +228,6 @@ class BatchPlan:
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
         self._pend = (host, done, hid, items, touched, validate, counts)
-        if not defer:
-            self._finish()
 
     def _finish(self):
         """Complete a deferred index build: read (bad ids, heavy lists, work items, entities) and size the lists."""
@@ -289,15 +299,16 @@ class BatchPlan:
             if q.occ_ptr is None:
                 q.build_index(defer=True)
         lib = _lib.load()
-        ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev)
         rows = torch.empty(min(T, (self.B + next_plan.B) * self.spec.F) or 1, dtype=torch.int32, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
-        check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
-                                 current_stream_ptr(dev)), "vfm_union_rows")
-        host = _pinned_ints(1)
-        host.copy_(count, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(dev))
+        with _ENQUEUE_LOCK:
+            ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev)
+            check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
+                                     current_stream_ptr(dev)), "vfm_union_rows")
+            host = _pinned_ints(1)
+            host.copy_(count, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
         pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done))
         if len(pairs) > 4:
             pairs.pop(next(iter(pairs)))
