@@ -75,3 +75,25 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     den = max(np.abs(b).max(), 1e-30)
     return np.abs(a - b).max() / den
+
+
+# ---- the big-shape learning-curve fixture (tools/make_bigfit_golden.py, tests/test_gpu_bigfit.py)
+BIGFIT = {"N": 138493, "M": 26744, "d": 128, "batch": 100000, "n_train": 1600000, "n_test": 200000, "n_epochs": 2,
+          "sampler_seeds": [0, 1, 2]}
+
+
+def bigfit_data():
+    """Synthetic low-rank ratings with ML-20M id ranges from a seeded torch CPU generator (the same values wherever this
+    runs): y = clip(3.2 + <U_u, V_i> + 0.3 noise, 1, 5).  Returns (X_train, y_train, X_test, y_test), ids int64."""
+    import torch
+    c = BIGFIT
+    g = torch.Generator().manual_seed(20260101)
+    k = 8
+    U, V = torch.randn(c["N"], k, generator=g) * 0.7, torch.randn(c["M"], k, generator=g) * 0.7
+    n = c["n_train"] + c["n_test"]
+    u = torch.randint(0, c["N"], (n,), generator=g)
+    i = torch.randint(0, c["M"], (n,), generator=g)
+    y = (3.2 + (U[u] * V[i]).sum(1) + 0.3 * torch.randn(n, generator=g)).clamp(1, 5)
+    X = torch.stack([u, i + c["N"]], 1)
+    nt = c["n_train"]
+    return X[:nt].contiguous(), y[:nt].contiguous(), X[nt:].contiguous(), y[nt:].contiguous()

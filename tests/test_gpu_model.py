@@ -58,6 +58,13 @@ def test_autograd_path(name):
     assert m.prec_global_bias_prior.grad is None        # unused params get no grad (reference quirk 7)
 
 
+# Multi-step checks against the reference's own runs: 5e-4 of the largest entry, the bound the 140-step run
+# (test_long_trajectory_vs_reference_adam) holds.  What is compared are fp32 trajectories of two implementations of dense
+# Adam that round differently per step (hardware sqrt / rcp in the fused scaled-moment form: 1 ulp each; torch: IEEE), so
+# the distance grows with the step count; single-step quantities are held to 1e-4 / 1e-5 elsewhere.
+TRAJ_TOL = 5e-4
+
+
 def test_trajectory_train_step_and_torch_adam():
     """6 Adam steps (3 batches x 2 epochs, short last batch): (a) train_step = HIP fwd/bwd + HIP
     Adam, (b) autograd path + torch.optim.Adam; both must land on the reference's weights."""
@@ -104,12 +111,12 @@ def test_trajectory_train_step_and_torch_adam():
                     opt.step()
                     loss = l.item()
                 assert abs(loss - z["losses"][step]) / abs(z["losses"][step]) < 1e-4, (mode, step)
-                assert rel_err(pred.cpu().numpy(), z[f"s{step}_pred"]) < 1e-3
+                assert rel_err(pred.cpu().numpy(), z[f"s{step}_pred"]) < TRAJ_TOL, (mode, step)
                 step += 1
         sd = m.state_dict()
         for k in PARAM_KEYS:
             got = sd[k if "params" not in k else k + ".weight"].cpu().numpy()
-            assert rel_err(got, z["pT_" + k]) < 2e-3, (mode, k)
+            assert rel_err(got, z["pT_" + k]) < TRAJ_TOL, (mode, k)
 
 
 @pytest.mark.parametrize("mode", ["fused_scaled", "fused_plain", "unfused"])
@@ -190,21 +197,21 @@ def test_eval_block_vs_reference(name):
         lik, last, mean, kl = m.forward(xt, eps=tables(f"e{epoch}"))
         want = z[f"e{epoch}_pred"]
         assert kl is None
-        assert rel_err(lik.mean.cpu().numpy().reshape(want.shape), want) < 2e-3, epoch
+        assert rel_err(lik.mean.cpu().numpy().reshape(want.shape), want) < TRAJ_TOL, epoch
         if output == "reg":
-            assert rel_err(last.cpu().numpy(), z[f"e{epoch}_last_logits"]) < 2e-3
-            assert rel_err(mean.cpu().numpy(), z[f"e{epoch}_mean_logits"]) < 2e-3
+            assert rel_err(last.cpu().numpy(), z[f"e{epoch}_last_logits"]) < TRAJ_TOL
+            assert rel_err(mean.cpu().numpy(), z[f"e{epoch}_mean_logits"]) < TRAJ_TOL
             out = m.predict(xt, eps=tables(f"e{epoch}"))         # :402-417
             y_pred = np.clip(want, 1, 5)
             all_preds.append(y_pred)
-            assert rel_err(out["y_pred"].cpu().numpy(), y_pred) < 2e-3
-            assert rel_err(out["mean_pred"].cpu().numpy(), np.mean(all_preds, axis=0)) < 2e-3
-            assert rel_err(out["y_pred_of_last"].cpu().numpy(), z[f"e{epoch}_last_logits"]) < 2e-3   # (not clipped, :402-417)
-            assert rel_err(out["y_pred_of_mean"].cpu().numpy(), np.clip(z[f"e{epoch}_mean_logits"], 1, 5)) < 2e-3
+            assert rel_err(out["y_pred"].cpu().numpy(), y_pred) < TRAJ_TOL
+            assert rel_err(out["mean_pred"].cpu().numpy(), np.mean(all_preds, axis=0)) < TRAJ_TOL
+            assert rel_err(out["y_pred_of_last"].cpu().numpy(), z[f"e{epoch}_last_logits"]) < TRAJ_TOL   # (not clipped, :402-417)
+            assert rel_err(out["y_pred_of_mean"].cpu().numpy(), np.clip(z[f"e{epoch}_mean_logits"], 1, 5)) < TRAJ_TOL
         else:
             assert last is None and mean is None                 # the reference saves weights for 'reg' only
             out = m.predict(xt, eps=tables(f"e{epoch}"))
-            assert rel_err(out["y_pred"].cpu().numpy(), want.mean(axis=0)) < 2e-3
+            assert rel_err(out["y_pred"].cpu().numpy(), want.mean(axis=0)) < TRAJ_TOL
 
 
 def test_predict_samples_moments_vs_oracle():

@@ -1,0 +1,128 @@
+"""GPU: fixed-seed STATE-MACHINE FUZZ of `VFM.train_step`.  The step has eight forms (plain fused, look-ahead with a row
+list or a scan, row-list lazy, pipelined, unfused, each of them eager or as a replayed graph, with or without the packed
+first-order records) steered by hidden state (`_lazy_dirty`, `_lazy_kind`, `_la_ready_for`, `_zrec_for`,
+`_moments_scaled`, `_wrec_ok`, the device step counters); every transition has a hand-written test somewhere, this file
+walks RANDOM sequences of them.
+
+Reference: a second model that only ever takes the plain dense fused step (and an unfused step where the sequence has
+one).  After EVERY step the loss triple and the predictions must equal the reference's bit for bit; at random points, and
+at the end, so must every parameter and both Adam moments.  In between: predictions, save_weights, state_dict reads,
+checkpoint round trips of the model into itself, learning-rate changes, un-announced batches.  The software-pipelined
+step sums in another order (the backward adds the other entity's sample instead of sumz - z), so sequences that contain
+it are compared to 1e-4 of the largest entry instead (second test; measured 1.2e-5 on the second moments).  Reference loop: vfm-torch.py:351-370."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_TRACE = bool(__import__("os").environ.get("VFM_SM_TRACE"))
+CONFIGS = {"F2_d32": ((300, 200), 32, 64, "reg"), "F3_d16": ((200, 150, 100), 16, 48, "class"),
+           "F2_d128_heavy": ((400, 12), 128, 96, "reg")}
+
+
+def _make(sizes, d, B, nb, output):
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    torch.manual_seed(3)
+    m = VFM(field_sizes=list(sizes), embedding_size=d, device="cuda", rng_seed=11, output=output)
+    m.lazy_min_params = 0
+    m.pipeline_min_T, m.pipeline_min_d = 0, 0
+    X, y = synthetic_triples(list(sizes), nb * B, seed=4, device="cuda", output=output)
+    m.set_training_data(X, nb_train=nb * B)
+    plans = [m.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
+    return m, plans, X
+
+
+def _same_state(a, b, exact, where):
+    a.sync_lazy(); b.sync_lazy()
+    for name in ("_flat", "_adam_m", "_adam_v"):
+        ta, tb = getattr(a, name), getattr(b, name)
+        if name != "_flat" and a._moments_scaled != b._moments_scaled:
+            continue                               # (the two hold the moments in different forms right now)
+        if exact:
+            assert torch.equal(ta, tb), (where, name)
+        else:
+            assert float((ta - tb).abs().max()) <= 1e-4 * float(tb.abs().max()) + 1e-30, (where, name)
+    assert a._adam_t == b._adam_t and a.global_step == b.global_step, where
+
+
+def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None):
+    import vae_amd.model as M
+    if monkeypatch is not None:
+        monkeypatch.setattr(M, "_CHECK_WREC", True)
+    sizes, d, B, output = CONFIGS[cfg]
+    nb = 5
+    ref, plans_r, X = _make(sizes, d, B, nb, output)
+    tst, plans_t, _ = _make(sizes, d, B, nb, output)
+    ref.lookahead = ref.pipeline = ref.replay = ref.use_wrec = False
+    ref.lazy_adam = False
+    g = np.random.default_rng(seed)
+    lr = 0.05
+    cur = 0
+    announced = None
+    trace = []
+    for s in range(n_steps):
+        # ---- something between two steps
+        act = g.choice(["none", "none", "none", "predict", "save", "state_dict", "checkpoint", "lr", "reload_own"])
+        if act == "predict":
+            pa, pb = ref.predict(X[:70]), tst.predict(X[:70])
+            assert (torch.equal(pa["y_pred"], pb["y_pred"]) if not with_pipeline else
+                    float((pa["y_pred"] - pb["y_pred"]).abs().max()) <= 1e-4 * float(pa["y_pred"].abs().max())), (s, trace[-5:])
+        elif act == "save":
+            ref.save_weights(); tst.save_weights()
+        elif act == "state_dict":
+            tst.state_dict()
+        elif act == "checkpoint":
+            sd = tst.training_state_dict()
+            tst.load_training_state_dict(sd)
+        elif act == "reload_own":
+            tst.load_state_dict(tst.state_dict())
+        elif act == "lr":
+            lr = float(g.choice([0.05, 0.02, 0.08]))
+        # ---- the step form of the model under test
+        form = str(g.choice(["dense", "la_list", "la_scan", "lazy_list", "lazy_auto", "unfused"] + (["pipe", "pipe"] if with_pipeline else [])))
+        tst.lookahead = form in ("la_list", "la_scan")
+        tst.lookahead_list = form != "la_scan"
+        tst.lazy_adam = {"lazy_list": True, "lazy_auto": "auto"}.get(form, False)
+        tst.lazy_threshold = 0.9 if form == "lazy_auto" else 0.35
+        tst.pipeline = True if form == "pipe" else False
+        tst.replay = bool(g.random() < 0.5)
+        tst.use_wrec = bool(g.random() < 0.6)
+        nxt = (cur + 1) % nb
+        if g.random() < 0.12:
+            nxt = int(g.integers(0, nb))                     # the next batch is not the one in line ...
+        name_next = g.random() < 0.85                        # ... and sometimes nobody names one
+        fused = form != "unfused"
+        trace.append((s, str(act), form, tst.replay, tst.use_wrec, cur, nxt if name_next else None))
+        if _TRACE:
+            print(trace[-1], "adam_t", tst._adam_t, "dirty", tst._lazy_dirty, tst._lazy_kind, flush=True)
+        lt, pt = tst.train_step(plans_t[cur], lr=lr, next_plan=plans_t[nxt] if name_next else None, fused=fused)
+        lr_, pr = ref.train_step(plans_r[cur], lr=lr, fused=fused)
+        if with_pipeline:
+            assert torch.allclose(lt, lr_, rtol=1e-4), (trace[-6:], lt, lr_)
+            assert float((pt - pr).abs().max()) <= 1e-4 * float(pr.abs().max()), trace[-6:]
+        else:
+            assert torch.equal(lt, lr_), (trace[-6:], lt, lr_)
+            assert torch.equal(pt, pr), trace[-6:]
+        if g.random() < 0.12:
+            _same_state(tst, ref, not with_pipeline, trace[-6:])
+        cur = nxt if g.random() < 0.9 else int(g.integers(0, nb))      # an un-announced batch now and then
+    _same_state(tst, ref, not with_pipeline, "end")
+    if tst._step_state is not None:
+        assert not tst._step_state.error()
+    return trace
+
+
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_step_form_sequences_are_bitwise_the_dense_trajectory(cfg, seed, monkeypatch):
+    trace = _walk(cfg, seed, with_pipeline=False, monkeypatch=monkeypatch)
+    forms = {t[2] for t in trace}
+    assert {"dense", "la_list", "lazy_list", "unfused"} <= forms         # the walk did visit the forms
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_random_sequences_with_the_pipelined_step(seed, monkeypatch):
+    trace = _walk("F2_d32", seed, with_pipeline=True, monkeypatch=monkeypatch)
+    assert "pipe" in {t[2] for t in trace}

@@ -329,7 +329,8 @@ class VFM(nn.Module):
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
-            self._lazy_last, self._lazy_lr = None, {}
+            self._lazy_lr = {}             # (_lazy_last keeps its buffer -- captured graphs point at it; no row lags, so
+                                           #  the next lazy step stamps every entry before anything reads one)
         self._forget_derived_state()          # (with or without optimiser state: the restored rows are current)
         if getattr(self, "_dims", None) is not None:
             self._dims.scatter(self)
@@ -720,8 +721,10 @@ class VFM(nn.Module):
                     next_plan.index_tensors()
                     if self.lookahead_list:
                         plan.lookahead_rows(next_plan)
-                key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled), wrec is not None,
-                       self.lookahead_list if la else None)
+                # (everything a captured launch points at is part of the key or allocated once per model and device)
+                key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled),
+                       wrec.data_ptr() if wrec is not None else 0, self.lookahead_list if la else None,
+                       self._lazy_last.data_ptr() if la else 0)
                 out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, sumz, grow, pred))
             else:
                 self._eager_step_ran()
@@ -859,7 +862,7 @@ class VFM(nn.Module):
             if next_plan is not None:
                 next_plan.index_tensors()
             key = ("pipe", id(plan), id(next_plan) if next_plan is not None else 0, cur.data_ptr(), bool(scaled),
-                   wrec is not None)
+                   wrec.data_ptr() if wrec is not None else 0)
             out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, cur, nxt, grow, pred))
         else:
             self._eager_step_ran()
