@@ -19,26 +19,31 @@ run() {  # label, env assignments (may be empty), bench args...
 import json,sys
 j=json.loads(sys.stdin.readline()); j['point']='$label'; print(json.dumps(j))" >> $OUT || echo "{\"point\": \"$label\", \"error\": true}" >> $OUT
 }
-run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30
-run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6
-run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --pipeline off
-run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions
-run cfg2_ml100k_d20_pipelined_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline on
-run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20
-run cfg5_criteo_d256_auto "" --workload criteo_d256 --steps 200 --warmup 20
-run cfg5_criteo_d256_row_list_form "" --workload criteo_d256 --lazy-adam on --steps 200 --warmup 20
-run cfg3_B5000_auto "" --batch 5000 --steps 300 --warmup 20 --no-regions
-run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --lookahead off --steps 40 --warmup 4
-run cfg3_lookahead_off "" --lookahead off --steps 200 --warmup 20 --no-regions
-run cfg3_fwd_ab_k_fwd "VFM_FWD_KERNEL=1" --steps 200 --warmup 20 --no-regions
-run cfg3_fwd_ab_k_fwd2 "" --steps 200 --warmup 20 --no-regions
-run cfg3_fwd_ab_k_fwd2_table_eps "" --fwd-eps table --steps 200 --warmup 20 --no-regions
-run cfg3_fwd_ab_k_fwd2_no_rng "VFM_FWD_AB_NORNG=1" --steps 200 --warmup 20 --no-regions
-run cfg3_unsorted_rows "" --no-sort --steps 200 --warmup 20 --no-regions
+COMMON="--sustained-steps 1000"
+run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30 $COMMON
+run cfg2_ml100k_d20_replayed_graphs "" --workload ml100k_d20 --steps 300 --warmup 30 --replay on $COMMON
+run cfg3_no_packed_records "" --no-wrec --steps 200 --warmup 20 --no-regions $COMMON
+run cfg5_criteo_d256_k_fwd "VFM_FWD_KERNEL=1" --workload criteo_d256 --steps 200 --warmup 20 --sustained-steps 0
+run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --sustained-steps 0
+run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --pipeline off --sustained-steps 0
+run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg2_ml100k_d20_pipelined_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline on --sustained-steps 0
+run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20 --sustained-steps 0
+run cfg5_criteo_d256_auto "" --workload criteo_d256 --steps 200 --warmup 20 $COMMON
+run cfg5_criteo_d256_row_list_form "" --workload criteo_d256 --lazy-adam on --steps 200 --warmup 20 --sustained-steps 0
+run cfg3_B5000_auto "" --batch 5000 --steps 300 --warmup 20 --no-regions $COMMON
+run cfg5_criteo_d256_dense "" --workload criteo_d256 --lazy-adam off --lookahead off --steps 40 --warmup 4 --sustained-steps 0
+run cfg3_lookahead_off "" --lookahead off --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg3_fwd_ab_k_fwd "VFM_FWD_KERNEL=1" --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg3_fwd_ab_k_fwd2 "" --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg3_fwd_ab_k_fwd2_table_eps "" --fwd-eps table --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg3_fwd_ab_k_fwd2_no_rng "VFM_FWD_AB_NORNG=1" --steps 200 --warmup 20 --no-regions --sustained-steps 0
+run cfg3_unsorted_rows "" --no-sort --steps 200 --warmup 20 --no-regions --sustained-steps 0
 python3 - <<PY
 import json
 for l in open("$OUT"):
     j = json.loads(l)
     if j.get("error"): print(j); continue
-    print(j["point"], "ms/step", j["ms_per_step"], "value", j["value"], {k: v["avg_us"] for k, v in j["kernels"].items()})
+    print(j["point"], "ms/step", j["ms_per_step"], "value", j["value"], {k: v["avg_us"] for k, v in j["kernels"].items()},
+          "sustained", (j.get("sustained") or {}).get("ms_per_step"), "replayed", (j.get("replayed") or {}).get("ms_per_step"))
 PY

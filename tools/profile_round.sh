@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline ${EXTRA_ARGS:-}"     # e.g. EXTRA_ARGS="--workload ml20m_d16 --n-batches 4"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --sustained-steps 0 --event-every 1 ${EXTRA_ARGS:-}"     # e.g. EXTRA_ARGS="--workload ml20m_d16 --n-batches 4"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_write.json 2> $OUT/pmc_write.err
