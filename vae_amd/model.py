@@ -615,158 +615,39 @@ class VFM(nn.Module):
                 raise ValueError("the entity-sharded step always applies Adam")
             self._set_moment_form(self.scaled_moments)
             return train_step_sharded(self, plan, lr, eps=eps, out_pred=out_pred, mark=mark)
-        ent, bia, scal = self._views(self._flat)
-        g_ent, g_bias, g_scal = self._views(self._gflat)
-        loss3 = self._gflat[self._n_flat: self._n_flat + 3]
-        rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
-        flags = prior_terms_flag(rank)
         step = self.global_step
         self.global_step += 1
         marking = mark is not None
         mark = mark or (lambda name: None)      # bench.py records HIP events at these points
         mark("start")
-        sumz, grow, pred = self._step_buffers(plan.B)
         if fused is None:
             fused = self.fuse_adam
         fused = fused and adam and process_group is None
-        lazy = rows = None
-        la = False
         # the packed first-order records: kept coherent by the fused single-rank step alone (every other step form drops them)
         wrec = self._wrec_for_step(fused and eps is None and self.n_samples == 1 and not self.sparse_adam)
         if fused:
-            scaled = self.scaled_moments and not self.sparse_adam
-            self._set_moment_form(scaled)
-            self._adam_t += 1
-            k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1            # position of this step in its moment period
-            # look-ahead form: visit only the rows of this batch and of the next (named by the caller).  Preferred to the
-            # row-list form below wherever both apply: no separate replay pass (B = 5,000 at cfg3: 0.079 vs 0.099 ms;
-            # Criteo shape: 0.361 vs 0.364)
-            la = (scaled and k < ops.MOMENT_PERIOD and eps is None and self.n_samples == 1 and self.lazy_adam is not True
-                  and next_plan is not None and next_plan.y is not None and next_plan.spec.T == self.T
-                  and self._lookahead_pays(plan, next_plan))
-            lazy = scaled and not la and self.n_samples >= 1 and self._use_lazy(plan)
-            # may this step be a replayed graph?  (no per-kernel events, no caller-owned buffers, Philox eps)
-            may_replay = (self.replay is True and not marking and eps is None and out_pred is None and self.n_samples == 1
-                          and not self.sparse_adam)
-            if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
-                    and out_pred is None and ops.pipeline_supported(plan.spec)
-                    and (self.pipeline is True or (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T))):
-                ready = self._records_ready(plan, step)
-                nxt = next_plan
-                if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
-                    nxt = None                # too few rows per entity for the records to pay: do not prepare them
-                if ready or (nxt is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
-                    return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay)
-            if k == 1:
-                self._lazy_lr = {}
-            self._lazy_lr[k] = float(lr)
-            kind = "list" if lazy else ("la" if la else None)
-            caught_up = False                # a catch-up pass ran in front of this step: not a replayable launch sequence
-            if self._lazy_dirty and kind != self._lazy_kind:
-                self.sync_lazy(self._adam_t - 1)      # another step form than the one that let rows lag: all rows current first
-            if kind is not None:
-                if self._lazy_last is None:
-                    self._lazy_last = torch.empty(self.T, dtype=torch.int32, device=self.device)
-                if not self._lazy_dirty:     # no row lags: every row is at the step before this one, however it got there
-                    self._lazy_last.fill_(self._adam_t - 1)
-                mv, vv = self._views(self._adam_m), self._views(self._adam_v)
-                if lazy and k < ops.MOMENT_PERIOD:
-                    # rows of this batch: replay what they skipped, they get step _adam_t below; the others wait
-                    ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
-                                     upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
-                    rows, self._lazy_dirty, self._lazy_kind = "touched", True, "list"
-                    caught_up = True
-                    mark("catchup")
-                elif la:
-                    if self._la_tab is None:
-                        self._la_tab = torch.zeros(2 * (ops.MOMENT_PERIOD + 1), dtype=torch.float32, device=self.device)
-                    ready = self._la_ready_for
-                    if self._lazy_dirty and not (ready is not None and ready[0] is plan and ready[1] == self._adam_t - 1):
-                        # this batch was not the one announced to the previous step: bring its rows up to date now
-                        ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
-                                         upto=self._adam_t - 1, mark=self._adam_t - 1, wrec=wrec)
-                        mark("catchup")
-                else:
-                    # last step of a moment period (the dense kernel rewrites every row's moments): every row up to
-                    # date first, then the ordinary dense step
-                    ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, None, self._lazy_lrs(k - 1),
-                                     upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
-                    self._lazy_dirty = False
-                    mark("catchup")
-            elif self._lazy_dirty:
-                self.sync_lazy(self._adam_t - 1)
-
-            def launch(dev):
-                """The launches of the fused step (forward, then loss + backward + dense Adam in ONE kernel: the gradient
-                rows never reach HBM).  dev: None = step-dependent values as host arguments; else the device step state."""
-                st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
-                                      train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
-                                      out_sumz=sumz, out_grow=grow, out_partials=self._partials, wrec=wrec, dev_step=dev)
-                mark("fwd")
-                if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
-                    ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
-                                                     self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
-                                                     loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list,
-                                                     wrec=wrec, dev_step=dev)
-                else:
-                    ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                           self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                           sparse=self.sparse_adam, scaled_moments=scaled, rows=rows, wrec=wrec, dev_step=dev)
-                mark("bwd_adam")
-                return st.pred
-
-            if may_replay and not caught_up and not lazy:
-                plan.index_tensors()                  # (deferred index readbacks: not inside a capture)
-                if la:
-                    next_plan.index_tensors()
-                    if self.lookahead_list:
-                        plan.lookahead_rows(next_plan)
-                # (everything a captured launch points at is part of the key or allocated once per model and device)
-                key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled),
-                       wrec.data_ptr() if wrec is not None else 0, self.lookahead_list if la else None,
-                       self._lazy_last.data_ptr() if la else 0)
-                out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, sumz, grow, pred))
-            else:
-                self._eager_step_ran()
-                out = launch(None)
-            if la:
-                self._lazy_dirty, self._lazy_kind = True, "la"
-                self._la_ready_for = (next_plan, self._adam_t)
-            return loss3, out
-        elif self._lazy_dirty:
+            return self._step_fused(plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec)
+        if self._lazy_dirty:
             self.sync_lazy()
+        if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
+            from .dist import step_stats
+            return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark)
+        return self._step_unfused(plan, lr, step, eps, out_pred, adam, mark, process_group)
+
+    def _step_unfused(self, plan, lr, step, eps, out_pred, adam, mark, process_group=None):
+        """forward, loss, backward (the dense gradient written), [ONE all-reduce of the flat [gradients | loss] buffer --
+        the literal north-star exchange, `exchange = "grads"`], [flat dense Adam]: the single-rank step with separate
+        kernels, and the multi-rank step in its gradient form."""
+        ent, bia, scal = self._views(self._flat)
+        g_ent, g_bias, g_scal = self._views(self._gflat)
+        loss3 = self._gflat[self._n_flat: self._n_flat + 3]
+        rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        sumz, grow, pred = self._step_buffers(plan.B)
         st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
-                              train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
+                              train=True, flags=prior_terms_flag(rank), out_pred=out_pred if out_pred is not None else pred,
                               out_sumz=sumz, out_grow=grow, out_partials=self._partials)
         mark("fwd")
-        stats = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
-        self._set_moment_form(self.scaled_moments and stats)     # (the flat k_adam of the other paths: plain form)
-        if stats:
-            # multi-rank: exchange the gradient's sufficient statistics (sum grow, count, A_e) -- half
-            # the bytes of the gradient -- then epilogue + Adam on every rank.  The table is cut in
-            # `exchange_chunks` entity ranges: the all-reduce of chunk k overlaps the statistics kernel
-            # of chunk k+1 and the epilogue+Adam kernel of chunk k-1.
-            xacc, xs, xl, bounds = self._xviews()
-            ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
-            mark("finalize")
-            works = []
-            rl = ops.exchange_record_len(self.d)
-            for k in range(len(bounds) - 1):
-                lo, hi = bounds[k], bounds[k + 1]
-                ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
-                end = self._xflat.numel() if hi == self.T else hi * rl      # the last chunk carries sums + loss
-                works.append(torch.distributed.all_reduce(self._xflat[lo * rl: end], group=process_group,
-                                                          async_op=True))
-            mark("bwd_acc")
-            self._adam_t += 1
-            for k in range(len(bounds) - 1):
-                works[k].wait()
-                ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                    self._views(self._adam_v), lr, self._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1],
-                                    scaled_moments=self._moments_scaled)
-            mark("exchange_apply_adam")
-            loss3.copy_(xl)
-            return loss3, st.pred
+        self._set_moment_form(False)          # (the flat k_adam: plain moments)
         ops.elbo_finalize(st, scal, out=loss3)
         mark("finalize")
         ops.elbo_backward(plan, st, ent, bia, scal, self.inv_occ, self._gout, g_ent, g_bias, g_scal)
@@ -780,6 +661,117 @@ class VFM(nn.Module):
             ops.adam_step(self._flat, self._gflat, self._adam_m, self._adam_v, lr, self._adam_t)
             mark("adam")
         return loss3, st.pred
+
+    def _step_fused(self, plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec):
+        """The single-rank step with loss + backward + dense Adam in ONE kernel, in the form the state allows: look-ahead
+        (rows of this batch and of the next), row-list lazy (+ catch-up pass), software-pipelined, or plain dense -- each
+        either launched eagerly or replayed as a captured graph (`replay`).  All forms are the same dense Adam trajectory
+        (the lazy ones bit for bit: tests/test_gpu_lazy_adam.py, test_gpu_state_machine.py)."""
+        ent, bia, scal = self._views(self._flat)
+        loss3 = self._gflat[self._n_flat: self._n_flat + 3]
+        sumz, grow, pred = self._step_buffers(plan.B)
+        flags = 0
+        lazy = rows = None
+        la = False
+        scaled = self.scaled_moments and not self.sparse_adam
+        self._set_moment_form(scaled)
+        self._adam_t += 1
+        k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1            # position of this step in its moment period
+        # look-ahead form: visit only the rows of this batch and of the next (named by the caller).  Preferred to the
+        # row-list form below wherever both apply: no separate replay pass (B = 5,000 at cfg3: 0.079 vs 0.099 ms;
+        # Criteo shape: 0.361 vs 0.364)
+        la = (scaled and k < ops.MOMENT_PERIOD and eps is None and self.n_samples == 1 and self.lazy_adam is not True
+              and next_plan is not None and next_plan.y is not None and next_plan.spec.T == self.T
+              and self._lookahead_pays(plan, next_plan))
+        lazy = scaled and not la and self.n_samples >= 1 and self._use_lazy(plan)
+        # may this step be a replayed graph?  (no per-kernel events, no caller-owned buffers, Philox eps)
+        may_replay = (self.replay is True and not marking and eps is None and out_pred is None and self.n_samples == 1
+                      and not self.sparse_adam)
+        if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
+                and out_pred is None and ops.pipeline_supported(plan.spec)
+                and (self.pipeline is True or (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T))):
+            ready = self._records_ready(plan, step)
+            nxt = next_plan
+            if nxt is not None and self.pipeline == "auto" and nxt.B < self.pipeline_ratio * nxt.U:
+                nxt = None                # too few rows per entity for the records to pay: do not prepare them
+            if ready or (nxt is not None and (self.pipeline is True or plan.B >= self.pipeline_ratio * plan.U)):
+                return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay)
+        if k == 1:
+            self._lazy_lr = {}
+        self._lazy_lr[k] = float(lr)
+        kind = "list" if lazy else ("la" if la else None)
+        caught_up = False                # a catch-up pass ran in front of this step: not a replayable launch sequence
+        if self._lazy_dirty and kind != self._lazy_kind:
+            self.sync_lazy(self._adam_t - 1)      # another step form than the one that let rows lag: all rows current first
+        if kind is not None:
+            if self._lazy_last is None:
+                self._lazy_last = torch.empty(self.T, dtype=torch.int32, device=self.device)
+            if not self._lazy_dirty:     # no row lags: every row is at the step before this one, however it got there
+                self._lazy_last.fill_(self._adam_t - 1)
+            mv, vv = self._views(self._adam_m), self._views(self._adam_v)
+            if lazy and k < ops.MOMENT_PERIOD:
+                # rows of this batch: replay what they skipped, they get step _adam_t below; the others wait
+                ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
+                                 upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
+                rows, self._lazy_dirty, self._lazy_kind = "touched", True, "list"
+                caught_up = True
+                mark("catchup")
+            elif la:
+                if self._la_tab is None:
+                    self._la_tab = torch.zeros(2 * (ops.MOMENT_PERIOD + 1), dtype=torch.float32, device=self.device)
+                ready = self._la_ready_for
+                if self._lazy_dirty and not (ready is not None and ready[0] is plan and ready[1] == self._adam_t - 1):
+                    # this batch was not the one announced to the previous step: bring its rows up to date now
+                    ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
+                                     upto=self._adam_t - 1, mark=self._adam_t - 1, wrec=wrec)
+                    mark("catchup")
+            else:
+                # last step of a moment period (the dense kernel rewrites every row's moments): every row up to
+                # date first, then the ordinary dense step
+                ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, None, self._lazy_lrs(k - 1),
+                                 upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
+                self._lazy_dirty = False
+                mark("catchup")
+        elif self._lazy_dirty:
+            self.sync_lazy(self._adam_t - 1)
+
+        def launch(dev):
+            """The launches of the fused step (forward, then loss + backward + dense Adam in ONE kernel: the gradient
+            rows never reach HBM).  dev: None = step-dependent values as host arguments; else the device step state."""
+            st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
+                                  train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
+                                  out_sumz=sumz, out_grow=grow, out_partials=self._partials, wrec=wrec, dev_step=dev)
+            mark("fwd")
+            if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
+                ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
+                                                 self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
+                                                 loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list,
+                                                 wrec=wrec, dev_step=dev)
+            else:
+                ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                       self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
+                                       sparse=self.sparse_adam, scaled_moments=scaled, rows=rows, wrec=wrec, dev_step=dev)
+            mark("bwd_adam")
+            return st.pred
+
+        if may_replay and not caught_up and not lazy:
+            plan.index_tensors()                  # (deferred index readbacks: not inside a capture)
+            if la:
+                next_plan.index_tensors()
+                if self.lookahead_list:
+                    plan.lookahead_rows(next_plan)
+            # (everything a captured launch points at is part of the key or allocated once per model and device)
+            key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled),
+                   wrec.data_ptr() if wrec is not None else 0, self.lookahead_list if la else None,
+                   self._lazy_last.data_ptr() if la else 0)
+            out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, sumz, grow, pred))
+        else:
+            self._eager_step_ran()
+            out = launch(None)
+        if la:
+            self._lazy_dirty, self._lazy_kind = True, "la"
+            self._la_ready_for = (next_plan, self._adam_t)
+        return loss3, out
 
     def _wrec_for_step(self, keep: bool):
         """The packed first-order records for a step that keeps them coherent (None: this step form does not -- they are
