@@ -325,8 +325,11 @@ def main():
         model.sync_lazy()                          # rows still lagging get their skipped updates INSIDE the timed region
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        xbytes = None
+        if world > 1:      # what ONE step's exchange carried (the last step's; bytes per rank into the all-reduce)
+            xbytes = {"stats": 4 * int(model._exchanged_floats), "grads": 4 * int(model._gflat.numel())}.get(mode)
         return {"dt": dt, "t_host": t_host, "events": events, "lazy_kind": lazy_kind, "plans": plans,
-                "U": sum(uniq) / len(uniq), "B": setup.B, "steps": steps, "mode": mode}
+                "U": sum(uniq) / len(uniq), "B": setup.B, "steps": steps, "mode": mode, "exchange_bytes": xbytes}
 
     # ------------------------------------------------------------------ what to run
     exchange_note = None
@@ -469,7 +472,8 @@ def main():
             return {"scaling": reg, "exchange": m["mode"] if world > 1 else None, "batch_per_gpu": m["B"],
                     "global_batch": m["B"] * world, "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 4),
                     "value": round(m["steps"] * m["B"] * world / m["dt"], 1),
-                    "host_enqueue_ms_per_step": round(m["t_host"] / m["steps"] * 1e3, 4)}
+                    "host_enqueue_ms_per_step": round(m["t_host"] / m["steps"] * 1e3, 4),
+                    "allreduce_bytes_per_step": m.get("exchange_bytes")}
         head_reg = regimes[0][0]
         cand_lines = {reg: {k: (line_of(v, reg) if "dt" in v else {"skipped": v["skipped"]}) for k, v in rs.items()}
                       for reg, rs in results.items()}

@@ -264,7 +264,39 @@ def test_cfg4_batch_over_8_ranks_equals_1_rank(exchange, monkeypatch):
     want_p, want_l = _cfg4_single(n_steps)
     assert rel_err(out[0][0].cpu().numpy(), want_p) < 1e-5
     assert rel_err(out[0][1].cpu().numpy(), want_l) < 1e-5
-    # what the step's ONE exchange carries: the statistics table is half the gradient
-    per_step = (sh.bytes_allreduce - 16) / n_steps          # (minus the 2 fp64 normalisers, summed once per batch)
+    # what the step's ONE exchange carries: "grads" the flat [gradients | loss] buffer; "stats" the records of
+    # the entities SOME rank's shard contains (agreed once per plan: one 8-byte MAX + an all-gather of id lists) -- at
+    # this split 59 % of the T records, each half a gradient row -- plus the row sums and the loss
     T, d = sum(cfg["sizes"]), cfg["d"]
-    assert abs(per_step - {"stats": 4.0 * (T * (d + 4) + 8), "grads": 4.0 * (T * (2 * d + 2) + 8 + 2)}[exchange]) < 64
+    Ug = int(torch.unique(X).numel())
+    assert 0.55 * T < Ug < 0.62 * T
+    once = 16 + (8 if exchange == "stats" else 0)            # the 2 fp64 normalisers (+ the longest id list's length)
+    per_step = (sh.bytes_allreduce - once) / n_steps
+    assert per_step == {"stats": 4.0 * (Ug * (d + 4) + 8), "grads": 4.0 * (T * (2 * d + 2) + 8 + 2)}[exchange]
+    assert models[0]._exchanged_floats == (Ug * (d + 4) + 8 if exchange == "stats" else 0)
+
+
+def test_cfg4_compact_statistics_exchange_equals_the_dense_one(monkeypatch):
+    """exchange_compact on / off at cfg4 over 4 in-process ranks: the same sums travel (zeros are left at home), so the
+    two runs agree BIT FOR BIT."""
+    from thread_ranks import run_ranks
+    from vae_amd.dist import shard_rows
+    world, n_steps = 4, 2
+    cfg, X, y, occ = _cfg4_reference(n_steps)
+    outs = []
+    for compact in (True, False):
+        models = _replicas(cfg, world, exchange="stats", exchange_compact=compact)
+
+        def rank_body(rank, group):
+            m = models[rank]
+            m.set_training_data(X, nb_train=cfg["nb_train"], nb_occ=occ)
+            a, b = shard_rows(0, cfg["B"], rank, world)
+            plan = m.plan(X[a:b], y[a:b], B_global=cfg["B"], process_group=group)
+            losses = [m.train_step(plan, lr=0.01, process_group=group)[0].clone() for _ in range(n_steps)]
+            return m._flat, torch.stack(losses)
+
+        out, sh = run_ranks(world, rank_body, monkeypatch)
+        outs.append((out[0][0].clone(), out[0][1].clone(), sh.bytes_allreduce))
+        del models, out
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] < 0.7 * outs[1][2]

@@ -38,9 +38,12 @@ def _all_reduce(tensor, op=None, group=None, async_op=False):
     sh.bufs[group.rank] = tensor
     sh.barrier.wait()
     if group.rank == 0:
-        total = sh.bufs[0].clone()
-        for b in sh.bufs[1:]:                     # rank order: a fixed summation order
-            total += b
+        if op is not None and "MAX" in str(op).upper():
+            total = torch.stack(list(sh.bufs)).max(dim=0).values
+        else:
+            total = sh.bufs[0].clone()
+            for b in sh.bufs[1:]:                 # rank order: a fixed summation order
+                total += b
         sh.total = total
         sh.n_allreduce += 1
         sh.bytes_allreduce += tensor.numel() * tensor.element_size()
@@ -50,10 +53,22 @@ def _all_reduce(tensor, op=None, group=None, async_op=False):
     return _Done() if async_op else None
 
 
+def _all_gather(out_list, tensor, group=None, async_op=False):
+    sh = group.shared
+    sh.bufs[group.rank] = tensor
+    sh.barrier.wait()
+    for r in range(sh.world):
+        out_list[r].copy_(sh.bufs[r])
+    sh.barrier.wait()
+    return _Done() if async_op else None
+
+
 def run_ranks(world, fn, monkeypatch):
     """Run fn(rank, group) on `world` threads; returns (list of results by rank, the shared record)."""
     import torch.distributed as dist
-    real = (dist.all_reduce, dist.get_rank, dist.get_world_size)
+    real = (dist.all_reduce, dist.get_rank, dist.get_world_size, dist.all_gather)
+    monkeypatch.setattr(dist, "all_gather", lambda out, t, group=None, async_op=False:
+                        _all_gather(out, t, group, async_op) if isinstance(group, ThreadGroup) else real[3](out, t, group=group, async_op=async_op))
     monkeypatch.setattr(dist, "all_reduce", lambda t, op=None, group=None, async_op=False:
                         _all_reduce(t, op, group, async_op) if isinstance(group, ThreadGroup) else real[0](t, op=op, group=group, async_op=async_op))
     monkeypatch.setattr(dist, "get_rank", lambda group=None: group.rank if isinstance(group, ThreadGroup) else real[1](group))

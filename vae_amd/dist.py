@@ -40,6 +40,29 @@ def prior_terms_flag(rank: int) -> int:
     return 0 if rank == 0 else 1
 
 
+def global_touched(plan, group, T: int) -> torch.Tensor:
+    """Sorted ids (int64, on the device) of the entities that ANY rank's shard of this batch contains.  Plans are
+    parameter-free and reused every epoch (the loader does not shuffle, vfm-torch.py:121-122), so the ranks agree on the
+    set ONCE per plan: an all-gather of their sorted id lists (padded to the longest), then a sorted unique.  Collective:
+    every rank calls it at the same point (the first statistics-exchange step of the plan does)."""
+    hit = plan.__dict__.get("_gids")
+    if hit is not None and hit[0] is group:
+        return hit[1]
+    mine = plan.touched_ids()
+    dev = mine.device
+    n = torch.tensor([mine.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    nmax = max(int(n.item()), 1)
+    pad = torch.full((nmax,), T, dtype=torch.int32, device=dev)        # (T: a sentinel past every id)
+    pad[: mine.numel()] = mine
+    parts = [torch.empty_like(pad) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, pad, group=group)
+    g = torch.unique(torch.cat(parts))
+    g = g[g < T].to(torch.int64).contiguous()
+    plan.__dict__["_gids"] = (group, g)
+    return g
+
+
 def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambda name: None):
     """One multi-rank training step of `model` on its row shard `plan`, exchanging the gradient's sufficient statistics
     (per rank the reference's loop body, vfm-torch.py:351-370; across ranks one all-reduce of a flat fp32 buffer
@@ -58,17 +81,51 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
     xacc, xs, xl, bounds = model._xviews()
     ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
     mark("finalize")
-    works = []
     rl = ops.exchange_record_len(model.d)
-    for k in range(len(bounds) - 1):
-        lo, hi = bounds[k], bounds[k + 1]
-        ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
-        end = model._xflat.numel() if hi == model.T else hi * rl      # the last range carries the row sums + the loss
-        works.append(dist.all_reduce(model._xflat[lo * rl: end], group=group, async_op=True))
+    T, n = model.T, model.T * rl
+    # COMPACT exchange: only the records of entities that some rank's shard contains are non-zero, and the ranks know
+    # that set (global_touched) -- so what travels is [U_global records | row sums | loss] gathered out of the dense
+    # table, not all T records (cfg4 split 8 ways: 59 % of them; cfg5 at 8 x 2,048 rows: ~41 %).  Still ONE all-reduce
+    # per step, in the same ranges; the kernels keep working on the dense table (zeros stay zeros on every rank).
+    gids = None
+    if model.exchange_compact:
+        g = global_touched(plan, group, T)
+        if g.numel() <= model.exchange_compact_below * T:
+            gids = g
+    works = []
+    if gids is None:
+        for k in range(len(bounds) - 1):
+            lo, hi = bounds[k], bounds[k + 1]
+            ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
+            end = model._xflat.numel() if hi == T else hi * rl      # the last range carries the row sums + the loss
+            works.append(dist.all_reduce(model._xflat[lo * rl: end], group=group, async_op=True))
+        model._exchanged_floats = model._xflat.numel()
+    else:
+        Ug = gids.numel()
+        sb = plan.__dict__.get("_gid_bounds")
+        if sb is None or sb[0] != tuple(bounds):        # slot range of every entity range (once per plan)
+            sb = plan.__dict__["_gid_bounds"] = (tuple(bounds), torch.searchsorted(
+                gids, torch.tensor(bounds, dtype=torch.int64, device=gids.device)).tolist())
+        sb = sb[1]
+        if model._xcompact is None or model._xcompact.numel() < Ug * rl + 8:
+            model._xcompact = torch.empty(n + 8, dtype=torch.float32, device=model.device)
+        cbuf, dense = model._xcompact, xacc.view(T, rl)
+        ops.elbo_backward_acc(plan, st, xacc, xs, 0, T)                      # the statistics kernels are short: one launch
+        torch.index_select(dense, 0, gids, out=cbuf[: Ug * rl].view(Ug, rl))     # ... and one gather of the touched records
+        cbuf[Ug * rl: Ug * rl + 8].copy_(model._xflat[n: n + 8])               # (row sums | loss)
+        for k in range(len(bounds) - 1):
+            end = Ug * rl + 8 if k == len(bounds) - 2 else sb[k + 1] * rl
+            works.append(dist.all_reduce(cbuf[sb[k] * rl: end], group=group, async_op=True))
+        model._exchanged_floats = Ug * rl + 8
     mark("bwd_acc")
     model._adam_t += 1
     for k in range(len(bounds) - 1):
         works[k].wait()
+        if gids is not None:
+            if sb[k + 1] > sb[k]:
+                dense.index_copy_(0, gids[sb[k]: sb[k + 1]], cbuf[sb[k] * rl: sb[k + 1] * rl].view(-1, rl))
+            if k == len(bounds) - 2:
+                model._xflat[n: n + 8].copy_(cbuf[Ug * rl: Ug * rl + 8])
         ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, model._views(model._adam_m),
                             model._views(model._adam_v), lr, model._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1],
                             scaled_moments=model._moments_scaled)

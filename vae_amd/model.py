@@ -166,6 +166,10 @@ class VFM(nn.Module):
         # neither has been measured on a multi-GPU node yet.
         self.exchange = "auto"
         self.exchange_chunks = 4
+        # "stats": exchange only the records of entities some rank's shard contains (vae_amd/dist.py: the ranks agree on
+        # that set once per plan) when they are at most this share of the table
+        self.exchange_compact, self.exchange_compact_below = True, 0.85
+        self._xcompact, self._exchanged_floats = None, 0
         self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
         self.shard_deterministic = False   # (shard_gather=False) add the sources one launch per rank, no atomics
         self._stale_group = None
@@ -267,6 +271,7 @@ class VFM(nn.Module):
         self._xflat = None
         self._la_tab = self._la_ready_for = None          # (look-ahead step table: no row lags after sync_lazy above)
         self._wrec, self._wrec_ok = None, False
+        self._xcompact = None
         self._graphs, self._step_state = {}, None         # (captured steps hold pointers of the old device's buffers)
         self._zrec = self._zrec_for = None                # (sample records of the pipelined step: re-made on demand)
         self._shard_acc = self._shard_small = self._shard_klws = None
