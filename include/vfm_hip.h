@@ -370,6 +370,21 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
                             float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
                             const int32_t* rec_pos, void* stream);
+/* The apply stage over a LIST of rows -- the multi-rank step's lazy exact dense Adam.  With the statistics exchange
+ * compacted to the entities some rank's shard contains (the caller knows that set: it is what it all-reduced), every
+ * other row of the table has a zero gradient on EVERY rank this step, so -- as in the single-rank lazy forms -- its
+ * update can wait: the caller (1) replays what the listed rows skipped with vfm_adam_catchup_f32 (mark = this step)
+ * BEFORE the forward reads them, (2) calls this with the same list after the all-reduce: gradient epilogue + Adam on
+ * the listed rows only (sorted ids; their records at acc + id * (4 + round4(d)) of the DENSE statistics table), and
+ * (3) on the last step of every moment period brings all rows up to date and runs vfm_elbo_apply_adam_f32.  Identical
+ * lists on every rank keep the replicas bit-identical; the trajectory is the dense one (same kernel instance, same
+ * arithmetic per row).  VFM_FLAG_SCALED_MOMENTS required; Philox eps; the launch whose p->e_hi is 0 or T also moves
+ * the three scalars (give the other launches of a chunked run any 0 < e_hi < T). */
+int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const float* sums, const int32_t* row_ids,
+                                 int64_t n_rows, float* entity_params, float* bias_params, float* scalars,
+                                 const float* inv_occ, const double* W, float* m_entity, float* v_entity, float* m_bias,
+                                 float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1, float beta2,
+                                 float eps_adam, int64_t step, void* stream);
 /* rec_ptr / rec_pos (both or neither; rec_pos may be NULL when no record exists at all): GATHER form for the entity-sharded mode -- `acc` is the raw
  * receive buffer of the statistics all-to-all and the records of local entity li are those at positions
  * rec_pos[rec_ptr[li] .. rec_ptr[li+1]) (one per rank that had the entity in its rows); the kernel sums

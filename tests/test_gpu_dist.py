@@ -46,6 +46,7 @@ def _worker(rank, world, port, name, out_dir, exchange="stats"):
         plan = m.plan(torch.tensor(c.x[a:b]), torch.tensor(c.y[a:b]), B_global=B, process_group=dist.group.WORLD)
         loss3, _ = m.train_step(plan, lr=0.05, process_group=dist.group.WORLD)
         losses.append(loss3.cpu().numpy().copy())
+    m.sync_lazy()
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"params_{rank}.npy"), m._flat.cpu().numpy())
     np.save(os.path.join(out_dir, f"loss_{rank}.npy"), np.array(losses))
@@ -452,3 +453,55 @@ def test_switching_exchange_modes_mid_training(tmp_path):
     assert rel_err(g0[:n], want[:n]) < 1e-4 and rel_err(g1[:n], want[:n]) < 1e-4
     assert rel_err(g0[n:2 * n], want[n:2 * n]) < 1e-3 and rel_err(g0[2 * n:], want[2 * n:]) < 1e-3
     assert np.allclose(g0, g1, rtol=1e-5, atol=1e-6 * np.abs(g0).max())
+
+
+@pytest.mark.parametrize("F,d", [(3, 16), (2, 32)])
+def test_lazy_statistics_step_is_bitwise_the_dense_one(F, d, monkeypatch):
+    """The multi-rank statistics step with the exchange compacted to the globally touched entities and the other rows'
+    Adam updates deferred (`exchange_lazy`: catch-up pass + apply stage over the list, vfm_elbo_apply_adam_rows_f32)
+    against the same step with every row updated every step: 140 steps over 3 in-process ranks -- a moment-period
+    boundary, changing learning rates, predictions in between -- parameters and both moments BIT FOR BIT, replicas
+    identical."""
+    from thread_ranks import run_ranks
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    from vae_amd.dist import shard_rows
+    import copy
+    sizes, world, B, nb, n_steps = [900, 700, 400][:F], 3, 96, 5, 140
+    X, y = synthetic_triples(sizes, nb * B, seed=4, device="cuda")
+    results = []
+    for lazy in (True, False):
+        torch.manual_seed(3)
+        first = VFM(field_sizes=sizes, embedding_size=d, device="cuda", rng_seed=11)
+        first.exchange, first.exchange_lazy = "stats", lazy
+        models = [first] + [copy.deepcopy(first) for _ in range(world - 1)]
+        for m in models[1:]:
+            m._tie(); m.__dict__.pop("_view_cache", None)
+
+        def rank_body(rank, group):
+            m = models[rank]
+            m.set_training_data(X, nb_train=nb * B)
+            plans = []
+            for i in range(nb):
+                a, b = shard_rows(i * B, (i + 1) * B, rank, world)
+                plans.append(m.plan(X[a:b], y[a:b], B_global=B, process_group=group))
+            losses, lagged = [], False
+            for s in range(n_steps):
+                l3, _ = m.train_step(plans[s % nb], lr=0.05 if s % 7 else 0.02, process_group=group)
+                lagged = lagged or m._lazy_dirty
+                if s % 20 == 3 or s in (127, 128):
+                    losses.append(l3.clone())
+                if s == 60:
+                    losses.append(m.predict(X[:50])["y_pred"].sum().reshape(1).repeat(3))
+            m.sync_lazy()
+            return m._flat, m._adam_m, m._adam_v, torch.stack(losses), lagged, m._exchanged_floats
+
+        out, _ = run_ranks(world, rank_body, monkeypatch)
+        for r in range(1, world):
+            assert all(torch.equal(out[r][i], out[0][i]) for i in range(4))
+        results.append(out[0])
+    lz, dn = results
+    assert lz[4] and not dn[4]                       # rows did lag in the lazy run
+    assert lz[5] == dn[5] and lz[5] < 0.5 * first.T * (d + 4)      # both exchanged the compact buffer
+    for i in range(4):
+        assert torch.equal(lz[i], dn[i]), i

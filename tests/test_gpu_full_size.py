@@ -174,6 +174,7 @@ def test_cfg5_global_batch_over_8_ranks_equals_1_rank(exchange, monkeypatch):
         assert b - a == cfg["B"]
         plan = m.plan(X[a:b], y[a:b], B_global=Bg, process_group=group)
         losses = [m.train_step(plan, lr=0.01, process_group=group)[0].clone() for _ in range(n_steps)]
+        m.sync_lazy()              # (rows outside the exchanged set wait for their zero-gradient updates until read)
         return m._flat, torch.stack(losses)
 
     out, sh = run_ranks(world, rank_body, monkeypatch)
@@ -211,6 +212,7 @@ def _cfg4_worker(rank, world, port, exchange, n_steps, out_dir):
     a, b = shard_rows(0, cfg["B"], rank, world)
     plan = m.plan(X[a:b], y[a:b], B_global=cfg["B"], process_group=dist.group.WORLD)
     losses = [m.train_step(plan, lr=0.01, process_group=dist.group.WORLD)[0].cpu().numpy().copy() for _ in range(n_steps)]
+    m.sync_lazy()
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"p_{rank}.npy"), m._flat.cpu().numpy())
     np.save(os.path.join(out_dir, f"l_{rank}.npy"), np.array(losses))
@@ -256,6 +258,7 @@ def test_cfg4_batch_over_8_ranks_equals_1_rank(exchange, monkeypatch):
         assert b - a == 12500
         plan = m.plan(X[a:b], y[a:b], B_global=cfg["B"], process_group=group)
         losses = [m.train_step(plan, lr=0.01, process_group=group)[0].clone() for _ in range(n_steps)]
+        m.sync_lazy()              # (rows outside the exchanged set wait for their zero-gradient updates until read)
         return m._flat, torch.stack(losses)
 
     out, sh = run_ranks(world, rank_body, monkeypatch)

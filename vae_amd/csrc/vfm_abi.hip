@@ -584,15 +584,15 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   return after_launch("vfm_elbo_bwd_acc_f32");
 }
 
-int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const float* sums,
-                            float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
-                            const double* W, const float* eps_entity, const float* eps_bias,
-                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
-                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
-                            const int32_t* rec_pos, void* stream) {
+static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float* sums,
+                           float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
+                           const double* W, const float* eps_entity, const float* eps_bias,
+                           const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
+                           float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
+                           float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
+                           const int32_t* rec_pos, const int32_t* row_ids, int64_t n_rows, void* stream, const char* who) {
   if (int rc = check_problem(p)) return rc;
-  if (int rc = single_sample_only(p, "vfm_elbo_apply_adam_f32")) return rc;
+  if (int rc = single_sample_only(p, who)) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1)
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: bad argument");
@@ -607,14 +607,46 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
             const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
   if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
     return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
+  if (row_ids) {
+    if (rec_ptr || p->own_mod > 1 || n_rows < 0 || n_rows > p->T)
+      return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: a row list excludes the gather form and entity sharding; 0 <= n_rows <= T");
+    b.row_ids = row_ids; b.n_rows = n_rows;
+  }
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
+  if (row_ids && (!ad.scaled || ad.store_true))
+    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: scaled moments only, and not on the last step of a moment period "
+                               "(bring every row up to date and run vfm_elbo_apply_adam_f32)");
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
   if (kl_ws) hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, kl_ws);
-  return after_launch("vfm_elbo_apply_adam_f32");
+  return after_launch(who);
+}
+
+int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const float* sums,
+                            float* entity_params, float* bias_params, float* scalars, const float* inv_occ,
+                            const double* W, const float* eps_entity, const float* eps_bias,
+                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
+                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
+                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
+                            const int32_t* rec_pos, void* stream) {
+  return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, eps_entity, eps_bias, eps_global,
+                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, kl_ws,
+                         rec_ptr, rec_pos, nullptr, 0, stream, "vfm_elbo_apply_adam_f32");
+}
+
+int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const float* sums, const int32_t* row_ids,
+                                 int64_t n_rows, float* entity_params, float* bias_params, float* scalars,
+                                 const float* inv_occ, const double* W, float* m_entity, float* v_entity, float* m_bias,
+                                 float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1, float beta2,
+                                 float eps_adam, int64_t step, void* stream) {
+  if (!row_ids && n_rows != 0) return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: row_ids is NULL");
+  static const int32_t none = 0;
+  return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, nullptr, nullptr, nullptr,
+                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, nullptr,
+                         nullptr, nullptr, row_ids ? row_ids : &none, n_rows, stream, "vfm_elbo_apply_adam_rows_f32");
 }
 
 int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,

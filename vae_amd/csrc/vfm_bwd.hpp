@@ -161,7 +161,10 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   // fused Adam with a row list (the lazy exact-Adam step): li runs over the list (the batch's entities), not over
   // the table.  The SAME instance serves the dense step, so the two agree bit for bit on the rows they share
   // (different template instances are compiled with different fma contractions).
-  const bool listed = ADAM != 0 && STAGE == STAGE_FULL && b.row_ids != nullptr;
+  // (STAGE_APPLY with a list -- vfm_elbo_apply_adam_rows_f32: the multi-rank step's lazy exact form -- visits the
+  // listed rows only; their records sit in the DENSE statistics table, at the entity's own index)
+  const bool listed = ADAM != 0 && b.row_ids != nullptr &&
+                      (STAGE == STAGE_FULL || (STAGE == STAGE_APPLY && !sharded && b.occ_ptr == nullptr));
   const int64_t li_end = listed ? b.n_rows : a.e_hi;
   int64_t li = (listed ? 0 : a.e_lo) + (int64_t)blockIdx.x * GPB + tid / LPE;
   int64_t e_cur = li;
@@ -182,8 +185,9 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
           gc.x += t2.x; gc.y += t2.y;
         }
       } else {
-        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)li * xs);   // (sum of grow, occurrences) over ALL ranks
+        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)(listed ? e : li) * xs);   // (sum of grow, occurrences) over ALL ranks
       }
+      if (listed && en < li_end) e_cur = b.row_ids[en];
       beg = 0; end = 0;
     } else {
       if (en < li_end) {                                                    // next entity's offsets, early
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 #pragma unroll
           for (int i = 0; i < CPL; ++i) {
             const int j = lig + i * LPE;
-            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)li * xs + 4 + (size_t)j * VEC);
+            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)(listed ? e : li) * xs + 4 + (size_t)j * VEC);
           }
         }
       }

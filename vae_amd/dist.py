@@ -66,36 +66,68 @@ def global_touched(plan, group, T: int) -> torch.Tensor:
 def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambda name: None):
     """One multi-rank training step of `model` on its row shard `plan`, exchanging the gradient's sufficient statistics
     (per rank the reference's loop body, vfm-torch.py:351-370; across ranks one all-reduce of a flat fp32 buffer
-    [T records (sum grow, count, 0, 0 | A_e) | row sums | loss], in `model.exchange_chunks` entity ranges: the
-    all-reduce of range k overlaps the statistics kernel of range k+1 and the epilogue + Adam kernel of range k-1).
-    Every rank then applies the same dense Adam update from the global statistics: replicas stay bit-identical."""
+    [records (sum grow, count, 0, 0 | A_e) | row sums | loss], in `model.exchange_chunks` entity ranges: the
+    all-reduce of range k overlaps the epilogue + Adam kernel of range k-1).  Every rank then applies the same dense
+    Adam update from the global statistics: replicas stay bit-identical.
+
+    COMPACT exchange (`model.exchange_compact`): only the records of entities that some rank's shard contains are
+    non-zero, and the ranks know that set (`global_touched`) -- what travels is [U_global records | row sums | loss]
+    gathered out of the dense table, not all T records (cfg4 split 8 ways: 59 % of them; cfg5 at 8 x 2,048 rows: ~41 %).
+    LAZY exact Adam on top of it (`model.exchange_lazy`; scaled moments): every row outside that set has a zero gradient on
+    EVERY rank, so -- exactly as in the single-rank row-list form -- it is skipped and its zero-gradient updates are
+    replayed (bitwise as the dense kernel applies them) right before a later batch needs it: per step a catch-up pass on
+    the set's rows (before the forward reads them), then the apply stage over the same list; the last step of every moment
+    period brings all rows up to date and runs the dense apply.  The same lists on every rank: replicas stay identical."""
     from . import ops
     ent, bia, scal = model._views(model._flat)
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     sumz, grow, pred = model._step_buffers(plan.B)
-    st = ops.elbo_forward(plan, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
-                          flags=prior_terms_flag(dist.get_rank(group)), out_pred=out_pred if out_pred is not None else pred,
-                          out_sumz=sumz, out_grow=grow, out_partials=model._partials)
-    mark("fwd")
-    model._set_moment_form(model.scaled_moments)
-    xacc, xs, xl, bounds = model._xviews()
-    ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
-    mark("finalize")
     rl = ops.exchange_record_len(model.d)
     T, n = model.T, model.T * rl
-    # COMPACT exchange: only the records of entities that some rank's shard contains are non-zero, and the ranks know
-    # that set (global_touched) -- so what travels is [U_global records | row sums | loss] gathered out of the dense
-    # table, not all T records (cfg4 split 8 ways: 59 % of them; cfg5 at 8 x 2,048 rows: ~41 %).  Still ONE all-reduce
-    # per step, in the same ranges; the kernels keep working on the dense table (zeros stay zeros on every rank).
-    gids = None
+    model._set_moment_form(model.scaled_moments)
+    gids = gids32 = None
     if model.exchange_compact:
         g = global_touched(plan, group, T)
         if g.numel() <= model.exchange_compact_below * T:
             gids = g
+            gids32 = plan.__dict__.get("_gids32")
+            if gids32 is None or gids32.numel() != g.numel():
+                gids32 = plan.__dict__["_gids32"] = g.to(torch.int32)
+    # ---- lazy exact Adam over the exchanged set: the rows of the set are brought up to date BEFORE the forward reads them
+    t = model._adam_t + 1
+    k = (t - 1) % ops.MOMENT_PERIOD + 1
+    if k == 1:
+        model._lazy_lr = {}
+    model._lazy_lr[k] = float(lr)
+    lazy = gids is not None and model.exchange_lazy and model._moments_scaled and eps is None
+    mv, vv = model._views(model._adam_m), model._views(model._adam_v)
+    if model._lazy_dirty and (not lazy or model._lazy_kind != "list"):
+        model.sync_lazy(t - 1)
+    listed = False
+    if lazy:
+        if model._lazy_last is None:
+            model._lazy_last = torch.empty(T, dtype=torch.int32, device=model.device)
+        if not model._lazy_dirty:
+            model._lazy_last.fill_(t - 1)
+        if k < ops.MOMENT_PERIOD:
+            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, gids32, model._lazy_lrs(k - 1), upto=t - 1, mark=t)
+            model._lazy_dirty, model._lazy_kind, listed = True, "list", True
+        else:       # the dense kernel rewrites every row's moments at a period end: every row up to date first
+            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, None, model._lazy_lrs(k - 1), upto=t - 1, mark=t)
+            model._lazy_dirty = False
+        mark("catchup")
+    st = ops.elbo_forward(plan, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
+                          flags=prior_terms_flag(dist.get_rank(group)), out_pred=out_pred if out_pred is not None else pred,
+                          out_sumz=sumz, out_grow=grow, out_partials=model._partials)
+    mark("fwd")
+    xacc, xs, xl, bounds = model._xviews()
+    ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
+    mark("finalize")
     works = []
+    nch = len(bounds) - 1
     if gids is None:
-        for k in range(len(bounds) - 1):
-            lo, hi = bounds[k], bounds[k + 1]
+        for c in range(nch):
+            lo, hi = bounds[c], bounds[c + 1]
             ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
             end = model._xflat.numel() if hi == T else hi * rl      # the last range carries the row sums + the loss
             works.append(dist.all_reduce(model._xflat[lo * rl: end], group=group, async_op=True))
@@ -107,28 +139,31 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
             sb = plan.__dict__["_gid_bounds"] = (tuple(bounds), torch.searchsorted(
                 gids, torch.tensor(bounds, dtype=torch.int64, device=gids.device)).tolist())
         sb = sb[1]
-        if model._xcompact is None or model._xcompact.numel() < Ug * rl + 8:
+        if model._xcompact is None:
             model._xcompact = torch.empty(n + 8, dtype=torch.float32, device=model.device)
         cbuf, dense = model._xcompact, xacc.view(T, rl)
         ops.elbo_backward_acc(plan, st, xacc, xs, 0, T)                      # the statistics kernels are short: one launch
         torch.index_select(dense, 0, gids, out=cbuf[: Ug * rl].view(Ug, rl))     # ... and one gather of the touched records
         cbuf[Ug * rl: Ug * rl + 8].copy_(model._xflat[n: n + 8])               # (row sums | loss)
-        for k in range(len(bounds) - 1):
-            end = Ug * rl + 8 if k == len(bounds) - 2 else sb[k + 1] * rl
-            works.append(dist.all_reduce(cbuf[sb[k] * rl: end], group=group, async_op=True))
+        for c in range(nch):
+            end = Ug * rl + 8 if c == nch - 1 else sb[c + 1] * rl
+            works.append(dist.all_reduce(cbuf[sb[c] * rl: end], group=group, async_op=True))
         model._exchanged_floats = Ug * rl + 8
     mark("bwd_acc")
-    model._adam_t += 1
-    for k in range(len(bounds) - 1):
-        works[k].wait()
+    model._adam_t = t
+    for c in range(nch):
+        works[c].wait()
         if gids is not None:
-            if sb[k + 1] > sb[k]:
-                dense.index_copy_(0, gids[sb[k]: sb[k + 1]], cbuf[sb[k] * rl: sb[k + 1] * rl].view(-1, rl))
-            if k == len(bounds) - 2:
+            if sb[c + 1] > sb[c]:
+                dense.index_copy_(0, gids[sb[c]: sb[c + 1]], cbuf[sb[c] * rl: sb[c + 1] * rl].view(-1, rl))
+            if c == nch - 1:
                 model._xflat[n: n + 8].copy_(cbuf[Ug * rl: Ug * rl + 8])
-        ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, model._views(model._adam_m),
-                            model._views(model._adam_v), lr, model._adam_t, e_lo=bounds[k], e_hi=bounds[k + 1],
-                            scaled_moments=model._moments_scaled)
+        if listed:
+            ops.elbo_apply_adam_rows(plan, st, xacc, xs, gids32[sb[c]: sb[c + 1]], ent, bia, scal, model.inv_occ, mv, vv,
+                                     lr, t, move_scalars=c == nch - 1)
+        else:
+            ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, mv, vv, lr, t,
+                                e_lo=bounds[c], e_hi=bounds[c + 1], scaled_moments=model._moments_scaled)
     mark("exchange_apply_adam")
     loss3.copy_(xl)
     return loss3, st.pred

@@ -169,6 +169,9 @@ class VFM(nn.Module):
         # "stats": exchange only the records of entities some rank's shard contains (vae_amd/dist.py: the ranks agree on
         # that set once per plan) when they are at most this share of the table
         self.exchange_compact, self.exchange_compact_below = True, 0.85
+        # ... and let the rows outside that set (zero gradient on every rank) wait, replayed bit for bit later: the
+        # multi-rank form of the row-list lazy exact Adam (vae_amd/dist.py::step_stats)
+        self.exchange_lazy = True
         self._xcompact, self._exchanged_floats = None, 0
         self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
         self.shard_deterministic = False   # (shard_gather=False) add the sources one launch per rank, no atomics
@@ -602,8 +605,9 @@ class VFM(nn.Module):
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
-        if process_group is not None:
-            self.sync_lazy()          # the multi-rank steps update every row they own
+        stats_step = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
+        if process_group is not None and not stats_step:
+            self.sync_lazy()          # these multi-rank steps update every row they own (the statistics step keeps its own lazy state)
         # a step in another mode than the one that left the full tables stale: bring them up to date first
         if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_kind", None) not in (
                 None, self.exchange if process_group is not None else "single"):
@@ -632,11 +636,11 @@ class VFM(nn.Module):
         wrec = self._wrec_for_step(fused and eps is None and self.n_samples == 1 and not self.sparse_adam)
         if fused:
             return self._step_fused(plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec)
-        if self._lazy_dirty:
-            self.sync_lazy()
         if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             from .dist import step_stats
             return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark)
+        if self._lazy_dirty:
+            self.sync_lazy()
         return self._step_unfused(plan, lr, step, eps, out_pred, adam, mark, process_group)
 
     def _step_unfused(self, plan, lr, step, eps, out_pred, adam, mark, process_group=None):
