@@ -8,14 +8,21 @@ of the gradients when N>1,) dense Adam over every parameter.  Inputs (ids, targe
 counts, per-batch normalisers and inverted index) are resident in HBM before the timed region.
 
 Workload (BASELINE.json configs[2]): synthetic ML-20M-shape triples, N=138,493 users x M=26,744
-items, d=128, batch B=100,000 rows per GPU (the reference's BATCH_SIZE, vfm-torch.py:77),
+items, d=128, global batch B=100,000 rows (the reference's BATCH_SIZE, vfm-torch.py:77),
 uniform-random ids, ratings randint(1,6), eps generated in-kernel (Philox).
-N>1: every rank processes its own B rows of a global batch of N*B rows (weak scaling), tables
-replicated, one all-reduce of the flat gradient buffer per step.
+N>1 (BASELINE configs[3]): the north star's pattern only -- the batch row-sharded over the ranks, tables replicated, ONE
+all-reduce per step -- in both of its forms (`stats`: the gradient's sufficient statistics, compacted to the entities
+some rank's shard contains; `grads`: the flat gradient buffer), each timed, the faster one is the headline
+(`candidates` lists both).  Headline regime: STRONG (SURVEY cfg4: the 100,000-row batch split by rows); the same mode in
+the WEAK regime (100,000 rows per rank) under the key `weak`.  Every candidate is probed first and dropped if it projects
+past --mode-budget-s; a watchdog ends a run that hangs in a collective after --wall-limit-s.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the kernel that takes the most time per
-step (its `elbo_fwd_kernel` entry is the fused forward ELBO kernel); `kernels` lists all of them.  `cpu_baseline` = the reference-shaped torch-CPU restatement
-(oracle/vfm_oracle.py, pinned to the reference by tests/golden) timed on this node's host cores.
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel that takes the most time per step (its `elbo_fwd_kernel`
+entry is the fused forward ELBO kernel; `frac_fwd_8d` / `frac_K_8d` are SURVEY 8(d)'s own figures against the 0.60
+target); `kernels` lists all of them (HIP events on every 5th step of the timed region); `sustained` / `replayed` = 2,000
+more steps eagerly / as replayed HIP graphs.  `cpu_baseline` = the reference-shaped torch-CPU restatement
+(oracle/vfm_oracle.py, pinned to the reference by tests/golden; the reference's two unused per-row lookups included)
+timed on this node's host cores.
 """
 import argparse
 import json
