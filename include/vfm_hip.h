@@ -375,13 +375,18 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
  * other row of the table has a zero gradient on EVERY rank this step, so -- as in the single-rank lazy forms -- its
  * update can wait: the caller (1) replays what the listed rows skipped with vfm_adam_catchup_f32 (mark = this step)
  * BEFORE the forward reads them, (2) calls this with the same list after the all-reduce: gradient epilogue + Adam on
- * the listed rows only (sorted ids; their records at acc + id * (4 + round4(d)) of the DENSE statistics table), and
+ * the listed rows only (sorted ids; compact_records == 0: their records at acc + id * (4 + round4(d)) of the DENSE
+ * statistics table; != 0: acc is a COMPACT buffer, record i belongs to row_ids[i] -- what vfm_elbo_bwd_acc_rows_f32
+ * writes and the compacted exchange all-reduces, so no dense table is involved at all), and
  * (3) on the last step of every moment period brings all rows up to date and runs vfm_elbo_apply_adam_f32.  Identical
  * lists on every rank keep the replicas bit-identical; the trajectory is the dense one (same kernel instance, same
  * arithmetic per row).  VFM_FLAG_SCALED_MOMENTS required; Philox eps; the launch whose p->e_hi is 0 or T also moves
  * the three scalars (give the other launches of a chunked run any 0 < e_hi < T). */
+int vfm_elbo_bwd_acc_rows_f32(const vfm_problem_t* p, const vfm_index_t* idx, const int32_t* row_ids, int64_t n_rows,
+                              const float* sumz, const float* grow, const double* partials, float* acc,
+                              float* sums, void* stream);      /* statistics of the listed rows, record i <-> row_ids[i] */
 int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const float* sums, const int32_t* row_ids,
-                                 int64_t n_rows, float* entity_params, float* bias_params, float* scalars,
+                                 int64_t n_rows, int32_t compact_records, float* entity_params, float* bias_params, float* scalars,
                                  const float* inv_occ, const double* W, float* m_entity, float* v_entity, float* m_bias,
                                  float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1, float beta2,
                                  float eps_adam, int64_t step, void* stream);

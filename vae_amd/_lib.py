@@ -37,6 +37,7 @@ EXPORTS = (
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32", "vfm_union_rows", "vfm_union_workspace_bytes",
     "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
     "vfm_step_consts", "vfm_dev_step_set", "vfm_wrec_build_f32", "vfm_elbo_apply_adam_rows_f32",
+    "vfm_elbo_bwd_acc_rows_f32",
 )
 
 
@@ -134,7 +135,8 @@ def load():
     lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 7
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
                                             [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp, vp, vp])
-    lib.vfm_elbo_apply_adam_rows_f32.argtypes = ([PP, vp, vp, vp, i64] + [vp] * 11 +
+    lib.vfm_elbo_bwd_acc_rows_f32.argtypes = [PP, C.POINTER(Index), vp, i64] + [vp] * 6
+    lib.vfm_elbo_apply_adam_rows_f32.argtypes = ([PP, vp, vp, vp, i64, i32] + [vp] * 11 +
                                                  [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     lib.vfm_shard_sample_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]

@@ -558,17 +558,22 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   return after_launch("vfm_elbo_bwd_adam_f32");
 }
 
-int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
-                         const float* sumz, const float* grow, const double* partials, float* acc,
-                         float* sums, void* stream) {
+static int bwd_acc_impl(const vfm_problem_t* p, const vfm_index_t* idx, const int32_t* row_ids, int64_t n_rows,
+                        const float* sumz, const float* grow, const double* partials, float* acc, float* sums, void* stream,
+                        const char* who) {
   if (int rc = check_problem(p)) return rc;
-  if (int rc = single_sample_only(p, "vfm_elbo_bwd_acc_f32")) return rc;
-  if (int rc = check_index(p, idx, "vfm_elbo_bwd_acc_f32")) return rc;
+  if (int rc = single_sample_only(p, who)) return rc;
+  if (int rc = check_index(p, idx, who)) return rc;
   if (!partials || !acc || !sums || (p->B > 0 && (!sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
             nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  if (row_ids) {        // the listed rows only, their records written COMPACTLY (record i <-> row_ids[i])
+    if (n_rows < 0 || n_rows > p->T || p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T))
+      return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_rows_f32: 0 <= n_rows <= T, whole entity range");
+    b.row_ids = row_ids; b.n_rows = n_rows; b.rec_by_slot = 1;
+  }
   // (the pre-reduction covers whole lists, so with several entity chunks it runs with the first one)
   if (p->e_lo == 0)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
@@ -581,7 +586,22 @@ int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, EPS_ZERO, 10, a, b, ad, (hipStream_t)stream)) return rc;
-  return after_launch("vfm_elbo_bwd_acc_f32");
+  return after_launch(who);
+}
+
+int vfm_elbo_bwd_acc_f32(const vfm_problem_t* p, const vfm_index_t* idx,
+                         const float* sumz, const float* grow, const double* partials, float* acc,
+                         float* sums, void* stream) {
+  return bwd_acc_impl(p, idx, nullptr, 0, sumz, grow, partials, acc, sums, stream, "vfm_elbo_bwd_acc_f32");
+}
+
+int vfm_elbo_bwd_acc_rows_f32(const vfm_problem_t* p, const vfm_index_t* idx, const int32_t* row_ids, int64_t n_rows,
+                              const float* sumz, const float* grow, const double* partials, float* acc,
+                              float* sums, void* stream) {
+  static const int32_t none = 0;
+  if (!row_ids && n_rows != 0) return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_rows_f32: row_ids is NULL");
+  return bwd_acc_impl(p, idx, row_ids ? row_ids : &none, n_rows, sumz, grow, partials, acc, sums, stream,
+                      "vfm_elbo_bwd_acc_rows_f32");
 }
 
 static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float* sums,
@@ -590,7 +610,8 @@ static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float
                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
-                           const int32_t* rec_pos, const int32_t* row_ids, int64_t n_rows, void* stream, const char* who) {
+                           const int32_t* rec_pos, const int32_t* row_ids, int64_t n_rows, int32_t compact, void* stream,
+                           const char* who) {
   if (int rc = check_problem(p)) return rc;
   if (int rc = single_sample_only(p, who)) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
@@ -610,7 +631,7 @@ static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float
   if (row_ids) {
     if (rec_ptr || p->own_mod > 1 || n_rows < 0 || n_rows > p->T)
       return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: a row list excludes the gather form and entity sharding; 0 <= n_rows <= T");
-    b.row_ids = row_ids; b.n_rows = n_rows;
+    b.row_ids = row_ids; b.n_rows = n_rows; b.rec_by_slot = compact ? 1 : 0;
   }
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
@@ -634,11 +655,11 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const int32_t* rec_pos, void* stream) {
   return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, eps_entity, eps_bias, eps_global,
                          m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, kl_ws,
-                         rec_ptr, rec_pos, nullptr, 0, stream, "vfm_elbo_apply_adam_f32");
+                         rec_ptr, rec_pos, nullptr, 0, 0, stream, "vfm_elbo_apply_adam_f32");
 }
 
 int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const float* sums, const int32_t* row_ids,
-                                 int64_t n_rows, float* entity_params, float* bias_params, float* scalars,
+                                 int64_t n_rows, int32_t compact_records, float* entity_params, float* bias_params, float* scalars,
                                  const float* inv_occ, const double* W, float* m_entity, float* v_entity, float* m_bias,
                                  float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1, float beta2,
                                  float eps_adam, int64_t step, void* stream) {
@@ -646,7 +667,8 @@ int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const
   static const int32_t none = 0;
   return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, nullptr, nullptr, nullptr,
                          m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, nullptr,
-                         nullptr, nullptr, row_ids ? row_ids : &none, n_rows, stream, "vfm_elbo_apply_adam_rows_f32");
+                         nullptr, nullptr, row_ids ? row_ids : &none, n_rows, compact_records, stream,
+                         "vfm_elbo_apply_adam_rows_f32");
 }
 
 int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,

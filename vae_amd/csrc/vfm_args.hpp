@@ -104,6 +104,9 @@ struct BwdArgs {
   int32_t* last_step;             // [T] last Adam step applied to each row
   float2* step_tab;               // [VFM_MOMENT_PERIOD + 1] (a1, q2) of the k-th step of the moment period
   int32_t la_step, la_k;          // this Adam step and its position in the period
+  // multi-rank stages with a row list: 1 = the statistics records form a COMPACT buffer, record i belongs to row_ids[i]
+  // (what the compacted exchange all-reduces); 0 = records sit in the dense [T] table at the entity's own index
+  int32_t rec_by_slot;
 };
 
 struct AdamArgs {

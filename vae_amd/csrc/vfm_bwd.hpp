@@ -163,16 +163,21 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   // (different template instances are compiled with different fma contractions).
   // (STAGE_APPLY with a list -- vfm_elbo_apply_adam_rows_f32: the multi-rank step's lazy exact form -- visits the
   // listed rows only; their records sit in the DENSE statistics table, at the entity's own index)
-  const bool listed = ADAM != 0 && b.row_ids != nullptr &&
-                      (STAGE == STAGE_FULL || (STAGE == STAGE_APPLY && !sharded && b.occ_ptr == nullptr));
+  // (the multi-rank stages take a list too -- vfm_elbo_bwd_acc_rows_f32 / vfm_elbo_apply_adam_rows_f32: the rows some
+  // rank's shard contains; their records sit in the DENSE statistics table at the entity's own index, or, with
+  // b.rec_by_slot, in a COMPACT buffer at the row's position in the list)
+  const bool listed = b.row_ids != nullptr &&
+                      (STAGE == STAGE_FULL ? ADAM != 0
+                                           : (STAGE == STAGE_ACC || (!sharded && b.occ_ptr == nullptr)));
   const int64_t li_end = listed ? b.n_rows : a.e_hi;
   int64_t li = (listed ? 0 : a.e_lo) + (int64_t)blockIdx.x * GPB + tid / LPE;
   int64_t e_cur = li;
-  if (ADAM != 0 && listed && li < li_end) e_cur = b.row_ids[li];
+  if (listed && li < li_end) e_cur = b.row_ids[li];
   int2 pq = make_int2(0, 0);
   if (STAGE != STAGE_APPLY && li < li_end) pq = make_int2(b.occ_ptr[e_cur], b.occ_ptr[e_cur + 1]);
   for (; li < li_end; li += stride) {
-    const int64_t e = (ADAM != 0 && listed) ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
+    const int64_t e = listed ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
+    const int64_t rec = (listed && !b.rec_by_slot) ? e : li;      // where this row's statistics record sits (multi-rank stages)
     int beg = pq.x, end = pq.y;
     const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
@@ -185,13 +190,13 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
           gc.x += t2.x; gc.y += t2.y;
         }
       } else {
-        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)(listed ? e : li) * xs);   // (sum of grow, occurrences) over ALL ranks
+        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)rec * xs);   // (sum of grow, occurrences) over ALL ranks
       }
       if (listed && en < li_end) e_cur = b.row_ids[en];
       beg = 0; end = 0;
     } else {
       if (en < li_end) {                                                    // next entity's offsets, early
-        const int64_t e_next = (ADAM != 0 && listed) ? (int64_t)b.row_ids[en] : en;
+        const int64_t e_next = listed ? (int64_t)b.row_ids[en] : en;
         e_cur = e_next;
         pq = make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]);
       }
@@ -330,9 +335,9 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
         const int j = lig + i * LPE;
-        if (j < C) st_chunk<VEC>(b.acc + (size_t)e * xs + 4 + (size_t)j * VEC, A[i]);
+        if (j < C) st_chunk<VEC>(b.acc + (size_t)rec * xs + 4 + (size_t)j * VEC, A[i]);
       }
-      if (lig == 0) *reinterpret_cast<float4*>(b.acc + (size_t)e * xs) = make_float4(gs, cntf, 0.f, 0.f);
+      if (lig == 0) *reinterpret_cast<float4*>(b.acc + (size_t)rec * xs) = make_float4(gs, cntf, 0.f, 0.f);
       continue;
     }
     if constexpr (STAGE == STAGE_APPLY) {
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 #pragma unroll
           for (int i = 0; i < CPL; ++i) {
             const int j = lig + i * LPE;
-            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)(listed ? e : li) * xs + 4 + (size_t)j * VEC);
+            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)rec * xs + 4 + (size_t)j * VEC);
           }
         }
       }

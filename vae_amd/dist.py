@@ -121,18 +121,9 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
                           out_sumz=sumz, out_grow=grow, out_partials=model._partials)
     mark("fwd")
     xacc, xs, xl, bounds = model._xviews()
-    ops.elbo_finalize(st, scal, out=xl)               # this shard's loss terms (prior terms: rank 0)
-    mark("finalize")
     works = []
     nch = len(bounds) - 1
-    if gids is None:
-        for c in range(nch):
-            lo, hi = bounds[c], bounds[c + 1]
-            ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
-            end = model._xflat.numel() if hi == T else hi * rl      # the last range carries the row sums + the loss
-            works.append(dist.all_reduce(model._xflat[lo * rl: end], group=group, async_op=True))
-        model._exchanged_floats = model._xflat.numel()
-    else:
+    if gids is not None:
         Ug = gids.numel()
         sb = plan.__dict__.get("_gid_bounds")
         if sb is None or sb[0] != tuple(bounds):        # slot range of every entity range (once per plan)
@@ -141,29 +132,56 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
         sb = sb[1]
         if model._xcompact is None:
             model._xcompact = torch.empty(n + 8, dtype=torch.float32, device=model.device)
-        cbuf, dense = model._xcompact, xacc.view(T, rl)
-        ops.elbo_backward_acc(plan, st, xacc, xs, 0, T)                      # the statistics kernels are short: one launch
-        torch.index_select(dense, 0, gids, out=cbuf[: Ug * rl].view(Ug, rl))     # ... and one gather of the touched records
-        cbuf[Ug * rl: Ug * rl + 8].copy_(model._xflat[n: n + 8])               # (row sums | loss)
-        for c in range(nch):
-            end = Ug * rl + 8 if c == nch - 1 else sb[c + 1] * rl
-            works.append(dist.all_reduce(cbuf[sb[c] * rl: end], group=group, async_op=True))
+        cbuf = model._xcompact                              # [U_global records | row sums: 2 | pad: 2 | loss: 3 | pad]
+        tail = cbuf[Ug * rl: Ug * rl + 8]
         model._exchanged_floats = Ug * rl + 8
+    if listed:
+        # compact AND lazy: the statistics are written straight into the compact buffer (record i <-> gids[i]), that is
+        # all-reduced, and the apply stage reads it in place -- no dense statistics table in the step at all.  Ranges of
+        # SLOTS here, and no more of them than keeps an apply launch at >= ~48 K rows (a 24 K-row launch measured 51 us
+        # for 146 MB -- latency, not bandwidth; cfg4 split 8 ways: 2 ranges, cfg5: 4)
+        nch = max(1, min(int(model.exchange_chunks), -(-Ug // 49152)))
+        sb = [Ug * i // nch for i in range(nch + 1)]
+        xs, xl = tail[0:2], tail[4:7]
+        ops.elbo_finalize(st, scal, out=xl)           # this shard's loss terms (prior terms: rank 0)
+        mark("finalize")
+        ops.elbo_backward_acc_rows(plan, st, gids32, cbuf, xs)
+        for c in range(nch):
+            end = Ug * rl + 8 if c == nch - 1 else sb[c + 1] * rl      # the last range carries the row sums + the loss
+            works.append(dist.all_reduce(cbuf[sb[c] * rl: end], group=group, async_op=True))
+    else:
+        ops.elbo_finalize(st, scal, out=xl)
+        mark("finalize")
+        if gids is None:
+            for c in range(nch):
+                lo, hi = bounds[c], bounds[c + 1]
+                ops.elbo_backward_acc(plan, st, xacc, xs, lo, hi)
+                end = model._xflat.numel() if hi == T else hi * rl
+                works.append(dist.all_reduce(model._xflat[lo * rl: end], group=group, async_op=True))
+            model._exchanged_floats = model._xflat.numel()
+        else:       # compact exchange around the dense kernels (every row updated this step: period ends, exchange_lazy off)
+            dense = xacc.view(T, rl)
+            ops.elbo_backward_acc(plan, st, xacc, xs, 0, T)
+            torch.index_select(dense, 0, gids, out=cbuf[: Ug * rl].view(Ug, rl))
+            tail.copy_(model._xflat[n: n + 8])
+            for c in range(nch):
+                end = Ug * rl + 8 if c == nch - 1 else sb[c + 1] * rl
+                works.append(dist.all_reduce(cbuf[sb[c] * rl: end], group=group, async_op=True))
     mark("bwd_acc")
     model._adam_t = t
     for c in range(nch):
         works[c].wait()
+        if listed:
+            ops.elbo_apply_adam_rows(plan, st, cbuf[sb[c] * rl:], xs, gids32[sb[c]: sb[c + 1]], ent, bia, scal, model.inv_occ,
+                                     mv, vv, lr, t, move_scalars=c == nch - 1, compact=True)
+            continue
         if gids is not None:
             if sb[c + 1] > sb[c]:
                 dense.index_copy_(0, gids[sb[c]: sb[c + 1]], cbuf[sb[c] * rl: sb[c + 1] * rl].view(-1, rl))
             if c == nch - 1:
-                model._xflat[n: n + 8].copy_(cbuf[Ug * rl: Ug * rl + 8])
-        if listed:
-            ops.elbo_apply_adam_rows(plan, st, xacc, xs, gids32[sb[c]: sb[c + 1]], ent, bia, scal, model.inv_occ, mv, vv,
-                                     lr, t, move_scalars=c == nch - 1)
-        else:
-            ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, mv, vv, lr, t,
-                                e_lo=bounds[c], e_hi=bounds[c + 1], scaled_moments=model._moments_scaled)
+                model._xflat[n: n + 8].copy_(tail)
+        ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, mv, vv, lr, t,
+                            e_lo=bounds[c], e_hi=bounds[c + 1], scaled_moments=model._moments_scaled)
     mark("exchange_apply_adam")
     loss3.copy_(xl)
     return loss3, st.pred

@@ -614,15 +614,34 @@ def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bia
                                rec_index[0] if rec_index else None, rec_index[1] if rec_index else None)
 
 
+def elbo_backward_acc_rows(plan: BatchPlan, st: FwdState, row_ids, acc, sums):
+    """vfm_elbo_bwd_acc_rows_f32: this shard's gradient statistics of the listed rows (sorted int32 ids), written
+    COMPACTLY: record i of `acc` belongs to row_ids[i] (zeros for listed rows this shard does not contain)."""
+    t = plan.index_tensors()
+    ix = _lib.Index()
+    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
+    if len(t) == 5:
+        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
+        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+    spec = plan.spec
+    p = _problem(spec, plan.B, plan.B, 64)
+    check(_lib.load().vfm_elbo_bwd_acc_rows_f32(C.byref(p), C.byref(ix), ptr(row_ids), row_ids.numel(), ptr(st.sumz),
+                                                ptr(st.grow), ptr(st.partials), ptr(acc), ptr(sums),
+                                                current_stream_ptr(acc.device)), "vfm_elbo_bwd_acc_rows_f32")
+
+
 def elbo_apply_adam_rows(plan: BatchPlan, st: FwdState, acc, sums, row_ids, entity_params, bias_params, scalars, inv_occ,
-                         m_views, v_views, lr, step, move_scalars: bool, beta1=0.9, beta2=0.999, eps_adam=1e-8):
+                         m_views, v_views, lr, step, move_scalars: bool, compact: bool = False, beta1=0.9, beta2=0.999,
+                         eps_adam=1e-8):
     """vfm_elbo_apply_adam_rows_f32: the apply stage over a sorted int32 list of rows (the multi-rank step's lazy exact
-    Adam: the rows some rank's shard contains; scaled moments).  move_scalars: this launch also updates the three scalars."""
+    Adam: the rows some rank's shard contains; scaled moments).  move_scalars: this launch also updates the three scalars;
+    compact: `acc` is the compact buffer (record i <-> row_ids[i]) instead of the dense table."""
     p0, spec = st.problem, plan.spec
     p = _problem(spec, 0, p0.B_global, 64, p0.seed, p0.step, (p0.flags & ~FLAG_NO_PRIOR_TERMS) | FLAG_SCALED_MOMENTS)
     p.e_lo, p.e_hi = 0, (0 if move_scalars else 1)
     check(_lib.load().vfm_elbo_apply_adam_rows_f32(
-        C.byref(p), ptr(acc), ptr(sums), ptr(row_ids), row_ids.numel(), ptr(entity_params), ptr(bias_params), ptr(scalars),
+        C.byref(p), ptr(acc), ptr(sums), ptr(row_ids), row_ids.numel(), int(bool(compact)), ptr(entity_params), ptr(bias_params),
+        ptr(scalars),
         ptr(inv_occ), ptr(plan.W), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]), ptr(m_views[2]),
         ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), current_stream_ptr(entity_params.device)),
         "vfm_elbo_apply_adam_rows_f32")
