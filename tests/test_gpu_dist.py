@@ -467,6 +467,8 @@ def test_lazy_statistics_step_is_bitwise_the_dense_one(F, d, monkeypatch):
     from vae_amd.data import synthetic_triples
     from vae_amd.dist import shard_rows
     import copy
+    import vae_amd.model as M
+    monkeypatch.setattr(M, "_CHECK_WREC", True)       # (every step also checks the packed first-order records)
     sizes, world, B, nb, n_steps = [900, 700, 400][:F], 3, 96, 5, 140
     X, y = synthetic_triples(sizes, nb * B, seed=4, device="cuda")
     results = []

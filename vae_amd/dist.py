@@ -63,7 +63,7 @@ def global_touched(plan, group, T: int) -> torch.Tensor:
     return g
 
 
-def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambda name: None):
+def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambda name: None, wrec=None):
     """One multi-rank training step of `model` on its row shard `plan`, exchanging the gradient's sufficient statistics
     (per rank the reference's loop body, vfm-torch.py:351-370; across ranks one all-reduce of a flat fp32 buffer
     [records (sum grow, count, 0, 0 | A_e) | row sums | loss], in `model.exchange_chunks` entity ranges: the
@@ -110,15 +110,15 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
         if not model._lazy_dirty:
             model._lazy_last.fill_(t - 1)
         if k < ops.MOMENT_PERIOD:
-            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, gids32, model._lazy_lrs(k - 1), upto=t - 1, mark=t)
+            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, gids32, model._lazy_lrs(k - 1), upto=t - 1, mark=t, wrec=wrec)
             model._lazy_dirty, model._lazy_kind, listed = True, "list", True
         else:       # the dense kernel rewrites every row's moments at a period end: every row up to date first
-            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, None, model._lazy_lrs(k - 1), upto=t - 1, mark=t)
+            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, None, model._lazy_lrs(k - 1), upto=t - 1, mark=t, wrec=wrec)
             model._lazy_dirty = False
         mark("catchup")
     st = ops.elbo_forward(plan, ent, bia, scal, model.inv_occ, eps=eps, seed=model.rng_seed, step=step, train=True,
                           flags=prior_terms_flag(dist.get_rank(group)), out_pred=out_pred if out_pred is not None else pred,
-                          out_sumz=sumz, out_grow=grow, out_partials=model._partials)
+                          out_sumz=sumz, out_grow=grow, out_partials=model._partials, wrec=wrec)
     mark("fwd")
     xacc, xs, xl, bounds = model._xviews()
     works = []
@@ -173,7 +173,7 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
         works[c].wait()
         if listed:
             ops.elbo_apply_adam_rows(plan, st, cbuf[sb[c] * rl:], xs, gids32[sb[c]: sb[c + 1]], ent, bia, scal, model.inv_occ,
-                                     mv, vv, lr, t, move_scalars=c == nch - 1, compact=True)
+                                     mv, vv, lr, t, move_scalars=c == nch - 1, compact=True, wrec=wrec)
             continue
         if gids is not None:
             if sb[c + 1] > sb[c]:
@@ -182,6 +182,7 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
                 model._xflat[n: n + 8].copy_(tail)
         ops.elbo_apply_adam(plan, st, xacc, xs, ent, bia, scal, model.inv_occ, mv, vv, lr, t,
                             e_lo=bounds[c], e_hi=bounds[c + 1], scaled_moments=model._moments_scaled)
+        model._wrec_ok = False          # (the dense apply stage does not refresh the packed records: rebuilt by the next step)
     mark("exchange_apply_adam")
     loss3.copy_(xl)
     return loss3, st.pred

@@ -632,13 +632,14 @@ class VFM(nn.Module):
         if fused is None:
             fused = self.fuse_adam
         fused = fused and adam and process_group is None
-        # the packed first-order records: kept coherent by the fused single-rank step alone (every other step form drops them)
-        wrec = self._wrec_for_step(fused and eps is None and self.n_samples == 1 and not self.sparse_adam)
+        # the packed first-order records: kept coherent by the fused single-rank step and the multi-rank statistics step
+        # (every other step form drops them)
+        wrec = self._wrec_for_step((fused or stats_step) and eps is None and self.n_samples == 1 and not self.sparse_adam)
         if fused:
             return self._step_fused(plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec)
         if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             from .dist import step_stats
-            return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark)
+            return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark, wrec)
         if self._lazy_dirty:
             self.sync_lazy()
         return self._step_unfused(plan, lr, step, eps, out_pred, adam, mark, process_group)

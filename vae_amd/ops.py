@@ -632,12 +632,12 @@ def elbo_backward_acc_rows(plan: BatchPlan, st: FwdState, row_ids, acc, sums):
 
 def elbo_apply_adam_rows(plan: BatchPlan, st: FwdState, acc, sums, row_ids, entity_params, bias_params, scalars, inv_occ,
                          m_views, v_views, lr, step, move_scalars: bool, compact: bool = False, beta1=0.9, beta2=0.999,
-                         eps_adam=1e-8):
+                         eps_adam=1e-8, wrec=None):
     """vfm_elbo_apply_adam_rows_f32: the apply stage over a sorted int32 list of rows (the multi-rank step's lazy exact
     Adam: the rows some rank's shard contains; scaled moments).  move_scalars: this launch also updates the three scalars;
     compact: `acc` is the compact buffer (record i <-> row_ids[i]) instead of the dense table."""
     p0, spec = st.problem, plan.spec
-    p = _problem(spec, 0, p0.B_global, 64, p0.seed, p0.step, (p0.flags & ~FLAG_NO_PRIOR_TERMS) | FLAG_SCALED_MOMENTS)
+    p = _problem(spec, 0, p0.B_global, 64, p0.seed, p0.step, (p0.flags & ~FLAG_NO_PRIOR_TERMS) | FLAG_SCALED_MOMENTS, wrec=wrec)
     p.e_lo, p.e_hi = 0, (0 if move_scalars else 1)
     check(_lib.load().vfm_elbo_apply_adam_rows_f32(
         C.byref(p), ptr(acc), ptr(sums), ptr(row_ids), row_ids.numel(), int(bool(compact)), ptr(entity_params), ptr(bias_params),
