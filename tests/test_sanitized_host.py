@@ -61,6 +61,17 @@ for name, n in (("vfm_elbo_fwd_f32", 15), ("vfm_elbo_bwd_f32", 17), ("vfm_elbo_f
                 ("vfm_elbo_bwd_acc_f32", 7), ("vfm_elbo_lik_f32", 7), ("vfm_philox_eps_f32", 4)):
     assert getattr(lib, name)(C.byref(p), *([None] * n)) != 0, name
     assert len(lib.vfm_last_error()) > 0
+q = _lib.Problem()
+q.B, q.B_global, q.T, q.F, q.d, q.id_bits, q.n_samples, q.flags = 8, 8, 100, 2, 16, 64, 1, 32
+q.group_hi[0], q.group_hi[1], q.group_n[0], q.group_n[1] = 50, 100, 50.0, 50.0
+ix = _lib.Index()
+assert lib.vfm_elbo_bwd_acc_rows_f32(C.byref(q), C.byref(ix), None, 3, None, None, None, None, None, None) != 0
+assert lib.vfm_elbo_apply_adam_rows_f32(C.byref(q), None, None, None, 0, 1, *([None] * 11), 0.1, 0.9, 0.999, 1e-8, 1, None) != 0
+one = 0x1000
+ids = (C.c_int32 * 4)(1, 2, 3, 4)
+assert lib.vfm_elbo_apply_adam_rows_f32(C.byref(q), one, one, ids, 101, 1, *([one] * 11), 0.1, 0.9, 0.999, 1e-8, 1, None) == -1   # n_rows > T
+assert lib.vfm_elbo_apply_adam_rows_f32(C.byref(q), one, one, ids, 4, 1, *([one] * 11), 0.1, 0.9, 0.999, 1e-8, 128, None) == -1  # period end
+assert b"moment period" in lib.vfm_last_error()
 print("host exercise ok")
 """
 
