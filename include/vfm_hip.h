@@ -150,7 +150,7 @@ typedef struct vfm_dev_step {         /* DEVICE memory, caller-owned, 64 bytes, 
   int64_t error;
 } vfm_dev_step_t;
 /* HOST helper: the constants of Adam step `step` (1-based) as every fused entry point forms them from its host
- * arguments.  scaled != 0: for VFM_FLAG_SCALED_MOMENTS.  Returns 0, or VFM_E_* (beta^k underflow). */
+ * arguments (torch.optim.Adam's bias corrections and step size for the defaults of vfm-torch.py:339, lr of :92).  scaled != 0: for VFM_FLAG_SCALED_MOMENTS.  Returns 0, or VFM_E_* (beta^k underflow). */
 int vfm_step_consts(float lr, float beta1, float beta2, float eps_adam, int64_t step, int32_t scaled,
                     vfm_step_consts_t* out);
 /* Sets (philox_step, adam_step) of a device step state (one tiny launch; stream-ordered). */
@@ -204,6 +204,8 @@ typedef struct vfm_problem {
                                  the caller rebuilds (or passes NULL).  bias_params stays the parameter (state_dict layout
                                  of vfm-torch.py:152 unchanged).                                                          */
 } vfm_problem_t;
+/* wrec[e] = (bias_params[e][0], bias_params[e][1], inv_occ[e], 0): what the forward's gathers of vfm-torch.py:207
+ * (`self.bias_params(uniq_entities)`) and the `nb_occ[uniq]` divisors of :298-306 read per entity, in one 16-byte record. */
 int vfm_wrec_build_f32(const float* bias_params, const float* inv_occ, int64_t T, float* wrec, void* stream);
 
 /* Inverted index of one batch (entity -> batch rows), built once per batch by the caller:
@@ -370,7 +372,9 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
                             float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
                             const int32_t* rec_pos, void* stream);
-/* The apply stage over a LIST of rows -- the multi-rank step's lazy exact dense Adam.  With the statistics exchange
+/* The apply stage over a LIST of rows -- the multi-rank step's lazy exact dense Adam (replaces, per rank of a
+ * data-parallel run, `optimizer.step()` of vfm-torch.py:370 on the gradients of :368-369 summed over ranks; the
+ * reference itself is single-process).  With the statistics exchange
  * compacted to the entities some rank's shard contains (the caller knows that set: it is what it all-reduced), every
  * other row of the table has a zero gradient on EVERY rank this step, so -- as in the single-rank lazy forms -- its
  * update can wait: the caller (1) replays what the listed rows skipped with vfm_adam_catchup_f32 (mark = this step)

@@ -142,3 +142,43 @@ def test_dimension_sharded_scatter_gather_roundtrip(tmp_path):
     # the moments travel the same way (unchanged here)
     m0 = np.load(tmp_path / "dims_m_0.npy")
     assert np.array_equal(m0[: T * 2 * d], np.arange(T * 2 * d, dtype=np.float32))
+
+
+class _FakePlan:
+    """What vae_amd.dist.global_touched needs of a plan: the sorted ids of the entities its shard contains."""
+
+    def __init__(self, ids):
+        self._ids = ids
+
+    def touched_ids(self):
+        return self._ids
+
+
+def _gids_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import global_touched
+    T = 1000
+    g = np.random.default_rng(100 + rank)
+    # shards of different lengths (rank 2's is empty): the id lists are padded to the longest before the all-gather
+    n = [37, 120, 0][rank]
+    ids = torch.tensor(np.sort(g.choice(T, n, replace=False)).astype(np.int32))
+    plan = _FakePlan(ids)
+    got = global_touched(plan, dist.group.WORLD, T)
+    again = global_touched(plan, dist.group.WORLD, T)          # cached on the plan: no second collective
+    assert again is got
+    np.save(os.path.join(out_dir, f"gids_{rank}.npy"), got.numpy())
+    np.save(os.path.join(out_dir, f"mine_{rank}.npy"), ids.numpy())
+    dist.destroy_process_group()
+
+
+def test_global_touched_set_is_the_sorted_union_on_every_rank(tmp_path):
+    """The set the compacted statistics exchange is built on (vae_amd/dist.py::global_touched): every rank ends up with
+    the same sorted union of the ranks' touched ids -- ragged list lengths, an empty shard -- over gloo, world size 3."""
+    world = 3
+    mp.spawn(_gids_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.unique(np.concatenate([np.load(tmp_path / f"mine_{r}.npy") for r in range(world)])).astype(np.int64)
+    for r in range(world):
+        got = np.load(tmp_path / f"gids_{r}.npy")
+        assert got.dtype == np.int64 and np.array_equal(got, want), r
