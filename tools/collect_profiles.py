@@ -52,7 +52,10 @@ traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_su
                       "included in the count)")
 sys.path.insert(0, ROOT)
 from vae_amd.build import sources_digest        # noqa: E402  (hash of csrc/: bench.py drops the figures when the kernels changed)
-traffic["_csrc_sha1"] = sources_digest()
+stamp = os.path.join(src, "csrc_sha1.txt")      # written on the GPU box by tools/profile_round.sh: the sources the passes ran on
+traffic["_csrc_sha1"] = open(stamp).read().strip() if os.path.exists(stamp) else sources_digest()
+if traffic["_csrc_sha1"] != sources_digest():
+    print("WARNING: the profiled sources are not the current ones (bench.py will not attach these figures)")
 json.dump(traffic, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
 if len(sys.argv) > 2:
     shutil.copy(sys.argv[2], os.path.join(dst, f"{tag}_bench.json"))
