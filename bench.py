@@ -122,6 +122,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # VFM_BENCH_FORCE_GROUP=1 at N = 1: run the MULTI-RANK path (process group, candidates, regimes) over a communicator
+    # of world size 1 -- on a one-GPU box the only way to take bench.py's N > 1 code through RCCL itself (which refuses
+    # two ranks on one device).  A rehearsal of the code path, labelled as such; not a measurement of anything.
+    forced = world == 1 and os.environ.get("VFM_BENCH_FORCE_GROUP") == "1"
+    multi = world > 1 or forced
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
 
@@ -144,8 +149,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     pg = None
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         doing[0] = "init_process_group"
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -155,7 +161,7 @@ def main():
 
     # what the collective library itself reports: N ranks, and a 1-element all-reduce that must give N
     comm_check = None
-    if world > 1:
+    if multi:
         doing[0] = "comm_check all_reduce"
         one = torch.ones(1, device=dev)
         dist.all_reduce(one, group=pg)
@@ -189,12 +195,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier(group=pg)
             torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        if world > 1:
+        if multi:
             t = torch.tensor([v], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
             v = float(t.item())
@@ -213,7 +219,7 @@ def main():
             # expected counts of nb_train uniform triples, at least the counts seen in the generated rows (keeps
             # 1/occ finite for every touched id)
             occ = torch.bincount(self.X.reshape(-1).to(torch.int64), minlength=model.T)
-            if world > 1:
+            if multi:
                 dist.all_reduce(occ, group=pg)
             scale = max(1.0, nb_train / float(nbt * B * world))
             self.occ = torch.clamp((occ.to(torch.float64) * scale).round().to(torch.int64), min=1)
@@ -245,12 +251,12 @@ def main():
             (vfm_build_index: radix sort) and its one readback.  The reference pays torch.unique x3 inside every
             step (vfm-torch.py:190-192); here a plan is built once per batch and reused every epoch (the loader
             does not shuffle, :121-122), so its cost is reported separately and amortised over the 50 epochs."""
-            key = mode if world > 1 else "single"
+            key = mode if multi else "single"
             if key in self.plans:
                 return self.plans[key]
             B = self.B
             ps, batches = [], []
-            dims = world > 1 and mode == "dims"
+            dims = multi and mode == "dims"
             Bp = B * world if dims else B
             Xs, ys = self.global_rows() if dims else (self.X, self.y)
             for i in range(nbt):
@@ -265,14 +271,14 @@ def main():
             t0 = time.perf_counter()
             for xb, yb in batches:         # as fit() does: the index builds are enqueued back to back, their 16-byte
                 ps.append(model.plan(xb, yb, B_global=B * world, process_group=pg, defer_readback=True))     # readbacks
-            if world == 1 and model.lookahead and model.lookahead_list:
+            if not multi and model.lookahead and model.lookahead_list:
                 for i_, p_ in enumerate(ps):   # the look-ahead step's row lists (this batch + the next one), also per batch
                     p_.prepare_lookahead(ps[(i_ + 1) % len(ps)])
             for p_ in ps:                  # are collected afterwards
                 p_.U
             torch.cuda.synchronize()
             self.plan_build[key] = (time.perf_counter() - t0) / nbt * 1e3
-            if world == 1:       # the same once more (discarded): the allocator now has the buffers -- what a loop that
+            if not multi:       # the same once more (discarded): the allocator now has the buffers -- what a loop that
                 t0 = time.perf_counter()                 # rebuilds its plans every epoch (shuffled batches) pays per batch
                 again = [model.plan(xb, yb, B_global=B * world, process_group=pg, defer_readback=True) for xb, yb in batches]
                 for p_ in again:
@@ -300,7 +306,7 @@ def main():
                     e.record()
                     ev[name] = e
             model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables,
-                             next_plan=plans[(s + 1) % nbt] if world == 1 else None)
+                             next_plan=plans[(s + 1) % nbt] if not multi else None)
             if args.sync_each_step:
                 torch.cuda.synchronize()
         model.replay = False
@@ -333,14 +339,14 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         xbytes = None
-        if world > 1:      # what ONE step's exchange carried (the last step's; bytes per rank into the all-reduce)
+        if multi:      # what ONE step's exchange carried (the last step's; bytes per rank into the all-reduce)
             xbytes = {"stats": 4 * int(model._exchanged_floats), "grads": 4 * int(model._gflat.numel())}.get(mode)
         return {"dt": dt, "t_host": t_host, "events": events, "lazy_kind": lazy_kind, "plans": plans,
                 "U": sum(uniq) / len(uniq), "B": setup.B, "steps": steps, "mode": mode, "exchange_bytes": xbytes}
 
     # ------------------------------------------------------------------ what to run
     exchange_note = None
-    if world == 1:
+    if not multi:
         regimes = [("strong", B_global)]
         cands = ["single"]
     else:
@@ -359,7 +365,7 @@ def main():
 
     def reset_state():
         model.sync_lazy()
-        if world > 1 and getattr(model, "_stale_group", None) is not None:
+        if multi and getattr(model, "_stale_group", None) is not None:
             model.sync_params(pg)
         model._flat.copy_(init)
         model._adam_m.zero_(); model._adam_v.zero_()
@@ -377,8 +383,8 @@ def main():
         for mode in use:
             reset_state()
             try:
-                m = measure(setup, mode, args.steps, args.warmup, with_events=not args.no_events and not (world == 1 and args.replay == "on"),
-                            replay=world == 1 and args.replay == "on", probe=world > 1)
+                m = measure(setup, mode, args.steps, args.warmup, with_events=not args.no_events and not (not multi and args.replay == "on"),
+                            replay=not multi and args.replay == "on", probe=multi)
             except Exception as exc:      # communication-pattern fallback only (never a compute fallback)
                 if len(use) == 1:
                     raise
@@ -391,18 +397,18 @@ def main():
             raise SystemExit("[bench] no exchange pattern ran: " + str({k: v.get("skipped") for k, v in results[reg].items()}))
         if head is None:
             head = min(ok.values(), key=lambda v: v["dt"])
-    model.exchange = head["mode"] if world > 1 else model.exchange
+    model.exchange = head["mode"] if multi else model.exchange
     setup, B, U, dt, plans = head["setup"], head["B"], head["U"], head["dt"], head["plans"]
     events, lazy_kind, t_host = head["events"], head["lazy_kind"], head["t_host"]
     loss = float(model._gflat[model._n_flat].item())
-    if world > 1 and model.exchange in ("sharded", "dims"):
+    if multi and model.exchange in ("sharded", "dims"):
         model.sync_params(pg)
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- N = 1: figures over a long region next to the commanded one: `sustained` = the same eager steps without
     # events, `replayed` = the same steps as replayed HIP graphs (what VFM.fit runs)
     sustained = replayed = None
-    if world == 1 and args.sustained_steps > 0:
+    if not multi and args.sustained_steps > 0:
         setup.activate()
         for name, rp in (("sustained", False), ("replayed", True)):
             m = measure(setup, "single", args.sustained_steps, nbt + 4 if rp else 4, with_events=False, replay=rp)
@@ -414,13 +420,13 @@ def main():
                 replayed["graphs"] = sum(1 for v in model._graphs.values() if v is not None)
             else:
                 sustained = rec
-    if world == 1 and events is None and not args.no_events:
+    if not multi and events is None and not args.no_events:
         # (--replay on: nothing can be recorded inside a replayed step) per-kernel durations from an eager pass
         m = measure(setup, "single", min(100, args.steps), 4, with_events=True)
         events, lazy_kind = m["events"], m["lazy_kind"]
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
-    kern, roof = kernel_report(events, model, args, world, B, d, F, U, lazy_kind)
+    kern, roof = kernel_report(events, model, args, world if not forced else 2, B, d, F, U, lazy_kind)
     copy_gbs = stream_copy_rate(dev)
     if roof is not None:
         roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
@@ -430,7 +436,7 @@ def main():
     # full step.  The timed step fuses the backward with Adam, so K comes from a short run of the UNFUSED step
     # (separate k_bwd writing the dense gradient, then k_adam) after the timed region.
     regions = None
-    if world == 1 and kern and not args.unfused and not args.no_regions:
+    if not multi and kern and not args.unfused and not args.no_regions:
         ev2 = []
         for s_ in range(5):
             model.train_step(plans[s_ % nbt], fused=False, eps=eps_tables)
@@ -471,12 +477,12 @@ def main():
 
     # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu = cpu_baseline(sizes, d, B, nb_train, output, plans[0], setup.occ, args.cpu_seconds)
 
     if rank == 0:
         def line_of(m, reg):
-            return {"scaling": reg, "exchange": m["mode"] if world > 1 else None, "batch_per_gpu": m["B"],
+            return {"scaling": reg, "exchange": m["mode"] if multi else None, "batch_per_gpu": m["B"],
                     "global_batch": m["B"] * world, "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 4),
                     "value": round(m["steps"] * m["B"] * world / m["dt"], 1),
                     "host_enqueue_ms_per_step": round(m["t_host"] / m["steps"] * 1e3, 4),
@@ -485,13 +491,13 @@ def main():
         cand_lines = {reg: {k: (line_of(v, reg) if "dt" in v else {"skipped": v["skipped"]}) for k, v in rs.items()}
                       for reg, rs in results.items()}
         value = args.steps * B * world / dt
-        piped = bool(model._zrec is not None and world == 1)
+        piped = bool(model._zrec is not None and not multi)
         out = {
             "metric": "rating-triples/sec (ELBO step) at d=%d" % d,
             "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": head_reg if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": head_reg if multi else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "fields": F, "entities": model.T, "d": d,
                        "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
@@ -501,38 +507,38 @@ def main():
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "adam_moments": "scaled form (untouched rows do not write m, v)" if (
-                           model.scaled_moments and world == 1 and not args.unfused) else "plain",
+                           model.scaled_moments and not multi and not args.unfused) else "plain",
                        "lazy_exact_adam": {"list": "rows of the batch only + replay pass", "la": "look-ahead (this batch + next batch)",
                                            None: False}[lazy_kind],
-                       "pipelined_step": piped, "packed_first_order_records": bool(model.use_wrec and world == 1 and not args.unfused),
-                       "timed_steps_replayed_as_graphs": bool(world == 1 and args.replay == "on"),
-                       "exchange": model.exchange if world > 1 else None, "exchange_note": exchange_note,
+                       "pipelined_step": piped, "packed_first_order_records": bool(model.use_wrec and not multi and not args.unfused),
+                       "timed_steps_replayed_as_graphs": bool(not multi and args.replay == "on"),
+                       "exchange": model.exchange if multi else None, "exchange_note": exchange_note,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
                                  "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
                                  "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
                                  "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
                                          "on d/N coordinates"}[model.exchange]
-                                if world > 1 else "fwd+loss+bwd+dense-adam") if
-                               (world > 1 or args.unfused) else ("fwd(records)+loss+fused(bwd+dense-adam+next batch's sampling)" if
+                                if multi else "fwd+loss+bwd+dense-adam") if
+                               (multi or args.unfused) else ("fwd(records)+loss+fused(bwd+dense-adam+next batch's sampling)" if
                                                                  piped else "fwd+loss+fused(bwd+dense-adam)"),
                        "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
-                                       f"{d // world} of {d} coordinates)") if (world > 1 and model.exchange == "dims")
-                       else (f"entity-sharded tables x{world} + row-sharded batch" if (world > 1 and model.exchange == "sharded")
+                                       f"{d // world} of {d} coordinates)") if (multi and model.exchange == "dims")
+                       else (f"entity-sharded tables x{world} + row-sharded batch" if (multi and model.exchange == "sharded")
                              else f"row-sharded dp{world}: {B} of {B * world} rows per rank, tables replicated, one all-reduce per step")},
             "roofline": roof, "kernels": kern, "kernel_events_on_every_nth_step": max(1, args.event_every), "regions": regions,
             "sustained": sustained, "replayed": replayed,
-            "candidates": cand_lines if world > 1 else None,
+            "candidates": cand_lines if multi else None,
             "weak": (lambda w: line_of(min(w, key=lambda v: v["dt"]), "weak") if w else None)(
-                [v for v in results.get("weak", {}).values() if "dt" in v]) if world > 1 and head_reg != "weak" else None,
+                [v for v in results.get("weak", {}).values() if "dt" in v]) if multi and head_reg != "weak" else None,
             "plan_build_ms_per_batch": {k: round(v, 4) for k, v in setup.plan_build.items()},
             "plan_build_rebuilt_ms_per_batch": {k: round(v, 4) for k, v in setup.plan_build_warm.items()},
             "plan_build_amortised_us_per_step_at_50_epochs": {k: round(v * 1e3 / 50, 3) for k, v in setup.plan_build.items()},
-            "comm_check": comm_check,
+            "comm_check": comm_check, "forced_single_rank_group": forced or None,
             "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
         }
         print(json.dumps(out))
     doing[0] = "destroy_process_group"
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
