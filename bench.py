@@ -113,6 +113,7 @@ def main():
     args = ap.parse_args()
     if args.strong:
         args.scaling = "strong"
+    args.event_every = max(1, min(args.event_every, args.steps // 10))      # (at least ten sampled steps in a short region)
 
     import threading
     import torch
