@@ -103,6 +103,10 @@ def main():
                          "the per-kernel durations then come from an eager pass right after the timed region.  Whatever this "
                          "says, the line carries `sustained` (eager) and `replayed` (graphs) figures over >= 2000 steps.")
     ap.add_argument("--sustained-steps", type=int, default=2000)
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed training steps before the warm-up of a commanded region (0: none); the same region "
+                         "without them is timed first and reported as settle.cold_ms_per_step")
+    ap.add_argument("--settle-max-s", type=float, default=1.0, help="wall-clock bound of the settling steps")
     ap.add_argument("--no-wrec", action="store_true", help="A/B: without the packed first-order records")
     ap.add_argument("--no-regions", action="store_true", help="skip the short unfused run that measures region K")
     ap.add_argument("--lazy-adam", default="auto", choices=["auto", "on", "off"],
@@ -113,7 +117,7 @@ def main():
     args = ap.parse_args()
     if args.strong:
         args.scaling = "strong"
-    args.event_every = max(1, min(args.event_every, args.steps // 10))      # (at least ten sampled steps in a short region)
+    args.event_every = max(1, min(args.event_every, args.steps // 5))       # (at least five sampled steps in a short region)
 
     import threading
     import torch
@@ -127,6 +131,11 @@ def main():
     # of world size 1 -- on a one-GPU box the only way to take bench.py's N > 1 code through RCCL itself (which refuses
     # two ranks on one device).  A rehearsal of the code path, labelled as such; not a measurement of anything.
     forced = world == 1 and os.environ.get("VFM_BENCH_FORCE_GROUP") == "1"
+    # stdout carries ONE line, the JSON: whatever libraries print there (RCCL's version banner at communicator creation
+    # goes to fd 1 in this image) is sent to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     multi = world > 1 or forced
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -277,6 +286,10 @@ def main():
                     p_.prepare_lookahead(ps[(i_ + 1) % len(ps)])
             for p_ in ps:                  # are collected afterwards
                 p_.U
+            if not multi and model.lookahead and model.lookahead_list:
+                for i_, p_ in enumerate(ps):   # (the row lists' deferred counts too: no readback is left for the timed region)
+                    if model._lookahead_pays(p_, ps[(i_ + 1) % len(ps)]):
+                        p_.lookahead_rows(ps[(i_ + 1) % len(ps)])
             torch.cuda.synchronize()
             self.plan_build[key] = (time.perf_counter() - t0) / nbt * 1e3
             if not multi:       # the same once more (discarded): the allocator now has the buffers -- what a loop that
@@ -312,7 +325,7 @@ def main():
                 torch.cuda.synchronize()
         model.replay = False
 
-    def measure(setup, mode, steps, warmup, with_events, replay=False, probe=False):
+    def measure(setup, mode, steps, warmup, with_events, replay=False, probe=False, settle=0):
         """warm-up, then `steps` timed steps bracketed by barrier + synchronize on both sides, MAX over ranks.  With
         `probe`, three steps are timed first and the candidate is dropped if it projects past --mode-budget-s."""
         doing[0] = f"measure {mode} B={setup.B}"
@@ -329,6 +342,28 @@ def main():
                 return {"skipped": f"probe: {per * 1e3:.2f} ms per step projects past --mode-budget-s {args.mode_budget_s}"}
         if replay:
             warmup = max(warmup, 2 * nbt + 2)      # every (batch, next batch) pair seen twice: first eagerly, then captured
+        cold = None
+        if settle > 0:
+            # The chip needs 10-50 ms of THIS work after an idle stretch before the backward kernel reaches its steady
+            # duration (tools/transient_probe.py: 163 -> 151 us over the first 60-260 steps, again after 0.3 s of
+            # idleness, not after a reload of the same values without one).  A commanded region of 20 steps is 4 ms,
+            # so it is preceded by untimed settling steps -- real training steps, like the warm-up's -- and the same
+            # region WITHOUT them is timed first and reported beside the headline as `settle.cold_ms_per_step`.
+            kc = min(steps, 20)
+            run(plans, warmup, None, replay)
+            barrier()
+            t0 = time.perf_counter()
+            run(plans, kc, None, replay)
+            barrier()
+            cold = {"steps": kc, "ms_per_step": max_over_ranks(time.perf_counter() - t0) / kc * 1e3}
+            done, t0 = 0, time.perf_counter()
+            while done < settle:
+                run(plans, 50, None, replay)
+                done += 50
+                torch.cuda.synchronize()
+                if max_over_ranks(time.perf_counter() - t0) >= args.settle_max_s:     # (every rank takes the same decision)
+                    break
+            cold["settle_steps"] = done
         run(plans, warmup, None, replay)
         barrier()
         events = [] if with_events else None
@@ -342,7 +377,7 @@ def main():
         xbytes = None
         if multi:      # what ONE step's exchange carried (the last step's; bytes per rank into the all-reduce)
             xbytes = {"stats": 4 * int(model._exchanged_floats), "grads": 4 * int(model._gflat.numel())}.get(mode)
-        return {"dt": dt, "t_host": t_host, "events": events, "lazy_kind": lazy_kind, "plans": plans,
+        return {"dt": dt, "t_host": t_host, "events": events, "lazy_kind": lazy_kind, "plans": plans, "cold": cold,
                 "U": sum(uniq) / len(uniq), "B": setup.B, "steps": steps, "mode": mode, "exchange_bytes": xbytes}
 
     # ------------------------------------------------------------------ what to run
@@ -374,6 +409,9 @@ def main():
         model._dims = model._stale_kind = None
         model.params_changed()
 
+    # the box's streaming rate (device-to-device copies of 1 GiB) -- measured before the timed regions, it touches
+    # nothing of the model
+    copy_gbs = stream_copy_rate(dev)
     results = {}          # regime -> {mode: measurement}
     head = None           # the headline measurement: first regime, fastest north-star candidate
     for reg, B in regimes:
@@ -385,7 +423,7 @@ def main():
             reset_state()
             try:
                 m = measure(setup, mode, args.steps, args.warmup, with_events=not args.no_events and not (not multi and args.replay == "on"),
-                            replay=not multi and args.replay == "on", probe=multi)
+                            replay=not multi and args.replay == "on", probe=multi, settle=args.settle_steps)
             except Exception as exc:      # communication-pattern fallback only (never a compute fallback)
                 if len(use) == 1:
                     raise
@@ -428,7 +466,6 @@ def main():
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
     kern, roof = kernel_report(events, model, args, world if not forced else 2, B, d, F, U, lazy_kind)
-    copy_gbs = stream_copy_rate(dev)
     if roof is not None:
         roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
         roof["frac_of_box_stream_copy"] = round(roof["achieved"] / copy_gbs, 4)
@@ -528,6 +565,11 @@ def main():
                              else f"row-sharded dp{world}: {B} of {B * world} rows per rank, tables replicated, one all-reduce per step")},
             "roofline": roof, "kernels": kern, "kernel_events_on_every_nth_step": max(1, args.event_every), "regions": regions,
             "sustained": sustained, "replayed": replayed,
+            "settle": None if not head.get("cold") else {
+                "untimed_steps_before_warmup": head["cold"]["settle_steps"],
+                "cold_ms_per_step": round(head["cold"]["ms_per_step"], 4), "cold_steps": head["cold"]["steps"],
+                "note": "the same warm-up + region timed first, WITHOUT the settling steps (the chip reaches the steady "
+                        "duration of the backward kernel 10-50 ms of this work after an idle stretch: tools/transient_probe.py)"},
             "candidates": cand_lines if multi else None,
             "weak": (lambda w: line_of(min(w, key=lambda v: v["dt"]), "weak") if w else None)(
                 [v for v in results.get("weak", {}).values() if "dt" in v]) if multi and head_reg != "weak" else None,
@@ -537,7 +579,7 @@ def main():
             "comm_check": comm_check, "forced_single_rank_group": forced or None,
             "cpu_baseline": cpu, "final_loss": loss, "nan_params": nan_params,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     doing[0] = "destroy_process_group"
     if multi:
         dist.destroy_process_group()
@@ -663,6 +705,8 @@ def stream_copy_rate(dev):
     dst = torch.empty_like(src)
     dst.copy_(src)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        dst.copy_(src)
     e0.record()
     for _ in range(10):
         dst.copy_(src)
