@@ -396,24 +396,28 @@ def test_end_to_end_learning_matches_cpu_reference_port():
     hist = m.fit(Xtr, ytr, n_epochs=epochs, batch_size=B, X_test=Xte, y_test=yte, display_every=epochs - 1,
                  verbose=False)
     gpu_rmse = hist["test"][-1]["rmse_of_last"]        # deterministic prediction from the final posterior means
-    # CPU port, same init, same loop
-    torch.manual_seed(42)
-    P = O.make_params(N + M, d)
-    with torch.no_grad():
-        P["alpha"].copy_(m.alpha.detach().cpu() * 0 + P["alpha"])   # own init is fine; same distribution
+    # CPU port, same init distribution, same loop -- for THREE sampler seeds, compared through their median: at this
+    # learning rate (1 / (1 + 20000 // 5000) = 0.2) a single 160-step trajectory of the reference's own algorithm is
+    # chaotic enough that one seed on one host CPU now and then ends far from the others (seen once in a dozen suite
+    # runs on the GPU pool: 1.21 where the same code had read 0.62-0.68 on other hosts)
     nb_occ = torch.bincount(Xtr.flatten(), minlength=N + M)
-    opt = torch.optim.Adam(list(P.values()), lr=1 / (1 + len(ytr) // B))
-    torch.manual_seed(7)
-    for ep in range(epochs):
-        for lo in range(0, len(ytr), B):
-            O.reference_shaped_step(P, opt, Xtr[lo:lo + B], ytr[lo:lo + B], nb_occ, N, M, len(ytr), "reg")
-    with torch.no_grad():
-        mu_w, mu_v = P["bias_params"][:, 0], P["entity_params"][:, :d]
-        pred = (P["global_bias_mean"] + mu_w[Xte].sum(1) + mu_v[Xte].prod(1).sum(1)).clamp(1, 5)
-        cpu_rmse = float(torch.sqrt(torch.mean((pred - yte) ** 2)))
+    cpu = []
+    for sampler_seed in (7, 8, 9):
+        torch.manual_seed(42)
+        P = O.make_params(N + M, d)
+        opt = torch.optim.Adam(list(P.values()), lr=1 / (1 + len(ytr) // B))
+        torch.manual_seed(sampler_seed)
+        for ep in range(epochs):
+            for lo in range(0, len(ytr), B):
+                O.reference_shaped_step(P, opt, Xtr[lo:lo + B], ytr[lo:lo + B], nb_occ, N, M, len(ytr), "reg")
+        with torch.no_grad():
+            mu_w, mu_v = P["bias_params"][:, 0], P["entity_params"][:, :d]
+            pred = (P["global_bias_mean"] + mu_w[Xte].sum(1) + mu_v[Xte].prod(1).sum(1)).clamp(1, 5)
+            cpu.append(float(torch.sqrt(torch.mean((pred - yte) ** 2))))
+    cpu_rmse = sorted(cpu)[1]
     base = float(torch.sqrt(torch.mean((ytr.mean() - yte) ** 2)))
-    assert gpu_rmse < 0.8 * base and cpu_rmse < 0.8 * base
-    assert abs(gpu_rmse - cpu_rmse) < 0.2 * cpu_rmse
+    assert gpu_rmse < 0.8 * base and cpu_rmse < 0.8 * base, (gpu_rmse, cpu, base)
+    assert abs(gpu_rmse - cpu_rmse) < 0.2 * cpu_rmse, (gpu_rmse, cpu)
 
 
 def test_philox_stream_statistics():
