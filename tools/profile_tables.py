@@ -25,6 +25,8 @@ def bench_table(tag):
     r, k = j["roofline"], j["kernels"]
     rows = ["| figure | value |", "|---|---|",
             f"| `value` (commanded region: {j['steps']} steps, events on every {j.get('kernel_events_on_every_nth_step', 1)}th) | **{j['value'] / 1e6:.1f} M triples/s**, {j['ms_per_step']} ms/step |"]
+    if j.get("settle"):
+        rows.append(f"| `settle` ({j['settle']['untimed_steps_before_warmup']} untimed steps before the warm-up; the same warm-up + {j['settle']['cold_steps']} steps timed first, without them) | cold: {j['settle']['cold_ms_per_step']} ms/step |")
     if j.get("sustained"):
         rows.append(f"| `sustained` ({j['sustained']['steps']} eager steps, no events) | {j['sustained']['triples_per_s'] / 1e6:.1f} M triples/s, {j['sustained']['ms_per_step']} ms/step |")
     if j.get("replayed"):
