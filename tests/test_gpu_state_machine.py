@@ -42,8 +42,14 @@ def _same_state(a, b, exact, where):
             continue                               # (the two hold the moments in different forms right now)
         if exact:
             assert torch.equal(ta, tb), (where, name)
-        else:
-            assert float((ta - tb).abs().max()) <= 1e-4 * float(tb.abs().max()) + 1e-30, (where, name)
+            continue
+        # per table: 1e-4 of its largest entry.  The three scalars apart: the gradient of alpha is a sum over ALL rows of
+        # terms that cancel ((y - pred)^2 / 2 - 1 / (2|alpha|), SURVEY A-6), so a 1e-7 difference in the predictions is a
+        # 1e-3 difference in its FIRST moment for a step or two (24 more seeds x 200 steps: up to 1.7e-3 there, while the
+        # parameters stayed within 6e-6 and the second moments within 3e-5); it owns the largest entry of the flat buffer
+        for part, (pa, pb) in enumerate(zip(a._views(ta), b._views(tb))):
+            tol = 1e-2 if (part == 2 and name == "_adam_m") else 1e-4
+            assert float((pa - pb).abs().max()) <= tol * float(pb.abs().max()) + 1e-30, (where, name, part)
     assert a._adam_t == b._adam_t and a.global_step == b.global_step, where
 
 
@@ -122,7 +128,7 @@ def test_random_step_form_sequences_are_bitwise_the_dense_trajectory(cfg, seed, 
     assert {"dense", "la_list", "lazy_list", "unfused"} <= forms         # the walk did visit the forms
 
 
-@pytest.mark.parametrize("seed", [4, 5])
+@pytest.mark.parametrize("seed", [4, 5, 100, 102])          # (100, 102: the alpha first moment leaves 1e-4 there, see _same_state)
 def test_random_sequences_with_the_pipelined_step(seed, monkeypatch):
     trace = _walk("F2_d32", seed, with_pipeline=True, monkeypatch=monkeypatch)
     assert "pipe" in {t[2] for t in trace}
