@@ -61,10 +61,11 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
-    ap.add_argument("--exchange", default="north-star", choices=["north-star", "stats", "grads", "sharded", "dims", "auto"],
+    ap.add_argument("--exchange", default="north-star", choices=["north-star", "stats", "grads", "rows", "sharded", "dims", "auto"],
                     help="N>1, what the ranks exchange per step (DESIGN.md section 6).  north-star (default): the row-sharded "
-                         "batch with ONE all-reduce per step, in both of its forms -- `stats` (sufficient statistics of the "
-                         "gradient) and `grads` (the literal gradient) -- each timed, the faster one is the headline.  auto: "
+                         "batch with ONE all-reduce per step, in its three forms -- `stats` (sufficient statistics of the "
+                         "gradient), `grads` (the literal gradient) and `rows` (every row's dloss/dpred; two fields) -- each "
+                         "timed, the fastest one is the headline.  auto: "
                          "also the opt-in sharded / dims modes (never the default: different parallelism).")
     ap.add_argument("--scaling", default="both", choices=["both", "strong", "weak"],
                     help="N>1: strong = the workload's global batch split by rows over the ranks (SURVEY cfg4; the headline), "
@@ -376,7 +377,8 @@ def main():
         dt = max_over_ranks(time.perf_counter() - t0)
         xbytes = None
         if multi:      # what ONE step's exchange carried (the last step's; bytes per rank into the all-reduce)
-            xbytes = {"stats": 4 * int(model._exchanged_floats), "grads": 4 * int(model._gflat.numel())}.get(mode)
+            xbytes = {"stats": 4 * int(model._exchanged_floats), "grads": 4 * int(model._gflat.numel()),
+                      "rows": 4 * int(model._exchanged_floats)}.get(mode)
         return {"dt": dt, "t_host": t_host, "events": events, "lazy_kind": lazy_kind, "plans": plans, "cold": cold,
                 "U": sum(uniq) / len(uniq), "B": setup.B, "steps": steps, "mode": mode, "exchange_bytes": xbytes}
 
@@ -390,6 +392,9 @@ def main():
                    for r in (("strong", "weak") if args.scaling == "both" else (args.scaling,))]
         if args.exchange in ("north-star", "auto"):
             cands = ["stats", "grads"]
+            from vae_amd.dist import rows_supported
+            if rows_supported(model.spec()):
+                cands.append("rows")
             if args.exchange == "auto":       # opt-in: other parallelism than the north star's (never the default)
                 from vae_amd.dims import supported as dims_supported
                 table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
@@ -465,6 +470,7 @@ def main():
         events, lazy_kind = m["events"], m["lazy_kind"]
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region + the roofline object
+    args._plans = plans
     kern, roof = kernel_report(events, model, args, world if not forced else 2, B, d, F, U, lazy_kind)
     if roof is not None:
         roof["box_stream_copy_GBs"] = round(copy_gbs, 1)
@@ -553,6 +559,8 @@ def main():
                        "exchange": model.exchange if multi else None, "exchange_note": exchange_note,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
                                  "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
+                                 "rows": "sample(records of all the batch's entities)+fwd(own rows)+allreduce(row gradients: B_global+8 doubles)"
+                                         "+fused(loss+bwd+dense-adam) over the whole batch on every rank",
                                  "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
                                  "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
                                          "on d/N coordinates"}[model.exchange]
@@ -604,6 +612,9 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
             d_k, B_k, n_params = d // world, B * world, model._dims.n_flat
         else:
             d_k, B_k = d, B
+        rows_mode = world > 1 and model.exchange == "rows"
+        if rows_mode:         # per rank: own rows in the forward, ALL rows (and their entities: U_all) in the sampling pass and the backward
+            U_all = sum(p_.__dict__["_gplan"][1].U for p_ in getattr(args, "_plans", []) if "_gplan" in p_.__dict__) / max(1, len(getattr(args, "_plans", []))) or U
         bytes_fwd = U * (8 * d_k + 16) + B_k * (idb * F + 8)        # touched rows once + ids, y, pred
         bytes_bwd = bytes_fwd + U * (8 * d_k + 8)                   # re-read + one write per touched row
         look = lazy_kind == "la"  # look-ahead lazy exact Adam: rows in neither this nor the next batch are skipped
@@ -636,6 +647,13 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                "sample_a2a": U * (8 * d + 8) + 2 * 4.0 * U * (d + 4), "acc_a2a": B * F * (4 * d + 8) + 2 * 4.0 * U * (d + 4),
                "apply_adam": 24.0 * n_params / max(world, 1) + 4.0 * U * (d + 4)}
         alg["allreduce"] = 4.0 * n_params
+        if rows_mode:
+            Bg = args._plans[0].B_global
+            alg["fwd"] = U * (4 * d + 16) + B * (idb * F + 12)                      # the own rows' records once + ids, y, pred, grow
+            alg["sample_rec"] = U_all * (8 * d + 16) + U_all * (4 * d + 16)
+            alg["exchange"] = 8.0 * (Bg + 8)
+            alg["bwd_adam"] = (Bg * (idb * F + 8) + U_all * 16 + 24.0 * n_params
+                               - (8.0 * (model.T - U_all) * (2 * d + 2) if model.scaled_moments else 0.0) + U_all * (4 * d + 16))
         forced = os.environ.get("VFM_FWD_KERNEL", "0")        # (use_fwd2 in csrc/vfm_abi.hip: k_fwd2 from d = 20 on)
         fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and not dims_mode and \
             forced != "1" and (d >= 20 or forced == "2")
@@ -650,6 +668,7 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                  "sample_rec": "k_sample_rec (sample records of a batch from the tables: first step of a pipelined run)",
                  "catchup": "k_adam_catchup (lazy exact dense Adam: replay of the skipped zero-gradient updates on the batch's rows)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
+                 "exchange": "RCCL all-reduce of every row's dloss/dpred + the six ELBO sums (B_global + 8 doubles), with its packing",
                  "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",
                  "lik": "k_lik (likelihood terms + dloss/dpred of all rows)",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
@@ -658,6 +677,10 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                  "sample_a2a": "k_sample (owners) + all-to-all of (w | z) records",
                  "acc_a2a": "k_bwd<ACC> over slots + all-to-all of statistics records",
                  "apply_adam": "k_records_add + k_bwd<APPLY,ADAM> on owned rows + scalar all-reduce"}
+        if rows_mode:
+            names["fwd"] = "k_fwd2<ZREC> (the rank's own rows: gather of the sample records -> FM -> ELBO)"
+            names["sample_rec"] = "k_sample_rec (records of ALL entities of the global batch, from this rank's replica of the tables)"
+            names["bwd_adam"] = "k_bwd<ADAM, records> (loss + gradients + dense Adam over the WHOLE batch, on every rank)"
         for k, ms in acc.items():
             us = ms / len(events) * 1e3
             gbs = alg[k] / (us * 1e-6) / 1e9 if us > 0 else 0.0

@@ -182,3 +182,27 @@ def test_global_touched_set_is_the_sorted_union_on_every_rank(tmp_path):
     for r in range(world):
         got = np.load(tmp_path / f"gids_{r}.npy")
         assert got.dtype == np.int64 and np.array_equal(got, want), r
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_amd.dist import gather_shards, shard_rows
+    B, F = 7, 2                                      # 7 rows over 4 ranks: blocks of 2, 2, 2, 1 ... and over 8: some empty
+    g = np.random.default_rng(5)
+    X = torch.tensor(g.integers(0, 50, (B, F)))
+    Y = torch.tensor(g.random(B).astype(np.float32))
+    a, b = shard_rows(0, B, rank, world)
+    Xg, Yg, off = gather_shards(X[a:b], Y[a:b], dist.group.WORLD)
+    assert off == a and torch.equal(Xg, X) and torch.equal(Yg, Y), (rank, off, a)
+    open(os.path.join(out_dir, f"ok_{rank}"), "w").write("1")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_shards_rebuilds_the_batch_on_every_rank(world, tmp_path):
+    """What the rows exchange (vae_amd/dist.py::step_rows) is built on: the ranks' contiguous row blocks -- ragged, the
+    last ones possibly short -- all-gathered into the whole batch, in row order, on every rank (gloo)."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(world))

@@ -228,7 +228,7 @@ def _cfg4_single(n_steps):
     return ref._flat.cpu().numpy(), ref_l
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "stats"), (2, "grads"), (4, "stats"), (4, "grads")])
+@pytest.mark.parametrize("world,exchange", [(2, "stats"), (2, "grads"), (4, "stats"), (4, "grads"), (2, "rows"), (4, "rows")])
 def test_cfg4_batch_over_gloo_ranks_equals_1_rank(world, exchange, tmp_path):
     """B = 100,000 at T = 165,237, d = 128 split over 2 / 4 processes (gloo, sharing the GPU): the real transport path."""
     n_steps = 2
@@ -241,7 +241,7 @@ def test_cfg4_batch_over_gloo_ranks_equals_1_rank(world, exchange, tmp_path):
     assert rel_err(np.load(tmp_path / "l_0.npy"), want_l) < 1e-5
 
 
-@pytest.mark.parametrize("exchange", ["stats", "grads"])
+@pytest.mark.parametrize("exchange", ["stats", "grads", "rows"])
 def test_cfg4_batch_over_8_ranks_equals_1_rank(exchange, monkeypatch):
     """... and over 8 ranks of 12,500 rows (in-process ranks: a GPU box allows 6 processes on the card)."""
     from thread_ranks import run_ranks
@@ -273,10 +273,12 @@ def test_cfg4_batch_over_8_ranks_equals_1_rank(exchange, monkeypatch):
     T, d = sum(cfg["sizes"]), cfg["d"]
     Ug = int(torch.unique(X).numel())
     assert 0.55 * T < Ug < 0.62 * T
-    once = 16 + (8 if exchange == "stats" else 0)            # the 2 fp64 normalisers (+ the longest id list's length)
+    # "rows": every row's dloss/dpred and the six ELBO sums as doubles -- 0.8 MB where the statistics are 50 MB -- once the
+    # ranks have gathered each other's ids (per plan: the shard sizes, 8 bytes per rank, then an all-gather of ids + targets)
+    once = 16 + {"stats": 8, "grads": 0, "rows": 8 * world}[exchange]      # the 2 fp64 normalisers (+ the longest id list's length / the shard sizes)
     per_step = (sh.bytes_allreduce - once) / n_steps
-    assert per_step == {"stats": 4.0 * (Ug * (d + 4) + 8), "grads": 4.0 * (T * (2 * d + 2) + 8 + 2)}[exchange]
-    assert models[0]._exchanged_floats == (Ug * (d + 4) + 8 if exchange == "stats" else 0)
+    assert per_step == {"stats": 4.0 * (Ug * (d + 4) + 8), "grads": 4.0 * (T * (2 * d + 2) + 8 + 2), "rows": 8.0 * (cfg["B"] + 8)}[exchange]
+    assert models[0]._exchanged_floats == {"stats": Ug * (d + 4) + 8, "grads": 0, "rows": 2 * (cfg["B"] + 8)}[exchange]
 
 
 def test_cfg4_compact_statistics_exchange_equals_the_dense_one(monkeypatch):

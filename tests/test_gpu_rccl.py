@@ -64,7 +64,7 @@ def _worker(rank, world, port, exchange, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["stats", "grads"])
+@pytest.mark.parametrize("exchange", ["stats", "grads", "rows"])
 def test_step_through_rccl_world_size_one(exchange, tmp_path):
     mp.spawn(_worker, args=(1, _free_port(), exchange, str(tmp_path)), nprocs=1, join=True)
     X, y = _data()
@@ -77,3 +77,5 @@ def test_step_through_rccl_world_size_one(exchange, tmp_path):
     lagged, xfloats = np.load(tmp_path / "meta.npy")
     if exchange == "stats":          # 1,500 rows over 3,900 entities: the compact + lazy form ran through RCCL
         assert lagged == 1 and 0 < xfloats < 0.8 * 3900 * 36
+    if exchange == "rows":           # every row's dloss/dpred + the six sums, as doubles (all_gather of the ids + a float64 all-reduce through RCCL)
+        assert lagged == 0 and xfloats == 2 * (1500 + 8)

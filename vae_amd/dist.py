@@ -6,6 +6,10 @@ normalisers W_f once per batch, ONE all-reduce per step, rank 0 alone adding the
           (sum of grow_r, occurrences, A_e = sum grow_r * sumz_r) -- half the bytes of the gradient, cut in entity
           ranges so that the all-reduce of one range overlaps the kernels of its neighbours;
   "grads" (`VFM._step_unfused` with a process group)  the literal pattern: all-reduce of [gradients | loss], flat Adam.
+  "rows"  (`step_rows` below)  the all-reduce carries the per-ROW gradient dloss/dpred_r of the whole batch and the six
+          ELBO sums -- B_global + 8 doubles (0.8 MB at cfg4 where the statistics are 50 MB): the tables are replicated and
+          eps is keyed on the entity id, so every rank can form every entity's sample itself and needs from the others
+          only what their rows contributed to the likelihood.  Two fields, one sample.
 
 `backend="nccl"` is RCCL on ROCm; the CPU tests use gloo; tests/thread_ranks.py runs any number of in-process ranks."""
 from __future__ import annotations
@@ -186,3 +190,115 @@ def step_stats(model, plan, lr, step, group, eps=None, out_pred=None, mark=lambd
     mark("exchange_apply_adam")
     loss3.copy_(xl)
     return loss3, st.pred
+
+
+def gather_shards(x: torch.Tensor, y: torch.Tensor, group):
+    """All ranks' row shards ([B_r, F] ids and [B_r] targets; B_r may differ and may be 0) concatenated in rank order on
+    every rank.  Returns (X [sum B_r, F], Y [sum B_r], offset of this rank's rows)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = x.device
+    n = torch.zeros(world, dtype=torch.int64, device=dev)
+    n[rank] = x.shape[0]
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    counts = [int(v) for v in n.tolist()]
+    nmax = max(max(counts), 1)
+    xp = torch.zeros(nmax, x.shape[1], dtype=x.dtype, device=dev)
+    yp = torch.zeros(nmax, dtype=torch.float32, device=dev)
+    xp[: x.shape[0]] = x
+    yp[: x.shape[0]] = y
+    xs = [torch.empty_like(xp) for _ in range(world)]
+    ys = [torch.empty_like(yp) for _ in range(world)]
+    dist.all_gather(xs, xp, group=group)
+    dist.all_gather(ys, yp, group=group)
+    X = torch.cat([t[:c] for t, c in zip(xs, counts)]).contiguous()
+    Y = torch.cat([t[:c] for t, c in zip(ys, counts)]).contiguous()
+    return X, Y, sum(counts[:rank])
+
+
+def global_plan(plan, group, model):
+    """The plan of the WHOLE batch, on every rank: the ranks' row shards (contiguous blocks in rank order, `shard_rows`)
+    all-gathered once per plan -- ids and targets, 20 bytes per row -- and indexed locally.  Returns (plan of all rows,
+    offset of this rank's rows in it).  Collective: every rank calls it at the same point (the first rows-exchange step of
+    the plan does); plans are parameter-free and reused every epoch (vfm-torch.py:121-122: no shuffling)."""
+    hit = plan.__dict__.get("_gplan")
+    if hit is not None and hit[0] is group:
+        return hit[1], hit[2]
+    from . import ops
+    X, Y, off = gather_shards(plan.x, plan.y, group)
+    if X.shape[0] != plan.B_global:
+        raise RuntimeError(f"the ranks' shards hold {X.shape[0]} rows, the plan says B_global = {plan.B_global}")
+    gp = ops.BatchPlan(plan.spec, X, Y, model.inv_occ, B_global=plan.B_global)       # (no group: W from all rows, locally)
+    plan.__dict__["_gplan"] = (group, gp, off)
+    return gp, off
+
+
+def rows_supported(spec) -> bool:
+    """The rows exchange runs the two-field record kernels (csrc/vfm_fwd2.hpp EPS_ZREC, k_bwd<PIPE>)."""
+    from . import ops
+    return ops.pipeline_supported(spec)
+
+
+def step_rows(model, plan, lr, step, group, mark=lambda name: None):
+    """One multi-rank training step of `model` on its row shard `plan`, exchanging per-ROW gradients (per rank the
+    reference's loop body, vfm-torch.py:351-370; across ranks ONE all-reduce of B_global + 8 doubles):
+      1. every rank samples the records (w_e, KL share, z_e) of ALL entities of the global batch from its replica of the
+         tables -- eps is keyed on (entity, step), so the replicas draw the same samples (vfm_sample_records_f32);
+      2. forward of the rank's OWN rows as a gather of those records: pred_r, g_r = dloss/dpred_r, the ELBO sums of its rows;
+      3. all-reduce of [g of all rows (zeros outside the own block) | the six sums]: afterwards every rank holds every row's g;
+      4. loss + backward + dense Adam over the WHOLE batch from the records and the gathered g, on every rank
+         (vfm_elbo_bwd_adam_pipe_f32 without next-batch records): the replicas apply the same update to the same values.
+    Against the statistics exchange: 0.8 MB instead of 50 MB per step at cfg4 -- the all-reduce stops being the step --
+    for one sampling pass over the batch's entities and a backward that walks all B_global rows instead of B_global / N."""
+    from . import ops
+    ent, bia, scal = model._views(model._flat)
+    loss3 = model._gflat[model._n_flat: model._n_flat + 3]
+    gp, off = global_plan(plan, group, model)
+    Bg, B = gp.B, plan.B
+    scaled = model.scaled_moments
+    model._set_moment_form(scaled)
+    model._adam_t += 1
+    if model._zrec is None:
+        rl = ops.record_len(model.d)
+        model._zrec = [torch.zeros(model.T, rl, dtype=torch.float32, device=model.device) for _ in range(2)]
+    cur = model._zrec[0]
+    bufs = model.__dict__.setdefault("_rows_bufs", {})
+    hit = bufs.get(Bg)
+    if hit is None:
+        dev = model.device
+        hit = bufs[Bg] = (torch.zeros(Bg + 8, dtype=torch.float64, device=dev),            # the exchanged buffer
+                          torch.zeros(Bg, dtype=torch.float32, device=dev),                # g of all rows
+                          torch.zeros(_PARTIALS_LEN(), dtype=torch.float64, device=dev),   # the global sums as ONE slot
+                          torch.zeros(max(Bg, 1), dtype=torch.float32, device=dev))        # (placeholder predictions of the global pass)
+        hit[2][7] = 1.0                                    # (one "workgroup slot": the global sums)
+        if len(bufs) > 8:
+            bufs.pop(next(iter(bufs)))
+    xbuf, g_all, pg, _ = hit
+    ops.sample_records(gp, ent, bia, model.inv_occ, cur, model.rng_seed, step)
+    mark("sample_rec")
+    _, grow, pred = model._step_buffers(B)
+    if B > 0:
+        st = ops.elbo_forward_records(plan, cur, scal, model.rng_seed, step, pred, grow, model._partials)
+        ops.elbo_finalize(st, scal, out=model.__dict__.setdefault("_rows_loss", torch.zeros(3, dtype=torch.float32, device=model.device)))
+    mark("fwd")
+    xbuf.zero_()
+    if B > 0:
+        xbuf[off: off + B] = grow[:B]
+        xbuf[Bg: Bg + 6] = model._partials[:6]
+    dist.all_reduce(xbuf, op=dist.ReduceOp.SUM, group=group)
+    model._exchanged_floats = 2 * int(xbuf.numel())          # (doubles, counted in 4-byte units like the other forms)
+    g_all.copy_(xbuf[:Bg])
+    pg[8:14] = xbuf[Bg: Bg + 6]
+    mark("exchange")
+    p = ops._problem(gp.spec, Bg, Bg, gp.id_bits, model.rng_seed, step, 0)
+    stg = ops.FwdState(pred, pg, None, g_all, p, None)
+    ops.elbo_backward_adam_pipe(gp, stg, cur, None, None, step + 1, ent, bia, scal, model.inv_occ,
+                                model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t, loss3,
+                                scaled_moments=scaled)
+    mark("bwd_adam")
+    model._zrec_for = None
+    return loss3, pred[:B]
+
+
+def _PARTIALS_LEN():
+    from . import _lib
+    return _lib.PARTIALS_LEN

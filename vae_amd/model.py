@@ -155,7 +155,9 @@ class VFM(nn.Module):
         self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
         self._la_ready_for = None          # (plan, adam step): rows of that plan are current through that step
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
-        # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats)
+        # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats),
+        # "rows" = every row's dloss/dpred and the six ELBO sums (B_global + 8 doubles; two fields, one sample): each rank
+        # samples all the batch's entities from its replica and runs the whole batch's backward itself (dist.step_rows);
         # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
         # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
         # "dims" = the embedding dimension cut over the ranks (vae_amd/dims.py): every rank sees all rows, holds
@@ -640,6 +642,11 @@ class VFM(nn.Module):
         if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             from .dist import step_stats
             return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark, wrec)
+        if process_group is not None and adam and self.exchange == "rows":
+            from .dist import step_rows, rows_supported
+            if not rows_supported(plan.spec) or eps is not None or out_pred is not None or self.sparse_adam:
+                raise ValueError('exchange = "rows": two fields, one sample, d % 4 == 0, d <= 512, Philox eps, dense Adam')
+            return step_rows(self, plan, lr, step, process_group, mark)
         if self._lazy_dirty:
             self.sync_lazy()
         return self._step_unfused(plan, lr, step, eps, out_pred, adam, mark, process_group)
