@@ -91,3 +91,67 @@ def test_random_multi_rank_statistics_runs_are_bitwise_the_every_row_run(seed, m
             assert torch.equal(got[i], dense[i]), (seed, cfg[:7], lazy, compact, name)
         assert any(n < full for _, n in got[4]) and any(n == full for _, n in got[4])      # compact AND dense exchanges ran
         assert any(lag for lag, _ in got[4]) == lazy                                       # rows lagged iff the lazy form is on
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_switching_between_the_exchange_forms_mid_training(seed, monkeypatch):
+    """The three north-star exchange forms ("stats" with its compact / lazy state, "grads", "rows") taken in a random
+    order step by step by the same replicas -- every switch has to leave the tables, the moments, the lagging-row
+    bookkeeping, the packed first-order records and the sample records in a state the next form can start from.  The
+    forms sum in different orders, so the comparison with ONE rank's plain step is to 1e-4 per table (2e-4 on the
+    losses); the replicas themselves must stay BIT-identical."""
+    from thread_ranks import run_ranks
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    from vae_amd.dist import shard_rows
+    import vae_amd.model as M
+    monkeypatch.setattr(M, "_CHECK_WREC", True)
+    g = np.random.default_rng(seed)
+    world = int(g.choice([2, 3, 5]))
+    sizes, d, B, nb, n_steps = [int(g.integers(100, 900)), int(g.integers(60, 500))], 16, int(g.choice([48, 200])), 4, 70
+    modes = [str(g.choice(["stats", "grads", "rows"])) for _ in range(n_steps)]
+    lrs = [float(g.choice([0.02, 0.01])) for _ in range(n_steps)]
+    X, y = synthetic_triples(sizes, nb * B, seed=4, device="cuda")
+    torch.manual_seed(3)
+    first = VFM(field_sizes=sizes, embedding_size=d, device="cuda", rng_seed=11)
+    single = copy.deepcopy(first); single._tie(); single.__dict__.pop("_view_cache", None)
+    models = [first] + [copy.deepcopy(first) for _ in range(world - 1)]
+    for m in models[1:]:
+        m._tie(); m.__dict__.pop("_view_cache", None)
+
+    def rank_body(rank, group):
+        m = models[rank]
+        m.set_training_data(X, nb_train=nb * B)
+        plans = []
+        for i in range(nb):
+            a, b = shard_rows(i * B, (i + 1) * B, rank, world)
+            plans.append(m.plan(X[a:b], y[a:b], B_global=B, process_group=group))
+        losses = []
+        for s in range(n_steps):
+            m.exchange = modes[s]
+            losses.append(m.train_step(plans[s % nb], lr=lrs[s], process_group=group)[0].clone())
+            if s % 23 == 7:
+                losses.append(m.predict(X[:30])["y_pred"].sum().reshape(1).repeat(3))
+        m.sync_lazy()
+        return m._flat, m._adam_m, m._adam_v, torch.stack(losses)
+
+    out, _ = run_ranks(world, rank_body, monkeypatch)
+    for r in range(1, world):
+        assert all(torch.equal(out[r][i], out[0][i]) for i in range(4)), ("replicas differ", r)
+    single.set_training_data(X, nb_train=nb * B)
+    plans = [single.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
+    want = []
+    for s in range(n_steps):
+        want.append(single.train_step(plans[s % nb], lr=lrs[s], fused=False)[0].clone())
+        if s % 23 == 7:
+            want.append(single.predict(X[:30])["y_pred"].sum().reshape(1).repeat(3))
+    want = torch.stack(want)
+    errs = {"losses": float(((out[0][3] - want).abs() / want.abs()).max())}
+    for name, got in zip(("_flat", "_adam_m", "_adam_v"), out[0][:3]):
+        if name != "_flat" and models[0]._moments_scaled != single._moments_scaled:
+            continue
+        for part, (pa, pb) in enumerate(zip(models[0]._views(got), single._views(getattr(single, name)))):
+            errs[(name, part)] = float((pa - pb).abs().max()) / (float(pb.abs().max()) + 1e-30)
+    for key, e in errs.items():
+        tol = 2e-4 if key == "losses" else (1e-2 if key == ("_adam_m", 2) else 1e-4)
+        assert e <= tol, (modes[:12], errs)
