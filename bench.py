@@ -79,6 +79,9 @@ def main():
                          "prints what it was doing and exits with code 3")
     ap.add_argument("--dim", type=int, default=0, help="embedding size instead of the workload's (shape sweeps)")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
+    ap.add_argument("--user-order", action="store_true",
+                    help="generated rows sorted by user id before they are cut into batches -- the order of the reference's data "
+                         "files (a batch then holds the consecutive ratings of a few hundred users instead of 100,000 random pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
@@ -225,6 +228,9 @@ def main():
             self.B = B
             self.X, self.y = synthetic_triples(sizes, nbt * B, seed=1000 + rank, output=output, device=dev,
                                                zipf=args.zipf if args.zipf > 0 else None)
+            if args.user_order:      # the data files' order (ML-20M's ratings.csv is sorted by user): a batch = few users' runs
+                o_ = torch.argsort(self.X[:, 0], stable=True)
+                self.X, self.y = self.X[o_].contiguous(), self.y[o_].contiguous()
             if args.id32:
                 self.X = self.X.to(torch.int32)
             # expected counts of nb_train uniform triples, at least the counts seen in the generated rows (keeps
@@ -547,7 +553,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "nb_train": nb_train,
                        "ids": "int32" if args.id32 else "int64",
                        "eps": "philox-in-kernel" if eps_tables is None else "tables (fixed draw, A/B)",
-                       "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
+                       "row_source_order": "sorted by user (the data files' order)" if args.user_order else "as generated", "id_distribution": ("zipf(%.2f) items" % args.zipf) if args.zipf > 0 else "uniform",
                        "likelihood": output, "unique_entities_per_batch": round(U, 1),
                        "row_order": "as-generated" if args.no_sort else "sorted by last id column inside each batch",
                        "adam_moments": "scaled form (untouched rows do not write m, v)" if (

@@ -107,3 +107,28 @@ def test_fit_with_pipeline_matches_fit_without():
     assert rel_err(np.array(h1["elbo"]), np.array(h2["elbo"])) < 1e-4
     assert rel_err(m1._flat.cpu().numpy(), m2._flat.cpu().numpy()) < 1e-3
     assert rel_err(np.array(h1["train_rmse"]), np.array(h2["train_rmse"])) < 1e-4
+
+
+def test_auto_takes_the_pipelined_step_only_where_a_batch_covers_the_table():
+    """`pipeline = "auto"`: many rows per entity is not enough -- the record backward visits ALL table rows, the look-ahead
+    form only this batch's and the next one's, so a batch that touches a small part of the table (rows in the data
+    files' order: the consecutive ratings of a few users) takes the look-ahead form (measured at the ML-20M shape: 0.173 vs
+    0.219 ms per step), one that covers it (many rows drawn over the whole table) the pipelined one."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    sizes, d, B = [10000, 500], 32, 30000
+    X, y = synthetic_triples(sizes, 4 * B, seed=3, device="cuda")
+    Xs = X[torch.argsort(X[:, 0], stable=True)].contiguous()          # sorted by user: a batch = 2,500 users' runs (29 % of the table)
+    for rows, want_pipe in ((Xs, False), (X, True)):
+        torch.manual_seed(1)
+        m = VFM(field_sizes=sizes, embedding_size=d, device="cuda", rng_seed=8)
+        m.set_training_data(rows, nb_train=4 * B)
+        plans = [m.plan(rows[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(4)]
+        touch = plans[0].U / m.T
+        assert plans[0].B >= 2 * plans[0].U                            # many rows per entity either way
+        assert (touch >= m.pipeline_min_touch) == want_pipe, touch
+        assert m._will_pipeline(plans[0], plans[1]) == want_pipe
+        for s in range(6):
+            m.train_step(plans[s % 4], lr=0.01, next_plan=plans[(s + 1) % 4])
+        assert (m._zrec is not None) == want_pipe
+        assert (m._lazy_kind == "la") == (not want_pipe)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the measurement points SURVEY 8(d) asks for besides the default bench line, one
 # JSON line each, into gpurun_out/points_$1.jsonl  (copy the file to profiles/ to have it judged).
-#   cfg2 (ML-100K shape) | cfg3 at B = 1,048,576 rows | cfg3 with Zipf(1.1) item popularity | cfg5 shape on one GPU
+#   cfg2 (ML-100K shape) | cfg3 at B = 1,048,576 rows | cfg3 with Zipf(1.1) item popularity | the same with the rows in the
+#   data files' order (sorted by user: a batch = ~900 users' consecutive ratings, 8 % of the table) | cfg5 shape on one GPU
 #   (lazy exact Adam: auto) and the same with the dense step | the software-pipelined step on / off where "auto"
 #   decides either way | cfg3 forward A/B: k_fwd (every occurrence sampled), k_fwd2 with table eps, k_fwd2 with the
 #   RNG compiled out, rows not sorted | cfg3 without the look-ahead lazy Adam form (every row every step)
@@ -29,6 +30,8 @@ run cfg3_B1048576_plain_step "" --batch 1048576 --n-batches 4 --steps 60 --warmu
 run cfg3_B100000_pipelined_step "" --pipeline on --steps 200 --warmup 20 --no-regions --sustained-steps 0
 run cfg2_ml100k_d20_pipelined_step "" --workload ml100k_d20 --steps 300 --warmup 30 --pipeline on --sustained-steps 0
 run cfg3_zipf1.1 "" --zipf 1.1 --steps 200 --warmup 20 --sustained-steps 0
+run cfg3_data_file_order_auto "" --user-order --zipf 1.1 --n-batches 160 --steps 320 --warmup 20 --no-regions --sustained-steps 1600
+run cfg3_data_file_order_pipelined_step "" --user-order --zipf 1.1 --n-batches 160 --steps 320 --warmup 20 --no-regions --pipeline on --sustained-steps 0
 run cfg5_criteo_d256_auto "" --workload criteo_d256 --steps 200 --warmup 20 $COMMON
 run cfg5_criteo_d256_row_list_form "" --workload criteo_d256 --lazy-adam on --steps 200 --warmup 20 --sustained-steps 0
 run cfg3_B5000_auto "" --batch 5000 --steps 300 --warmup 20 --no-regions $COMMON
