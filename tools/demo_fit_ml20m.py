@@ -18,9 +18,22 @@ u = torch.randint(0, N, (n,), generator=g, device=dev)
 i = torch.randint(0, M, (n,), generator=g, device=dev)
 y = (3.2 + (U[u] * V[i]).sum(1) + 0.3 * torch.randn(n, generator=g, device=dev)).clamp(1, 5)
 X = torch.stack([u, i + N], 1)
+if os.environ.get("USER_ORDER"):     # USER_ORDER=1: the TRAINING rows in the data files' order (ratings.csv is sorted by user):
+    ntr0 = int(0.8 * n)              # a batch = the consecutive ratings of ~700 users; item popularity Zipf(1.1)
+    w = 1.0 / torch.arange(1, M + 1, dtype=torch.float64, device=dev) ** 1.1
+    i = torch.multinomial(w, n, replacement=True, generator=g)
+    y = (3.2 + (U[u] * V[i]).sum(1) + 0.3 * torch.randn(n, generator=g, device=dev)).clamp(1, 5)
+    X = torch.stack([u, i + N], 1)
+    o = torch.argsort(X[:ntr0, 0], stable=True)
+    X = torch.cat([X[:ntr0][o], X[ntr0:]]).contiguous()
+    y = torch.cat([y[:ntr0][o], y[ntr0:]]).contiguous()
 ntr = int(0.8 * n)
 torch.manual_seed(42)
 m = VFM(N, M, d, device=dev, rng_seed=1)
+for kv in os.environ.get("VFM_SET", "").split(","):        # e.g. VFM_SET=replay=False,pipeline_min_touch=0 (A/B of the step-form rules)
+    if "=" in kv:
+        key, val = kv.split("=")
+        setattr(m, key, {"True": True, "False": False}.get(val, float(val) if val.replace(".", "").isdigit() else val))
 t0 = time.perf_counter()
 hist = m.fit(X[:ntr], y[:ntr], n_epochs=int(os.environ.get("EPOCHS", "6")), batch_size=100000,
              X_test=X[ntr:], y_test=y[ntr:], display_every=1, verbose=True)
