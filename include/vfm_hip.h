@@ -440,13 +440,20 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
  *   vfm_elbo_bwd_adam_pipe_f32  = vfm_elbo_bwd_adam_f32 (plain dense step; no row flags) with sumz replaced by
  *                            pipe->zrec + idx->occ_other, and -- when pipe->zrec_next != NULL -- the records of
  *                            step pipe->next_step for every entity e with next_occ_ptr[e+1] != next_occ_ptr[e]
- *                            (the next batch's inverted-index offsets), weighted with next_W. */
+ *                            (the next batch's inverted-index offsets), weighted with next_W.
+ * Look-ahead form (pipe->last_step != NULL; VFM_FLAG_SCALED_MOMENTS; not on the last step of a moment period): as
+ * vfm_elbo_bwd_adam_lookahead_f32 -- a row in neither this batch nor the next (next_occ_ptr, required) is skipped, a
+ * visited row first replays the zero-gradient updates it skipped (step_tab: the period's per-step constants, kept by the
+ * kernel) -- with idx->touched_ids, if given, as the list of rows to visit.  The rows of the next batch are then current
+ * when their records are written, which is all the next forward reads. */
 typedef struct vfm_pipe {
   const float* zrec;
   float* zrec_next;
   const int32_t* next_occ_ptr;
   const double* next_W;
   uint64_t next_step;
+  int32_t* last_step;           /* [T] last Adam step applied to each row; NULL = every row every step */
+  float* step_tab;              /* [2 * (VFM_MOMENT_PERIOD + 1)] floats, as for vfm_elbo_bwd_adam_lookahead_f32 */
 } vfm_pipe_t;
 int vfm_sample_records_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
                            const float* bias_params, const float* inv_occ, const double* W, float* zrec, void* stream);

@@ -67,6 +67,7 @@ def test_pipelined_trajectory_equals_plain(cfg):
         if s in (0, 1, 39):
             assert rel_err(pa.cpu().numpy(), pb.cpu().numpy()) < (1e-4 if s < 5 else 2e-3), s
     assert a._zrec is not None and b._zrec is None
+    a.sync_lazy(); b.sync_lazy()          # (the pipelined step runs in its look-ahead form: rows outside the two batches lag)
     # Adam normalises every coordinate's step, so a last-bit difference in a tiny gradient grows over the steps; the
     # skewed case (long lists: summed in another order by the two forms) is the loosest
     tol = 5e-3 if cfg.get("zipf") else 2e-4
@@ -109,26 +110,58 @@ def test_fit_with_pipeline_matches_fit_without():
     assert rel_err(np.array(h1["train_rmse"]), np.array(h2["train_rmse"])) < 1e-4
 
 
-def test_auto_takes_the_pipelined_step_only_where_a_batch_covers_the_table():
-    """`pipeline = "auto"`: many rows per entity is not enough -- the record backward visits ALL table rows, the look-ahead
-    form only this batch's and the next one's, so a batch that touches a small part of the table (rows in the data
-    files' order: the consecutive ratings of a few users) takes the look-ahead form (measured at the ML-20M shape: 0.173 vs
-    0.219 ms per step), one that covers it (many rows drawn over the whole table) the pipelined one."""
+def test_auto_pipelines_a_small_part_of_the_table_only_in_the_look_ahead_form():
+    """`pipeline = "auto"`: many rows per entity is not enough for the EVERY-ROW record backward -- it visits all T table
+    rows, so a batch that touches a small part of the table (rows in the data files' order: the consecutive ratings of a
+    few users) takes it only in the look-ahead form (k_bwd<PIPE, LA>; measured at the ML-20M shape: 0.131 ms per step
+    against 0.147 plain look-ahead and 0.219 every-row pipelined); with the look-ahead forms switched off it takes the
+    plain step.  A batch that covers the table pipelines either way."""
     from vae_amd.model import VFM
     from vae_amd.data import synthetic_triples
     sizes, d, B = [10000, 500], 32, 30000
     X, y = synthetic_triples(sizes, 4 * B, seed=3, device="cuda")
     Xs = X[torch.argsort(X[:, 0], stable=True)].contiguous()          # sorted by user: a batch = 2,500 users' runs (29 % of the table)
-    for rows, want_pipe in ((Xs, False), (X, True)):
-        torch.manual_seed(1)
-        m = VFM(field_sizes=sizes, embedding_size=d, device="cuda", rng_seed=8)
-        m.set_training_data(rows, nb_train=4 * B)
-        plans = [m.plan(rows[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(4)]
-        touch = plans[0].U / m.T
-        assert plans[0].B >= 2 * plans[0].U                            # many rows per entity either way
-        assert (touch >= m.pipeline_min_touch) == want_pipe, touch
-        assert m._will_pipeline(plans[0], plans[1]) == want_pipe
-        for s in range(6):
-            m.train_step(plans[s % 4], lr=0.01, next_plan=plans[(s + 1) % 4])
-        assert (m._zrec is not None) == want_pipe
-        assert (m._lazy_kind == "la") == (not want_pipe)
+    for rows, covers in ((Xs, False), (X, True)):
+        for lookahead in (True, False):
+            torch.manual_seed(1)
+            m = VFM(field_sizes=sizes, embedding_size=d, device="cuda", rng_seed=8)
+            m.lookahead = lookahead
+            m.set_training_data(rows, nb_train=4 * B)
+            plans = [m.plan(rows[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(4)]
+            touch = plans[0].U / m.T
+            assert plans[0].B >= 2 * plans[0].U                        # many rows per entity either way
+            assert (touch >= m.pipeline_min_touch) == covers, touch
+            want_pipe = covers or lookahead
+            assert m._will_pipeline(plans[0], plans[1]) == want_pipe
+            for s in range(6):
+                m.train_step(plans[s % 4], lr=0.01, next_plan=plans[(s + 1) % 4])
+            assert (m._zrec is not None) == want_pipe
+            assert (m._lazy_kind == "la") == (lookahead and not covers), (covers, lookahead, m._lazy_kind)
+
+
+@pytest.mark.parametrize("cfg", [dict(sizes=(3000, 1200), B=300, nb=8), dict(d=128, sizes=(2000, 300), B=900, nb=5),
+                                 dict(zipf=1.3, B=2000, sizes=(4000, 600), nb=6)])
+def test_pipelined_look_ahead_form_is_bitwise_the_pipelined_dense_form(cfg):
+    """k_bwd<PIPE, LA>: the pipelined step visiting only the rows of this batch and of the next one (a skipped row replays
+    its zero-gradient updates when it is next visited, or at the period's end) against the pipelined step that updates
+    every row every step -- 300 steps across two moment-period boundaries, a prediction and an un-announced batch in
+    between: every loss, the parameters and both moments BIT FOR BIT."""
+    a, plans_a = _model(**cfg)
+    b, plans_b = _model(**cfg)
+    a.lookahead_min_skip = 0.0
+    b.pipeline_lookahead = False
+    n = len(plans_a)
+    lagged = False
+    for s in range(300):
+        i, j = s % n, ((s + 1) % n if s != 150 else (s + 3) % n)          # (step 151 meets a batch nobody announced)
+        if s == 151:
+            i = (s - 1 + 1) % n
+        la, _ = a.train_step(plans_a[i], lr=0.02 if s % 5 else 0.01, next_plan=plans_a[j])
+        lb, _ = b.train_step(plans_b[i], lr=0.02 if s % 5 else 0.01, next_plan=plans_b[j])
+        lagged = lagged or (a._lazy_dirty and a._lazy_kind == "la")
+        assert torch.equal(la, lb), s
+        if s == 77:
+            assert torch.equal(a.predict(plans_a[0].x[:50])["y_pred"], b.predict(plans_b[0].x[:50])["y_pred"])
+    assert lagged and not b._lazy_dirty
+    a.sync_lazy()
+    assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)

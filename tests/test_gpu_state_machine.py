@@ -87,12 +87,12 @@ def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None):
         elif act == "lr":
             lr = float(g.choice([0.05, 0.02, 0.08]))
         # ---- the step form of the model under test
-        form = str(g.choice(["dense", "la_list", "la_scan", "lazy_list", "lazy_auto", "unfused"] + (["pipe", "pipe"] if with_pipeline else [])))
-        tst.lookahead = form in ("la_list", "la_scan")
+        form = str(g.choice(["dense", "la_list", "la_scan", "lazy_list", "lazy_auto", "unfused"] + (["pipe", "pipe_la", "pipe_la"] if with_pipeline else [])))
+        tst.lookahead = form in ("la_list", "la_scan", "pipe_la")
         tst.lookahead_list = form != "la_scan"
         tst.lazy_adam = {"lazy_list": True, "lazy_auto": "auto"}.get(form, False)
         tst.lazy_threshold = 0.9 if form == "lazy_auto" else 0.35
-        tst.pipeline = True if form == "pipe" else False
+        tst.pipeline = True if form in ("pipe", "pipe_la") else False
         tst.replay = bool(g.random() < 0.5)
         tst.use_wrec = bool(g.random() < 0.6)
         nxt = (cur + 1) % nb
@@ -131,4 +131,4 @@ def test_random_step_form_sequences_are_bitwise_the_dense_trajectory(cfg, seed, 
 @pytest.mark.parametrize("seed", [4, 5, 100, 102])          # (100, 102: the alpha first moment leaves 1e-4 there, see _same_state)
 def test_random_sequences_with_the_pipelined_step(seed, monkeypatch):
     trace = _walk("F2_d32", seed, with_pipeline=True, monkeypatch=monkeypatch)
-    assert "pipe" in {t[2] for t in trace}
+    assert {"pipe", "pipe_la"} <= {t[2] for t in trace}

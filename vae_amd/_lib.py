@@ -91,7 +91,7 @@ class DevStep(C.Structure):
 class Pipe(C.Structure):
     """Mirror of `vfm_pipe_t`."""
     _fields_ = [("zrec", C.c_void_p), ("zrec_next", C.c_void_p), ("next_occ_ptr", C.c_void_p), ("next_W", C.c_void_p),
-                ("next_step", C.c_uint64)]
+                ("next_step", C.c_uint64), ("last_step", C.c_void_p), ("step_tab", C.c_void_p)]
 
 
 def heavy_list_for(n_occ: int, T: int) -> int:

@@ -772,6 +772,12 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
   if (!pipe || !pipe->zrec || (p->B > 0 && !idx->occ_other) ||
       (pipe->zrec_next && (!pipe->next_occ_ptr || !pipe->next_W)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: pipe / idx->occ_other incomplete");
+  if (pipe->last_step) {      // look-ahead form
+    if (!pipe->next_occ_ptr || !pipe->step_tab || !(p->flags & VFM_FLAG_SCALED_MOMENTS))
+      return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32 (look-ahead form): next_occ_ptr, step_tab and VFM_FLAG_SCALED_MOMENTS");
+    if (!p->dev_step && step % VFM_MOMENT_PERIOD == 0)
+      return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32 (look-ahead form): the last step of a moment period is a dense one");
+  }
   if (!entity_params || !bias_params || !scalars || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
       !v_scalars || step < 1 || !inv_occ || !W || !partials || (p->B > 0 && !grow))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: bad argument");
@@ -783,6 +789,14 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
   b.zrec_next = pipe->zrec_next; b.next_occ_ptr = pipe->next_occ_ptr; b.next_W = pipe->next_W;
   b.next_key = a.key;
   b.next_key.step_lo = (uint32_t)pipe->next_step; b.next_key.step_hi = (uint32_t)(pipe->next_step >> 32);
+  if (pipe->last_step) {
+    b.last_step = pipe->last_step; b.step_tab = reinterpret_cast<float2*>(pipe->step_tab);
+    b.la_step = (int32_t)step; b.la_k = (int32_t)((step - 1) % VFM_MOMENT_PERIOD + 1);
+    if (idx->touched_ids && idx->n_touched > 0) {      // the rows to visit, listed (vfm_union_rows)
+      if (idx->n_touched > p->T) return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: more listed rows than table rows");
+      b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
+    }
+  }
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
   if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;

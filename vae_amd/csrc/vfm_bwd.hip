@@ -33,7 +33,10 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
   if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX && VEC == 4) {
     if (b.zrec != nullptr) {      // software-pipelined step: gathers samples, writes the next step's records
       if (a.S > 1) return fail(VFM_E_UNSUPPORTED, "pipelined step: one variational sample");
-      hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+      if (b.last_step != nullptr)     // ... in the look-ahead form: rows in neither this batch nor the next are skipped
+        hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false, true, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
+      else
+        hipLaunchKernelGGL((k_bwd<LPE, CPL, VEC, EPS, ADAM, STAGE, LINK, false, true>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad);
       return 0;
     }
   }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     load_dev_step(a, key, ad, la_step, la_k, next_key,
                   blockIdx.x == 0 && threadIdx.x == 0 && a.row_filter != 1 && a.row_filter != 3 && a.e_hi == a.T);
   static_assert(!PIPE || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "the pipelined step is the fused single-sample one");
-  static_assert(!LA || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI && !PIPE), "look-ahead lazy Adam is a form of the fused dense step");
+  static_assert(!LA || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "look-ahead lazy Adam is a form of the fused dense step");
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ float sh_cs_next[PIPE ? VFM_MAX_FIELDS : 1];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];

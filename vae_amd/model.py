@@ -122,11 +122,14 @@ class VFM(nn.Module):
         self.pipeline_min_d = 20
         self.pipeline_min_T = 8192         # small tables: every list is cut in work items and the plain step is faster
                                            # (ML-100K shape: 0.056 vs 0.063 ms)
-        # ... and only where a batch touches a good part of the table: the record backward visits ALL T rows, the
-        # look-ahead form only this batch's and the next one's.  Rows in the data files' order (ML-20M's ratings.csv is
-        # sorted by user: 100,000 consecutive ratings are ~900 users x ~10,000 items, 8 % of the table) have B = 8 U and
-        # still run 21 % faster in the look-ahead form (0.173 vs 0.219 ms per step, `bench.py --user-order --zipf 1.1`)
+        # ... and, in its every-row form, only where a batch touches a good part of the table: that record backward visits
+        # ALL T rows.  Rows in the data files' order (ML-20M's ratings.csv is sorted by user: 100,000 consecutive ratings are
+        # ~900 users x ~10,000 items, 8 % of the table) have B = 8 U and ran 0.219 ms per step that way against 0.147-0.173 in
+        # the plain look-ahead form (`bench.py --user-order --zipf 1.1`) ...
         self.pipeline_min_touch = 0.35
+        # ... so the pipelined step has a look-ahead form of its own (k_bwd<PIPE, LA>: rows in neither this batch nor the
+        # next are skipped and replayed later, bitwise the every-row pipelined step): 0.131 ms per step on that shape.
+        self.pipeline_lookahead = True
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"            # (row-list form: used when no next batch is named; with one, the look-ahead
@@ -521,7 +524,8 @@ class VFM(nn.Module):
             return True
         return (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T
                 and next_plan.B >= self.pipeline_ratio * next_plan.U and plan.B >= self.pipeline_ratio * plan.U
-                and min(plan.U, next_plan.U) >= self.pipeline_min_touch * self.T)
+                and (min(plan.U, next_plan.U) >= self.pipeline_min_touch * self.T
+                     or (self.pipeline_lookahead and self._lookahead_pays(plan, next_plan))))
 
     def _use_lazy(self, plan) -> bool:
         if self.lazy_adam is True:
@@ -710,20 +714,28 @@ class VFM(nn.Module):
         # may this step be a replayed graph?  (no per-kernel events, no caller-owned buffers, Philox eps)
         may_replay = (self.replay is True and not marking and eps is None and out_pred is None and self.n_samples == 1
                       and not self.sparse_adam)
-        if (self.pipeline and not lazy and not self._lazy_dirty and eps is None and not self.sparse_adam
+        if k == 1:
+            self._lazy_lr = {}
+        self._lazy_lr[k] = float(lr)
+        pipe_la = la and self.pipeline_lookahead      # the pipelined step in its look-ahead form (rows may go on lagging)
+        if (self.pipeline and not lazy and (not self._lazy_dirty or self._lazy_kind == "la") and eps is None
+                and not self.sparse_adam
                 and out_pred is None and ops.pipeline_supported(plan.spec)
                 and (self.pipeline is True or (self.d >= self.pipeline_min_d and self.T >= self.pipeline_min_T))):
             ready = self._records_ready(plan, step)
             nxt = next_plan
-            if nxt is not None and self.pipeline == "auto" and (nxt.B < self.pipeline_ratio * nxt.U
-                                                                 or nxt.U < self.pipeline_min_touch * self.T):
+            # (a batch that covers a small part of the table pipelines only in the look-ahead form: the every-row record
+            #  backward would visit all T rows for it)
+            if nxt is not None and self.pipeline == "auto" and (nxt.B < self.pipeline_ratio * nxt.U or (
+                    nxt.U < self.pipeline_min_touch * self.T and not pipe_la)):
                 nxt = None                # too few rows per entity / too small a part of the table for the records to pay
-            if ready or (nxt is not None and (self.pipeline is True or (plan.B >= self.pipeline_ratio * plan.U
-                                                                        and plan.U >= self.pipeline_min_touch * self.T))):
-                return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay)
-        if k == 1:
-            self._lazy_lr = {}
-        self._lazy_lr[k] = float(lr)
+            if ready or (nxt is not None and (self.pipeline is True or (plan.B >= self.pipeline_ratio * plan.U and (
+                    plan.U >= self.pipeline_min_touch * self.T or pipe_la)))):
+                if self._lazy_dirty and not pipe_la:      # (the last step of a moment period, or no next batch named: the
+                    self.sync_lazy(self._adam_t - 1)      #  every-row form -- all rows up to date first; the records stay valid)
+                    mark("catchup")
+                return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay,
+                                                  la_next=next_plan if pipe_la else None)
         kind = "list" if lazy else ("la" if la else None)
         caught_up = False                # a catch-up pass ran in front of this step: not a replayable launch sequence
         if self._lazy_dirty and kind != self._lazy_kind:
@@ -849,8 +861,11 @@ class VFM(nn.Module):
         f = self._zrec_for
         return f is not None and f[0] is plan and f[1] == step and f[2] == self._flat._version
 
-    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark, wrec=None, may_replay=False):
-        """The fused step with the sampling of the NEXT batch moved into this step's backward (see __init__)."""
+    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark, wrec=None, may_replay=False, la_next=None):
+        """The fused step with the sampling of the NEXT batch moved into this step's backward (see __init__).
+        la_next (the next batch's plan): the look-ahead form -- the backward visits only the rows of this batch and of that
+        one, replaying the zero-gradient updates a visited row skipped (exactly the bookkeeping of the look-ahead form in
+        `_step_fused`: `_lazy_last`, `_la_tab`, `_la_ready_for`)."""
         ent, bia, scal = self._views(self._flat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
         if self._zrec is None:
@@ -858,6 +873,25 @@ class VFM(nn.Module):
             self._zrec = [torch.zeros(self.T, rl, dtype=torch.float32, device=self.device) for _ in range(2)]
         cur, nxt = self._zrec
         fresh = not self._records_ready(plan, step)
+        la = la_next is not None
+        if la:
+            k = (self._adam_t - 1) % ops.MOMENT_PERIOD + 1
+            if self._lazy_last is None:
+                self._lazy_last = torch.empty(self.T, dtype=torch.int32, device=self.device)
+            if not self._lazy_dirty:     # no row lags: every row is at the step before this one
+                self._lazy_last.fill_(self._adam_t - 1)
+            if self._la_tab is None:
+                self._la_tab = torch.zeros(2 * (ops.MOMENT_PERIOD + 1), dtype=torch.float32, device=self.device)
+            ready = self._la_ready_for
+            if self._lazy_dirty and not (ready is not None and ready[0] is plan and ready[1] == self._adam_t - 1):
+                # this batch was not the one announced to the previous step: bring its rows up to date now (the records
+                # below are then sampled from current rows; the kernel finds nothing left to replay on them)
+                ops.adam_catchup(ent, bia, self._views(self._adam_m), self._views(self._adam_v), self._lazy_last,
+                                 plan.touched_ids(), self._lazy_lrs(k - 1), upto=self._adam_t - 1, mark=self._adam_t - 1,
+                                 wrec=wrec)
+                mark("catchup")
+                fresh = True             # (records written for this batch before its rows were caught up would be stale)
+            may_replay = False           # (the look-ahead bookkeeping of this form is not part of a captured graph)
         if fresh:                                     # first step of a run (or the tables changed since): from the tables
             ops.sample_records(plan, ent, bia, self.inv_occ, cur, self.rng_seed, step)
             mark("sample_rec")
@@ -870,7 +904,9 @@ class VFM(nn.Module):
             mark("fwd")
             ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
                                         self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
-                                        scaled_moments=scaled, wrec=wrec, dev_step=dev)
+                                        scaled_moments=scaled, wrec=wrec, dev_step=dev,
+                                        last_step=self._lazy_last if la else None, step_tab=self._la_tab if la else None,
+                                        listed=self.lookahead_list, la_next=la_next)
             mark("bwd_adam")
             return st.pred
 
@@ -889,6 +925,9 @@ class VFM(nn.Module):
             self._zrec_for = (next_plan, step + 1, self._flat._version)
         else:
             self._zrec_for = None
+        if la:
+            self._lazy_dirty, self._lazy_kind = True, "la"
+            self._la_ready_for = (la_next, self._adam_t)
         return loss3, out
 
     def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,

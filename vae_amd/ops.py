@@ -458,7 +458,8 @@ def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, o
 
 def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next_plan, next_step, entity_params,
                             bias_params, scalars, inv_occ, m_views, v_views, lr, step, loss_out, beta1=0.9, beta2=0.999,
-                            eps_adam=1e-8, scaled_moments=True, wrec=None, dev_step=None):
+                            eps_adam=1e-8, scaled_moments=True, wrec=None, dev_step=None, last_step=None, step_tab=None,
+                            listed=True, la_next=None):
     """vfm_elbo_bwd_adam_pipe_f32: loss + backward + dense Adam, gathering samples from `zrec`, and (next_plan given)
     writing the records of `next_plan`'s entities for Philox step `next_step` into `zrec_next`."""
     t = plan.index_tensors()
@@ -475,6 +476,17 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
             next_plan.build_index()
         pipe.zrec_next, pipe.next_occ_ptr, pipe.next_W = zrec_next.data_ptr(), next_plan.occ_ptr.data_ptr(), next_plan.W.data_ptr()
         pipe.next_step = int(next_step)
+    if last_step is not None:          # look-ahead form: visit the rows of this batch and of `la_next` only
+        if la_next.occ_ptr is None:
+            la_next.build_index()
+        pipe.last_step, pipe.step_tab = last_step.data_ptr(), step_tab.data_ptr()
+        pipe.next_occ_ptr = la_next.occ_ptr.data_ptr()
+        if next_plan is not None and next_plan is not la_next:
+            raise ValueError("pipelined look-ahead step: the records are prepared for the batch the look-ahead names")
+        if listed:
+            rows = plan.lookahead_rows(la_next)
+            if rows.numel() > 0:
+                ix.touched_ids, ix.n_touched = rows.data_ptr(), rows.numel()
     p = st.problem
     p.flags = plan.spec.link_flag | (FLAG_SCALED_MOMENTS if scaled_moments else 0)
     p.wrec = wrec.data_ptr() if wrec is not None else None
