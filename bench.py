@@ -327,7 +327,7 @@ def main():
                     e.record()
                     ev[name] = e
             model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables,
-                             next_plan=plans[(s + 1) % nbt] if not multi else None)
+                             next_plan=plans[(s + 1) % nbt] if (not multi or model.exchange == "rows") else None)
             if args.sync_each_step:
                 torch.cuda.synchronize()
         model.replay = False

@@ -509,8 +509,9 @@ def test_lazy_statistics_step_is_bitwise_the_dense_one(F, d, monkeypatch):
         assert torch.equal(lz[i], dn[i]), i
 
 
-@pytest.mark.parametrize("world,B,d,output,n_steps", [(3, 96, 32, "reg", 60), (5, 4, 16, "class", 60), (8, 300, 128, "reg", 20)])
-def test_rows_exchange_follows_the_single_rank_pipelined_step(world, B, d, output, n_steps, monkeypatch):
+@pytest.mark.parametrize("world,B,d,output,n_steps,announce", [(3, 96, 32, "reg", 60, False), (3, 96, 32, "reg", 150, True),
+                                                              (5, 4, 16, "class", 60, True), (8, 300, 128, "reg", 20, True)])
+def test_rows_exchange_follows_the_single_rank_pipelined_step(world, B, d, output, n_steps, announce, monkeypatch):
     """`exchange = "rows"` (vae_amd/dist.py::step_rows): the ranks all-reduce every row's dloss/dpred and the six ELBO sums
     (B_global + 8 doubles), each samples the records of all the batch's entities from its replica and runs the whole
     batch's backward + Adam itself.  Against one rank taking the software-pipelined step on the whole batch (the same
@@ -543,21 +544,30 @@ def test_rows_exchange_follows_the_single_rank_pipelined_step(world, B, d, outpu
             plans.append(m.plan(X[a:b], y[a:b], B_global=B, process_group=group))
         losses = []
         for s in range(n_steps):
-            l3, pr = m.train_step(plans[s % nb], lr=0.05 if s % 7 else 0.02, process_group=group)
-            assert pr.numel() == plans[s % nb].B
+            # announce: the step is told which batch follows -- it then runs in the look-ahead form (rows of neither
+            # global batch wait) and writes the next batch's records itself; step 40 meets a batch nobody announced
+            nxt = plans[(s + 1) % nb] if (announce and s != 39) else None
+            cur = plans[s % nb] if s != 40 else plans[(s + 2) % nb]
+            l3, pr = m.train_step(cur, lr=0.05 if s % 7 else 0.02, process_group=group, next_plan=nxt)
+            assert pr.numel() == cur.B
             losses.append(l3.clone())
-        return m._flat, m._adam_m, m._adam_v, torch.stack(losses), m._exchanged_floats
+        lagged = bool(m._lazy_dirty)
+        m.sync_lazy()
+        return m._flat, m._adam_m, m._adam_v, torch.stack(losses), m._exchanged_floats, lagged
 
     out, sh = run_ranks(world, rank_body, monkeypatch)
     for r in range(1, world):
         assert all(torch.equal(out[r][i], out[0][i]) for i in range(4)), r
     assert out[0][4] == 2 * (B + 8)
+    assert out[0][5] == (announce and B * 2 < 0.5 * sum(sizes))          # rows did wait where a batch leaves most of the table alone
     single.set_training_data(X, nb_train=nb * B)
     single.pipeline, single.lookahead, single.lazy_adam = True, False, False
     single.pipeline_min_T = single.pipeline_min_d = 0
     plans = [single.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(nb)]
-    want_l = torch.stack([single.train_step(plans[s % nb], lr=0.05 if s % 7 else 0.02, next_plan=plans[(s + 1) % nb])[0].clone()
+    want_l = torch.stack([single.train_step(plans[s % nb] if s != 40 else plans[(s + 2) % nb], lr=0.05 if s % 7 else 0.02,
+                                            next_plan=plans[(s + 1) % nb] if s != 39 else None)[0].clone()
                           for s in range(n_steps)])
+    single.sync_lazy()
     assert single._zrec is not None                                   # (the single rank did take the pipelined step)
     errs = {"loss": float(((out[0][3] - want_l).abs() / want_l.abs()).max())}
     for name, got in zip(("_flat", "_adam_m", "_adam_v"), out[0][:3]):

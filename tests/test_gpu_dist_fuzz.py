@@ -110,6 +110,7 @@ def test_switching_between_the_exchange_forms_mid_training(seed, monkeypatch):
     world = int(g.choice([2, 3, 5]))
     sizes, d, B, nb, n_steps = [int(g.integers(100, 900)), int(g.integers(60, 500))], 16, int(g.choice([48, 200])), 4, 70
     modes = [str(g.choice(["stats", "grads", "rows"])) for _ in range(n_steps)]
+    announce = [bool(g.random() < 0.6) for _ in range(n_steps)]       # (a step told which batch follows: the rows form then lets rows wait)
     lrs = [float(g.choice([0.02, 0.01])) for _ in range(n_steps)]
     X, y = synthetic_triples(sizes, nb * B, seed=4, device="cuda")
     torch.manual_seed(3)
@@ -129,7 +130,8 @@ def test_switching_between_the_exchange_forms_mid_training(seed, monkeypatch):
         losses = []
         for s in range(n_steps):
             m.exchange = modes[s]
-            losses.append(m.train_step(plans[s % nb], lr=lrs[s], process_group=group)[0].clone())
+            losses.append(m.train_step(plans[s % nb], lr=lrs[s], process_group=group,
+                                       next_plan=plans[(s + 1) % nb] if announce[s] else None)[0].clone())
             if s % 23 == 7:
                 losses.append(m.predict(X[:30])["y_pred"].sum().reshape(1).repeat(3))
         m.sync_lazy()

@@ -238,43 +238,72 @@ def rows_supported(spec) -> bool:
     return ops.pipeline_supported(spec)
 
 
-def step_rows(model, plan, lr, step, group, mark=lambda name: None):
+def step_rows(model, plan, lr, step, group, mark=lambda name: None, next_plan=None):
     """One multi-rank training step of `model` on its row shard `plan`, exchanging per-ROW gradients (per rank the
     reference's loop body, vfm-torch.py:351-370; across ranks ONE all-reduce of B_global + 8 doubles):
-      1. every rank samples the records (w_e, KL share, z_e) of ALL entities of the global batch from its replica of the
-         tables -- eps is keyed on (entity, step), so the replicas draw the same samples (vfm_sample_records_f32);
+      1. every rank holds the records (w_e, KL share, z_e) of ALL entities of the global batch, made from its replica of
+         the tables -- eps is keyed on (entity, step), so the replicas draw the same samples: written by the previous
+         step's backward when that step was told this batch would follow (`next_plan`), else sampled now
+         (vfm_sample_records_f32);
       2. forward of the rank's OWN rows as a gather of those records: pred_r, g_r = dloss/dpred_r, the ELBO sums of its rows;
       3. all-reduce of [g of all rows (zeros outside the own block) | the six sums]: afterwards every rank holds every row's g;
       4. loss + backward + dense Adam over the WHOLE batch from the records and the gathered g, on every rank
-         (vfm_elbo_bwd_adam_pipe_f32 without next-batch records): the replicas apply the same update to the same values.
+         (vfm_elbo_bwd_adam_pipe_f32) -- with `next_plan` in the look-ahead form (rows in neither this global batch nor
+         the next are skipped and replayed later, exactly as in the single-rank pipelined step) and writing the next
+         batch's records.  The replicas apply the same update to the same values.
     Against the statistics exchange: 0.8 MB instead of 50 MB per step at cfg4 -- the all-reduce stops being the step --
-    for one sampling pass over the batch's entities and a backward that walks all B_global rows instead of B_global / N."""
+    for a backward that walks all B_global rows instead of B_global / N."""
     from . import ops
     ent, bia, scal = model._views(model._flat)
     loss3 = model._gflat[model._n_flat: model._n_flat + 3]
     gp, off = global_plan(plan, group, model)
+    gnext = global_plan(next_plan, group, model)[0] if (next_plan is not None and next_plan.y is not None) else None
     Bg, B = gp.B, plan.B
-    scaled = model.scaled_moments
+    scaled = model.scaled_moments and not model.sparse_adam
     model._set_moment_form(scaled)
     model._adam_t += 1
+    t = model._adam_t
+    k = (t - 1) % ops.MOMENT_PERIOD + 1
+    if k == 1:
+        model._lazy_lr = {}
+    model._lazy_lr[k] = float(lr)
+    la = (gnext is not None and scaled and k < ops.MOMENT_PERIOD and model.pipeline_lookahead
+          and model._lookahead_pays(gp, gnext))
+    if model._lazy_dirty and not (la and model._lazy_kind == "la"):
+        model.sync_lazy(t - 1)            # (the last step of a moment period / another step form before: every row current)
+        mark("catchup")
     if model._zrec is None:
         rl = ops.record_len(model.d)
         model._zrec = [torch.zeros(model.T, rl, dtype=torch.float32, device=model.device) for _ in range(2)]
-    cur = model._zrec[0]
+    cur, nxt = model._zrec
+    fresh = not model._records_ready(gp, step)
+    mv, vv = model._views(model._adam_m), model._views(model._adam_v)
+    if la:
+        if model._lazy_last is None:
+            model._lazy_last = torch.empty(model.T, dtype=torch.int32, device=model.device)
+        if not model._lazy_dirty:
+            model._lazy_last.fill_(t - 1)
+        if model._la_tab is None:
+            model._la_tab = torch.zeros(2 * (ops.MOMENT_PERIOD + 1), dtype=torch.float32, device=model.device)
+        ready = model._la_ready_for
+        if model._lazy_dirty and not (ready is not None and ready[0] is gp and ready[1] == t - 1):
+            ops.adam_catchup(ent, bia, mv, vv, model._lazy_last, gp.touched_ids(), model._lazy_lrs(k - 1), upto=t - 1, mark=t - 1)
+            mark("catchup")
+            fresh = True
     bufs = model.__dict__.setdefault("_rows_bufs", {})
     hit = bufs.get(Bg)
     if hit is None:
         dev = model.device
         hit = bufs[Bg] = (torch.zeros(Bg + 8, dtype=torch.float64, device=dev),            # the exchanged buffer
                           torch.zeros(Bg, dtype=torch.float32, device=dev),                # g of all rows
-                          torch.zeros(_PARTIALS_LEN(), dtype=torch.float64, device=dev),   # the global sums as ONE slot
-                          torch.zeros(max(Bg, 1), dtype=torch.float32, device=dev))        # (placeholder predictions of the global pass)
+                          torch.zeros(_PARTIALS_LEN(), dtype=torch.float64, device=dev))   # the global sums as ONE slot
         hit[2][7] = 1.0                                    # (one "workgroup slot": the global sums)
         if len(bufs) > 8:
             bufs.pop(next(iter(bufs)))
-    xbuf, g_all, pg, _ = hit
-    ops.sample_records(gp, ent, bia, model.inv_occ, cur, model.rng_seed, step)
-    mark("sample_rec")
+    xbuf, g_all, pg = hit
+    if fresh:
+        ops.sample_records(gp, ent, bia, model.inv_occ, cur, model.rng_seed, step)
+        mark("sample_rec")
     _, grow, pred = model._step_buffers(B)
     if B > 0:
         st = ops.elbo_forward_records(plan, cur, scal, model.rng_seed, step, pred, grow, model._partials)
@@ -291,11 +320,19 @@ def step_rows(model, plan, lr, step, group, mark=lambda name: None):
     mark("exchange")
     p = ops._problem(gp.spec, Bg, Bg, gp.id_bits, model.rng_seed, step, 0)
     stg = ops.FwdState(pred, pg, None, g_all, p, None)
-    ops.elbo_backward_adam_pipe(gp, stg, cur, None, None, step + 1, ent, bia, scal, model.inv_occ,
-                                model._views(model._adam_m), model._views(model._adam_v), lr, model._adam_t, loss3,
-                                scaled_moments=scaled)
+    ops.elbo_backward_adam_pipe(gp, stg, cur, nxt if gnext is not None else None, gnext, step + 1, ent, bia, scal, model.inv_occ,
+                                mv, vv, lr, t, loss3, scaled_moments=scaled,
+                                last_step=model._lazy_last if la else None, step_tab=model._la_tab if la else None,
+                                listed=model.lookahead_list, la_next=gnext if la else None)
     mark("bwd_adam")
-    model._zrec_for = None
+    if gnext is not None:
+        model._zrec = [nxt, cur]
+        model._zrec_for = (gnext, step + 1, model._flat._version)
+    else:
+        model._zrec_for = None
+    if la:
+        model._lazy_dirty, model._lazy_kind = True, "la"
+        model._la_ready_for = (gnext, t)
     return loss3, pred[:B]
 
 

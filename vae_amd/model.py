@@ -618,8 +618,9 @@ class VFM(nn.Module):
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
         stats_step = process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1
-        if process_group is not None and not stats_step:
-            self.sync_lazy()          # these multi-rank steps update every row they own (the statistics step keeps its own lazy state)
+        rows_step = process_group is not None and adam and self.exchange == "rows"
+        if process_group is not None and not (stats_step or rows_step):
+            self.sync_lazy()          # these multi-rank steps update every row they own (the statistics / rows steps keep their own lazy state)
         # a step in another mode than the one that left the full tables stale: bring them up to date first
         if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_kind", None) not in (
                 None, self.exchange if process_group is not None else "single"):
@@ -656,7 +657,7 @@ class VFM(nn.Module):
             from .dist import step_rows, rows_supported
             if not rows_supported(plan.spec) or eps is not None or out_pred is not None or self.sparse_adam:
                 raise ValueError('exchange = "rows": two fields, one sample, d % 4 == 0, d <= 512, Philox eps, dense Adam')
-            return step_rows(self, plan, lr, step, process_group, mark)
+            return step_rows(self, plan, lr, step, process_group, mark, next_plan=next_plan)
         if self._lazy_dirty:
             self.sync_lazy()
         return self._step_unfused(plan, lr, step, eps, out_pred, adam, mark, process_group)
@@ -981,7 +982,8 @@ class VFM(nn.Module):
                     loss3, pr = self.train_step(plan, process_group=process_group)
                     train_pred[a:b] = pr
                 elif self.n_samples == 1:
-                    nxt = plans[(i + 1) % len(plans)] if world == 1 else None      # (pipelined step: names the next batch)
+                    # (the pipelined / look-ahead forms, and the multi-rank rows exchange, are told which batch follows)
+                    nxt = plans[(i + 1) % len(plans)] if (world == 1 or self.exchange == "rows") else None
                     loss3, pr = self.train_step(plan, process_group=process_group, next_plan=nxt)
                     train_pred[a:b] = pr
                 else:       # [S,B] predictions: the train metrics use their mean over the samples
