@@ -17,6 +17,7 @@ WANT = [
     ("vfm_fwdg.hip", [], "k_fwdg<32, true, 0, 1, true, 0, true>", "cfg5 forward (F = 32, d = 256: fields split over lane groups)"),
     ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg3 fused backward + dense Adam, look-ahead form"),
     ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<64, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg5 fused backward + dense Adam, look-ahead form"),
+    ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, true, true>", "pipelined step's backward in the look-ahead form (data-file-order batches; the rows exchange)"),
     ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 2, 0, false, false, false>", "multi-rank apply stage (epilogue + Adam from the summed statistics)"),
 ]
 CLASSES = ["global_load_dwordx4", "global_load_dwordx2", "global_load_dword", "global_store_dwordx4", "global_store_dwordx2",
