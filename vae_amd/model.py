@@ -968,8 +968,8 @@ class VFM(nn.Module):
         if world == 1 and self.lookahead and self.lookahead_list and len(plans) > 1 and self.n_samples == 1:
             for i, plan in enumerate(plans):              # row lists of the look-ahead step, once per pair of batches --
                 nxt = plans[(i + 1) % len(plans)]         # only where that step form will run (U: one deferred readback)
-                if self._lookahead_pays(plan, nxt) and not self._will_pipeline(plan, nxt):
-                    plan.prepare_lookahead(nxt)
+                if self._lookahead_pays(plan, nxt) and (not self._will_pipeline(plan, nxt) or self.pipeline_lookahead):
+                    plan.prepare_lookahead(nxt)       # (the pipelined step has a look-ahead form too)
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
         replay_before = self.replay
         if world > 1:
