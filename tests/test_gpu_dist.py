@@ -91,13 +91,14 @@ def _fit_worker(rank, world, port, out_dir, exchange="auto"):
               X_test=X[:500], y_test=y[:500])
     if exchange == "sharded":
         m.sync_params(dist.group.WORLD)
+    m.sync_lazy()                     # ("rows": fit() names the next batch, so rows outside two global batches may wait)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"fit_{rank}.npy"), m._flat.cpu().numpy())
     np.save(os.path.join(out_dir, f"elbo_{rank}.npy"), np.array(h["elbo"]))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["auto", "sharded"])
+@pytest.mark.parametrize("exchange", ["auto", "sharded", "rows"])
 def test_fit_two_ranks_matches_single_rank(exchange, tmp_path):
     """VFM.fit with a process group (row shards, W all-reduce, statistics exchange or entity-sharded
     tables, short last batch, per-epoch evaluation) lands on the same weights as the single-rank fit."""
