@@ -260,6 +260,19 @@ const char* vfm_last_error(void);
  *             clamps them --, n_heavy, n_items, n_touched = entities in the batch): the caller reads them
  *             back once to fill vfm_index_t */
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
+/* The heavy lists of an index once more, with a LOWER threshold than their work-item length: entities with more than
+ * `threshold` occurrences (VFM_HEAVY_MIN <= threshold <= heavy_list) become heavy, their lists still cut in items of up to
+ * heavy_list.  For batches with many rows per entity (rows in the data files' order: a few hundred users' consecutive
+ * ratings) the walk of a 17..64-row list by ONE lane group, two occurrences in flight, is what the fused backward waits
+ * for; pre-reduced, such a list is one work item with eight in flight (data-file order at the ML-20M shape: backward 103 ->
+ * 94 us, step 0.130 -> 0.112 ms; with users spread over the table it costs 3 %, with 10^6 rows covering the table 10 %, so
+ * the caller decides: vae_amd does it for plans with B >= 4 U and U <= T / 4 on tables of >= 8,192 rows).  occ_ptr: of the built index; ws: a workspace as for
+ * vfm_build_index; counts [4]: (0, n_heavy, n_items, n_touched) again.  Capacities that always suffice:
+ * cap_heavy = B*F / threshold + 1, cap_items = B*F / heavy_list + B*F / threshold + 2.
+ * vfm_heavy_threshold(heavy_list) = the threshold vae_amd uses: heavy_list / 4, at least VFM_HEAVY_MIN. */
+int vfm_rebuild_heavy(int64_t T, const int32_t* occ_ptr, void* ws, int32_t heavy_list, int32_t threshold, int32_t* heavy_ids,
+                      int64_t cap_heavy, int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream);
+int32_t vfm_heavy_threshold(int32_t heavy_list);
 /* The heavy-list length to build an index with: VFM_HEAVY_LIST when the table has at least VFM_HEAVY_UNITS rows
  * (one lane group per row already fills the chip and only the really long lists need cutting), else about
  * n_occ / VFM_HEAVY_UNITS occurrences per work item, never below VFM_HEAVY_MIN (small tables -- ML-100K shape:

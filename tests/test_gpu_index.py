@@ -8,13 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _ref(x, T, F, L):
+def _ref(x, T, F, L, thr=None):
+    thr = L if thr is None else thr
     flat = x.reshape(-1).astype(np.int64)
     order = np.argsort(flat, kind="stable")
     occ_rows = (order // F).astype(np.int32)
     counts = np.bincount(flat, minlength=T)
     occ_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-    heavy = np.nonzero(counts > L)[0]
+    heavy = np.nonzero(counts > thr)[0]          # thr = vfm_heavy_threshold(L): longer lists are pre-reduced, in items of L
     items = []
     for slot, e in enumerate(heavy):
         b, c = occ_ptr[e], counts[e]
@@ -34,6 +35,7 @@ CASES = [  # (B, field sizes, zipf exponent or None, id dtype)
     (300, [2 ** 21 + 5, 9], None, torch.int64),     # 22-bit keys, nearly empty table
     (300000, [138493, 26744], 1.05, torch.int32),   # 293 sort tiles: the per-digit scan kernel (more than 256 tiles)
     (263000, [90, 26744], None, torch.int64),       # 257 tiles, one column with very long lists
+    (60000, [300, 40000], 1.3, torch.int64),        # many rows per entity, a small part of a large table: the lowered heavy threshold
 ]
 
 
@@ -50,7 +52,11 @@ def test_index_equals_stable_sort(B, sizes, zipf, dtype):
     inv_occ = torch.ones(T, dtype=torch.float32, device=dev)
     plan = ops.BatchPlan(spec, X, y, inv_occ)
     assert plan.heavy_list == _lib.heavy_list_for(B * F, T) and 8 <= plan.heavy_list <= 64
-    ptr_want, rows_want, heavy_want, items_want = _ref(X.cpu().numpy(), T, F, plan.heavy_list)
+    # (many rows per entity on a large table: the heavy lists are rebuilt with a quarter of the item length as threshold)
+    lowered = plan.B >= 4 * plan.U and 4 * plan.U <= T and T >= 8192
+    thr = int(_lib.load().vfm_heavy_threshold(plan.heavy_list)) if lowered else plan.heavy_list
+    assert thr == (max(8, plan.heavy_list // 4) if lowered else plan.heavy_list) and getattr(plan, "heavy_threshold", plan.heavy_list) == thr
+    ptr_want, rows_want, heavy_want, items_want = _ref(X.cpu().numpy(), T, F, plan.heavy_list, thr)
     assert np.array_equal(plan.occ_ptr.cpu().numpy(), ptr_want)
     assert np.array_equal(plan.occ_rows.cpu().numpy(), rows_want)
     if len(heavy_want):

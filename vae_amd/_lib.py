@@ -37,7 +37,7 @@ EXPORTS = (
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32", "vfm_union_rows", "vfm_union_workspace_bytes",
     "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
     "vfm_step_consts", "vfm_dev_step_set", "vfm_wrec_build_f32", "vfm_elbo_apply_adam_rows_f32",
-    "vfm_elbo_bwd_acc_rows_f32",
+    "vfm_elbo_bwd_acc_rows_f32", "vfm_heavy_threshold", "vfm_rebuild_heavy",
 )
 
 
@@ -147,6 +147,7 @@ def load():
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_heavy_list_for.argtypes = [i64, i64]
     lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.vfm_rebuild_heavy.argtypes = [i64, vp, vp, i32, i32, vp, i64, vp, i64, vp, vp]
     lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), i64, C.c_float, C.c_float, C.c_float,
                                          i64, i64, vp, vp]
     lib.vfm_step_consts.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, i64, i32, C.POINTER(StepConsts)]

@@ -32,11 +32,12 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
 #pragma unroll
       for (int t = 0; t < VEC; ++t) A[i].v[t] = 0.f;
     float gs = 0.f;
-    for (int o = beg; o < end; o += 4) {      // four occurrences in flight
-      int r[4]; float g[4];
-      const float* src[4];           // the sumz row, or (pipelined step) the other entity's sample record
+    constexpr int W = 8 / CPL > 2 ? 8 / CPL : 2;      // occurrences in flight (added in list order: the sum's order is fixed)
+    for (int o = beg; o < end; o += W) {
+      int r[W]; float g[W];
+      const float* src[W];           // the sumz row, or (pipelined step) the other entity's sample record
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < W; ++u) {
         const bool ok = o + u < end;
         const int oo = ok ? o + u : beg;
         r[u] = occ_rows[oo];
@@ -48,11 +49,11 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
       for (int i = 0; i < CPL; ++i) {
         const int j = lig + i * LPE;
         if (j < C) {
-          Chunk<VEC> sv[4];
+          Chunk<VEC> sv[W];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) sv[u] = ld_chunk<VEC>(src[u] + (size_t)j * VEC);
+          for (int u = 0; u < W; ++u) sv[u] = ld_chunk<VEC>(src[u] + (size_t)j * VEC);
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < W; ++u)
 #pragma unroll
             for (int t = 0; t < VEC; ++t) A[i].v[t] = fmaf(g[u], sv[u].v[t], A[i].v[t]);
         }

@@ -240,19 +240,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_index_finish(const uint32_t* __r
 
 // ---- compaction passes over the entities, in id order: (a) entities with more than L occurrences and their work
 // items, (b) the entities the batch contains at all (`touched`: the row list of the lazy Adam step) ----
-__device__ __forceinline__ void heavy_of(const int32_t* occ_ptr, int64_t e, int64_t T, int L, int& cnt, int& beg, bool& any) {
+__device__ __forceinline__ void heavy_of(const int32_t* occ_ptr, int64_t e, int64_t T, int THR, int& cnt, int& beg, bool& any) {
   cnt = 0; beg = 0;
   if (e < T) { beg = occ_ptr[e]; cnt = occ_ptr[e + 1] - beg; }
   any = cnt > 0;
-  if (cnt <= L) cnt = 0;
+  if (cnt <= THR) cnt = 0;
 }
 
-__global__ __launch_bounds__(HV_CHUNK) void k_heavy_count(const int32_t* __restrict__ occ_ptr, int64_t T, int L,
+__global__ __launch_bounds__(HV_CHUNK) void k_heavy_count(const int32_t* __restrict__ occ_ptr, int64_t T, int L, int THR,
                                                           uint32_t* __restrict__ blk /*[3][NBH]*/, int NBH) {
   __shared__ uint32_t sh[3][HV_CHUNK / 64];
   const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + threadIdx.x;
   int cnt, beg; bool any;
-  heavy_of(occ_ptr, e, T, L, cnt, beg, any);
+  heavy_of(occ_ptr, e, T, THR, cnt, beg, any);
   uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); c += __shfl_xor(c, m, 64); }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(192) void k_heavy_scan(uint32_t* __restrict__ blk, 
   if (lane == 0) counters[1 + w] = carry;
 }
 
-__global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restrict__ occ_ptr, int64_t T, int L,
+__global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restrict__ occ_ptr, int64_t T, int L, int THR,
                                                           const uint32_t* __restrict__ blk, int NBH,
                                                           int32_t* __restrict__ heavy_ids, int32_t* __restrict__ items,
                                                           int cap_h, int cap_i, int32_t* __restrict__ touched_ids) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restr
   const int tid = threadIdx.x;
   const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
   int cnt, beg; bool any;
-  heavy_of(occ_ptr, e, T, L, cnt, beg, any);
+  heavy_of(occ_ptr, e, T, THR, cnt, beg, any);
   const uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
   uint32_t ia = a, ib = b, ic = c;                // inclusive scans inside the wave
 #pragma unroll
@@ -392,6 +392,13 @@ int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T) {
   return (int32_t)(l < VFM_HEAVY_MIN ? VFM_HEAVY_MIN : (l > VFM_HEAVY_LIST ? VFM_HEAVY_LIST : l));
 }
 
+// The lower threshold vfm_rebuild_heavy is meant to be called with: a quarter of the work-item length (VFM_HEAVY_THR: A/B runs)
+int32_t vfm_heavy_threshold(int32_t heavy_list) {
+  int thr = env_int("VFM_HEAVY_THR", heavy_list / 4);
+  if (thr > heavy_list) thr = heavy_list;
+  return thr < VFM_HEAVY_MIN ? VFM_HEAVY_MIN : thr;
+}
+
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
   if (B < 0 || F < 1 || T < 1 || B * (int64_t)F > 0x7FFFFFFFLL) return -1;
   const int64_t n = B * F;
@@ -467,15 +474,39 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
     hipLaunchKernelGGL(k_index_finish, dim3((unsigned)g), dim3(RS_THREADS), 0, st, k0, v0, n, (int)F, T, occ_ptr, occ_rows,
                        x, (int)(id_bits == 64), occ_other);
   }
-  hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, blk, NBH);
+  const int thr = (int)heavy_list;
+  hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, thr, blk, NBH);
   hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);
-  hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, blk, NBH, heavy_ids,
+  hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, thr, blk, NBH, heavy_ids,
                      heavy_items, (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy),
                      (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items), touched_ids);
   e = hipMemcpyAsync(counts, counters, 16, hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index: copy of the counters");
   e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index");
+  return 0;
+}
+
+int vfm_rebuild_heavy(int64_t T, const int32_t* occ_ptr, void* ws, int32_t heavy_list, int32_t threshold, int32_t* heavy_ids,
+                      int64_t cap_heavy, int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream) {
+  if (T < 1 || T > 0xFFFFFFFELL || !occ_ptr || !ws || !counts || heavy_list < VFM_HEAVY_MIN || threshold < VFM_HEAVY_MIN ||
+      threshold > heavy_list || cap_heavy < 0 || cap_items < 0 || (cap_heavy > 0 && !heavy_ids) || (cap_items > 0 && !heavy_items))
+    return fail(VFM_E_INVALID, "vfm_rebuild_heavy: bad argument (VFM_HEAVY_MIN <= threshold <= heavy_list)");
+  hipStream_t st = (hipStream_t)stream;
+  const int NBH = (int)((T + HV_CHUNK - 1) / HV_CHUNK);
+  uint32_t* blk = reinterpret_cast<uint32_t*>(ws);
+  unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)3 * NBH + 4);
+  hipError_t e = hipMemsetAsync(counters, 0, 16, st);
+  if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy: memset");
+  hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, (int)threshold, blk, NBH);
+  hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);
+  hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, (int)threshold, blk, NBH, heavy_ids,
+                     heavy_items, (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy),
+                     (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items), (int32_t*)nullptr);
+  e = hipMemcpyAsync(counts, counters, 16, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy: copy of the counters");
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy");
   return 0;
 }
 

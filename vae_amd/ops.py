@@ -240,6 +240,27 @@ class BatchPlan:
         spec, dev = self.spec, self.x.device
         self._U = n_touched                              # entities in the batch
         self._touched = touched[:n_touched]
+        # many rows per entity on a large table (rows in the data files' order: a few hundred users' consecutive ratings):
+        # the heavy lists once more with a lower threshold -- lists of 17..64 rows become work items of the pre-reduction
+        # (eight occurrences in flight) instead of being walked by one lane group of the main kernel, two at a time
+        # (vfm_rebuild_heavy in include/vfm_hip.h: backward 103 -> 94 us on that shape; 3 % slower where users are spread
+        # over the table, so only here)
+        thr = int(_lib.load().vfm_heavy_threshold(self.heavy_list))
+        # (... and where the batch covers the table -- 10^6 rows at the ML-20M shape -- the main kernel has 165 K rows to
+        #  hide those walks behind: lowering the threshold there cost 10 %)
+        if (n_touched > 0 and self.B >= 4 * n_touched and 4 * n_touched <= spec.T and spec.T >= 8192
+                and thr < self.heavy_list and not n_bad):
+            n, L = self.B * spec.F, self.heavy_list
+            cap_h, cap_i = n // thr + 1, n // L + n // thr + 2
+            arena = torch.empty(((cap_h + 3) & ~3) + 4 * cap_i + 8, dtype=torch.int32, device=dev)
+            hid, items, counts2 = arena[:cap_h], arena[(cap_h + 3) & ~3:((cap_h + 3) & ~3) + 4 * cap_i].view(cap_i, 4), arena[-4:]
+            lib = _lib.load()
+            with _ENQUEUE_LOCK:
+                ws = _index_workspace(int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T)) // 4 + 4, dev)
+                check(lib.vfm_rebuild_heavy(spec.T, ptr(self.occ_ptr), ptr(ws), L, thr, ptr(hid), cap_h, ptr(items), cap_i,
+                                            ptr(counts2), current_stream_ptr(dev)), "vfm_rebuild_heavy")
+                _, n_heavy, n_items, _ = (int(v) for v in counts2.tolist())          # (a second small readback, these plans only)
+            self.heavy_threshold = thr
         if validate and n_bad and not self._checked:
             # nn.Embedding would raise IndexError (vfm-torch.py:207)
             raise IndexError(f"entity id out of range [0,{spec.T}): min {int(self.x.min())}, max {int(self.x.max())}")
