@@ -128,7 +128,7 @@ class VFM(nn.Module):
         # the plain look-ahead form (`bench.py --user-order --zipf 1.1`) ...
         self.pipeline_min_touch = 0.35
         # ... so the pipelined step has a look-ahead form of its own (k_bwd<PIPE, LA>: rows in neither this batch nor the
-        # next are skipped and replayed later, bitwise the every-row pipelined step): 0.131 ms per step on that shape.
+        # next are skipped and replayed later, bitwise the every-row pipelined step): 0.113-0.131 ms per step on that shape.
         self.pipeline_lookahead = True
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
