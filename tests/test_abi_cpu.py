@@ -150,6 +150,12 @@ def test_bad_arguments_return_errors_not_crashes():
     p.n_samples, p.d = 1, 1027
     assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -2          # unsupported d
     assert lib.vfm_adam_f32(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, 1, None) == -1
+    # the heavy lists rebuilt with a lower threshold: VFM_HEAVY_MIN <= threshold <= heavy_list, no NULL tables
+    buf = (C.c_int32 * 64)()
+    assert lib.vfm_rebuild_heavy(10, buf, buf, 64, 65, buf, 4, buf, 4, buf, None) == -1 and b"threshold" in lib.vfm_last_error()
+    assert lib.vfm_rebuild_heavy(10, buf, buf, 64, 4, buf, 4, buf, 4, buf, None) == -1
+    assert lib.vfm_rebuild_heavy(10, None, buf, 64, 16, buf, 4, buf, 4, buf, None) == -1
+    assert lib.vfm_heavy_threshold(64) == 16 and lib.vfm_heavy_threshold(19) == 8 and lib.vfm_heavy_threshold(8) == 8
 
 
 def test_torch_ops_shim_registers_schemas():
