@@ -237,6 +237,10 @@ typedef struct vfm_index {
   int64_t n_touched;
   /* optional, two fields: occ_other[i] = the entity in the other column of row occ_rows[i] (vfm_elbo_bwd_adam_pipe_f32) */
   const int32_t* occ_other;
+  /* optional: the largest number of work items ONE heavy entity has (0 = not known).  When it is known to be at most
+   * VFM_HEAVY_DIRECT the main kernel adds every entity's item records itself and the k_heavy_sum launch -- which would
+   * find nothing to do -- is left out (ML-100K shape: one launch of three per backward). */
+  int32_t max_items;
 } vfm_index_t;
 
 int vfm_abi_version(void);

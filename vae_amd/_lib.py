@@ -70,7 +70,7 @@ class Index(C.Structure):
     _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
                 ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
                 ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64),
-                ("occ_other", C.c_void_p)]
+                ("occ_other", C.c_void_p), ("max_items", C.c_int32)]
 
 
 class StepConsts(C.Structure):

@@ -205,6 +205,7 @@ int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow,
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
                      (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec, hacc);
+  if (idx->max_items > 0 && idx->max_items <= VFM_HEAVY_DIRECT) return 0;      // (every entity's items are added by the main kernel)
   nb = idx->n_heavy;                                             // one workgroup per heavy entity
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy_sum<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,

@@ -127,6 +127,14 @@ int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
 // index = [occ_ptr, occ_rows] or [occ_ptr, occ_rows, heavy_ids, heavy_items, heavy_acc], each optionally followed by
 // [touched_ids] (3 or 6 tensors: the batch's entities as a sorted list, vfm_index_t.touched_ids)
 vfm_index_t index_of(at::TensorList index_all, int64_t T, int64_t B, int64_t F, int64_t d, int64_t n_samples = 1) {
+  // (a trailing HOST int32 tensor, if any: [max work items of one heavy entity] -- vfm_index_t.max_items)
+  int32_t max_items = 0;
+  if (index_all.size() > 0 && index_all[index_all.size() - 1].is_cpu()) {
+    const at::Tensor& meta = index_all[index_all.size() - 1];
+    TORCH_CHECK(meta.scalar_type() == at::kInt && meta.numel() >= 1, "index: the trailing host tensor holds int32 [max_items]");
+    max_items = meta.data_ptr<int32_t>()[0];
+    index_all = index_all.slice(0, index_all.size() - 1);
+  }
   TORCH_CHECK(index_all.size() == 2 || index_all.size() == 3 || index_all.size() == 5 || index_all.size() == 6,
               "index = [occ_ptr, occ_rows] (+ [heavy_ids, heavy_items, heavy_acc]) (+ [touched_ids])");
   const bool has_touched = index_all.size() == 3 || index_all.size() == 6;
@@ -143,6 +151,7 @@ vfm_index_t index_of(at::TensorList index_all, int64_t T, int64_t B, int64_t F, 
     ix.heavy_ids = index[2].data_ptr<int32_t>(); ix.heavy_items = index[3].data_ptr<int32_t>();
     ix.heavy_acc = index[4].data_ptr<float>();
     ix.n_heavy = (int32_t)index[2].numel(); ix.n_items = (int32_t)(index[3].numel() / 4);
+    ix.max_items = max_items;
   }
   if (has_touched) {
     const at::Tensor& t = index_all[index_all.size() - 1];

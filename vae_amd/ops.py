@@ -268,7 +268,12 @@ class BatchPlan:
         # long lists (skewed data, small tables): cut in work items of at most `heavy_list` occurrences, pre-reduced
         # by their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
         self._heavy = None
+        self.heavy_max_items = 0
         if n_heavy > 0:
+            # the most work items one entity has (one small reduction + readback, plans with long lists only): at most
+            # VFM_HEAVY_DIRECT and the backward leaves its k_heavy_sum launch out (vfm_index_t.max_items)
+            self.heavy_max_items = int(torch.bincount(items[:n_items, 0].long(), minlength=1).max())
+            self._heavy_meta = torch.tensor([self.heavy_max_items], dtype=torch.int32)
             rec = 4 + (spec.d + 3) // 4 * 4
             self._heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
                            torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
@@ -343,7 +348,9 @@ class BatchPlan:
         base = [self.occ_ptr, self.occ_rows]
         if self.heavy is not None:
             base = base + list(self.heavy)
-        return base + [self._touched] if with_touched else base
+        if with_touched:
+            base = base + [self._touched]
+        return base + [self._heavy_meta] if self.heavy is not None else base       # (host tensor: vfm_index_t.max_items)
 
 
 @dataclass
@@ -486,9 +493,10 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
     t = plan.index_tensors()
     ix = _lib.Index()
     ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
-    if len(t) == 5:
+    if len(t) >= 5:
         ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
         ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+        ix.max_items = plan.heavy_max_items
     ix.occ_other = plan.occ_other.data_ptr()
     pipe = _lib.Pipe()
     pipe.zrec = zrec.data_ptr()
@@ -531,9 +539,10 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
         rows = plan.lookahead_rows(next_plan)
         if rows.numel() > 0:
             ix.touched_ids, ix.n_touched = rows.data_ptr(), rows.numel()
-    if len(t) == 5:
+    if len(t) >= 5:
         ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
         ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+        ix.max_items = plan.heavy_max_items
     if next_plan.occ_ptr is None:
         next_plan.build_index()
     p = st.problem
@@ -653,9 +662,10 @@ def elbo_backward_acc_rows(plan: BatchPlan, st: FwdState, row_ids, acc, sums):
     t = plan.index_tensors()
     ix = _lib.Index()
     ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
-    if len(t) == 5:
+    if len(t) >= 5:
         ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
         ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
+        ix.max_items = plan.heavy_max_items
     spec = plan.spec
     p = _problem(spec, plan.B, plan.B, 64)
     check(_lib.load().vfm_elbo_bwd_acc_rows_f32(C.byref(p), C.byref(ix), ptr(row_ids), row_ids.numel(), ptr(st.sumz),
