@@ -11,16 +11,21 @@ Workload (BASELINE.json configs[2]): synthetic ML-20M-shape triples, N=138,493 u
 items, d=128, global batch B=100,000 rows (the reference's BATCH_SIZE, vfm-torch.py:77),
 uniform-random ids, ratings randint(1,6), eps generated in-kernel (Philox).
 N>1 (BASELINE configs[3]): the north star's pattern only -- the batch row-sharded over the ranks, tables replicated, ONE
-all-reduce per step -- in both of its forms (`stats`: the gradient's sufficient statistics, compacted to the entities
-some rank's shard contains; `grads`: the flat gradient buffer), each timed, the faster one is the headline
-(`candidates` lists both).  Headline regime: STRONG (SURVEY cfg4: the 100,000-row batch split by rows); the same mode in
+all-reduce per step -- in its three forms (`stats`: the gradient's sufficient statistics, compacted to the entities
+some rank's shard contains; `grads`: the flat gradient buffer; `rows`: every row's dloss/dpred), each timed, the fastest one
+is the headline (`candidates` lists all, each with the rows its forward / backward handle per rank and the table rows it
+updates per rank).  Headline regime: STRONG (SURVEY cfg4: the 100,000-row batch split by rows); the same mode in
 the WEAK regime (100,000 rows per rank) under the key `weak`.  Every candidate is probed first and dropped if it projects
-past --mode-budget-s; a watchdog ends a run that hangs in a collective after --wall-limit-s.
+past --mode-budget-s or past what is left of --total-budget-s; a watchdog ends a run that hangs in a collective after
+--wall-limit-s (480 s: below the 600 s the round-end driver gives a run).
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel that takes the most time per step (its `elbo_fwd_kernel`
 entry is the fused forward ELBO kernel; `frac_fwd_8d` / `frac_K_8d` are SURVEY 8(d)'s own figures against the 0.60
-target); `kernels` lists all of them (HIP events on every 5th step of the timed region); `sustained` / `replayed` = 2,000
-more steps eagerly / as replayed HIP graphs.  `cpu_baseline` = the reference-shaped torch-CPU restatement
+target); `kernels` lists all of them (HIP events on every 5th step of the timed region); `sustained` = 2,000
+more steps without events; `streamed` = the regime of a caller that cannot keep plans (streamed / shuffled batches): every
+step's plan -- inverted index, normalisers, look-ahead row list: what replaces the reference's torch.unique x3,
+vfm-torch.py:190-192 -- is built INSIDE the timed region, two steps ahead on a side stream (`--plans stream` makes that the
+headline region).  `cpu_baseline` = the reference-shaped torch-CPU restatement
 (oracle/vfm_oracle.py, pinned to the reference by tests/golden; the reference's two unused per-row lookups included)
 timed on this node's host cores.
 """
@@ -40,12 +45,6 @@ WORKLOADS = {
     "ml20m_d128": ([138493, 26744], 128, 100000, 16000210, "reg"),
     "ml100k_d20": ([943, 1682], 20, 80000, 80000, "reg"),
     "criteo_d256": ([31250] * 32, 256, 2048, 1 << 22, "class"),
-    # per-rank shapes of the embedding-dimension-sharded mode at cfg3 (d/N coordinates, N*B rows)
-    "ml20m_d64": ([138493, 26744], 64, 200000, 16000210, "reg"),
-    "ml20m_d32": ([138493, 26744], 32, 400000, 16000210, "reg"),
-    "ml20m_d16": ([138493, 26744], 16, 800000, 16000210, "reg"),
-    # ... and at cfg5 with N = 8: 16,384 rows of 32 fields, 32 of 256 coordinates
-    "criteo_d32": ([31250] * 32, 32, 16384, 1 << 22, "class"),
 }
 
 
@@ -61,12 +60,17 @@ def main():
     ap.add_argument("--no-sort", action="store_true",
                     help="keep the generated row order (default: rows of each batch ordered by item id, "
                          "as VFM.fit(sort_within_batch=True) does; loss and gradients are invariant)")
-    ap.add_argument("--exchange", default="north-star", choices=["north-star", "stats", "grads", "rows", "sharded", "dims", "auto"],
+    ap.add_argument("--exchange", default="north-star", choices=["north-star", "stats", "grads", "rows"],
                     help="N>1, what the ranks exchange per step (DESIGN.md section 6).  north-star (default): the row-sharded "
                          "batch with ONE all-reduce per step, in its three forms -- `stats` (sufficient statistics of the "
                          "gradient), `grads` (the literal gradient) and `rows` (every row's dloss/dpred; two fields) -- each "
-                         "timed, the fastest one is the headline.  auto: "
-                         "also the opt-in sharded / dims modes (never the default: different parallelism).")
+                         "timed, the fastest one is the headline.")
+    ap.add_argument("--plans", default="resident", choices=["resident", "stream"],
+                    help="N=1.  resident (default): plans are built once per batch before the timed region and reused (the "
+                         "reference's loader does not shuffle, vfm-torch.py:121-122); stream: the timed region builds every plan "
+                         "it uses, two steps ahead on a side stream -- the regime of a caller that streams or shuffles batches. "
+                         "Whatever this says, the line carries both figures (`ms_per_step` / `streamed`).")
+    ap.add_argument("--streamed-steps", type=int, default=400, help="steps of the extra `streamed` region (0: none)")
     ap.add_argument("--scaling", default="both", choices=["both", "strong", "weak"],
                     help="N>1: strong = the workload's global batch split by rows over the ranks (SURVEY cfg4; the headline), "
                          "weak = that many rows PER rank; both = the two in one run (weak under the key `weak`)")
@@ -74,9 +78,12 @@ def main():
     ap.add_argument("--mode-budget-s", type=float, default=90.0,
                     help="N>1: a candidate whose 3-step probe projects more than this many seconds for warm-up + timed steps "
                          "is skipped (recorded, never retried)")
-    ap.add_argument("--wall-limit-s", type=float, default=1500.0,
+    ap.add_argument("--wall-limit-s", type=float, default=480.0,
                     help="watchdog: if the whole run is still going after this many seconds (a hung collective), every rank "
-                         "prints what it was doing and exits with code 3")
+                         "prints what it was doing and exits with code 3 (the round-end driver gives a run 600 s)")
+    ap.add_argument("--total-budget-s", type=float, default=300.0,
+                    help="N>1: what init + all candidates + both regimes may take; a candidate whose probe projects past what "
+                         "is left of it is skipped")
     ap.add_argument("--dim", type=int, default=0, help="embedding size instead of the workload's (shape sweeps)")
     ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the item popularity (0 = uniform ids)")
     ap.add_argument("--user-order", action="store_true",
@@ -101,11 +108,6 @@ def main():
                     help="look-ahead lazy exact Adam: the fused step skips the rows that are neither in this batch nor in "
                          "the next (bitwise the dense trajectory); scan = the kernel classifies all table rows itself instead "
                          "of walking the pair's row list; off = every row every step")
-    ap.add_argument("--replay", default="off", choices=["on", "off"],
-                    help="N=1: run the TIMED steps as replayed HIP graphs (one per (batch, next batch) pair, step constants in "
-                         "device memory; bitwise the eager trajectory).  No events can be recorded inside a replayed step, so "
-                         "the per-kernel durations then come from an eager pass right after the timed region.  Whatever this "
-                         "says, the line carries `sustained` (eager) and `replayed` (graphs) figures over >= 2000 steps.")
     ap.add_argument("--sustained-steps", type=int, default=2000)
     ap.add_argument("--settle-steps", type=int, default=300,
                     help="untimed training steps before the warm-up of a commanded region (0: none); the same region "
@@ -179,7 +181,13 @@ def main():
         doing[0] = "comm_check all_reduce"
         one = torch.ones(1, device=dev)
         dist.all_reduce(one, group=pg)
-        comm_check = {"backend": backend, "world_size": dist.get_world_size(pg), "allreduce_of_ones": float(one.item())}
+        try:        # what the collective library says about itself (RCCL reports through torch's nccl binding)
+            lib_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception as exc:
+            lib_version = "unavailable: %s" % type(exc).__name__
+        comm_check = {"backend": backend, "library": "RCCL (torch.distributed backend 'nccl' on ROCm)" if backend == "nccl" else backend,
+                      "library_version": lib_version, "world_size": dist.get_world_size(pg),
+                      "allreduce_of_ones": float(one.item()), "device_of_rank0": torch.cuda.get_device_name(dev)}
         assert comm_check["world_size"] == world and comm_check["allreduce_of_ones"] == float(world), comm_check
 
     from vae_amd.model import VFM
@@ -201,7 +209,6 @@ def main():
     model.lookahead = args.lookahead != "off"
     model.lookahead_list = args.lookahead == "on"
     model.use_wrec = not args.no_wrec
-    model.replay = False
     eps_tables = None
     if args.fwd_eps == "table":
         from vae_amd import ops as _ops
@@ -250,19 +257,6 @@ def main():
             model.set_training_data(self.X, nb_train=nb_train, nb_occ=self.occ)
             model.lr = self.lr
 
-        def global_rows(self):
-            # dimension-sharded mode: every rank holds ALL rows of the global batch (the ranks' row blocks side by side)
-            if self.Xg is None:
-                B = self.B
-                blocks = [synthetic_triples(sizes, nbt * B, seed=1000 + r, output=output, device=dev,
-                                            zipf=args.zipf if args.zipf > 0 else None) for r in range(world)]
-                Xg = torch.stack([b[0] for b in blocks], 1).reshape(nbt, B, world, F).transpose(1, 2).reshape(-1, F)
-                yg = torch.stack([b[1] for b in blocks], 1).reshape(nbt, B, world).transpose(1, 2).reshape(-1)
-                if args.id32:
-                    Xg = Xg.to(torch.int32)
-                self.Xg, self.yg = Xg.contiguous(), yg.contiguous()
-            return self.Xg, self.yg
-
         def build_plans(self, mode):
             """The per-batch work OUTSIDE the timed step: batch normalisers W (k_norms), the inverted index
             (vfm_build_index: radix sort) and its one readback.  The reference pays torch.unique x3 inside every
@@ -273,11 +267,8 @@ def main():
                 return self.plans[key]
             B = self.B
             ps, batches = [], []
-            dims = multi and mode == "dims"
-            Bp = B * world if dims else B
-            Xs, ys = self.global_rows() if dims else (self.X, self.y)
             for i in range(nbt):
-                xb, yb = Xs[i * Bp:(i + 1) * Bp], ys[i * Bp:(i + 1) * Bp]
+                xb, yb = self.X[i * B:(i + 1) * B], self.y[i * B:(i + 1) * B]
                 if not args.no_sort:
                     o = torch.argsort(xb[:, -1], stable=True)
                     xb, yb = xb[o].contiguous(), yb[o].contiguous()
@@ -307,13 +298,29 @@ def main():
                 torch.cuda.synchronize()
                 self.plan_build_warm[key] = (time.perf_counter() - t0) / nbt * 1e3
                 del again
+            self.batches = batches
             self.plans[key] = (ps, [p.U for p in ps])
             return self.plans[key]
 
     step_no = [0]                     # batches are cycled through in order across warm-up and timed regions
 
-    def run(plans, n, events, replay=False):
-        model.replay = bool(replay)
+    def run_streamed(setup, n):
+        """n steps of a caller that keeps NO plan: the plan of batch t+2 (index, normalisers, the look-ahead row list of the
+        pair (t+1, t+2)) is built on the side stream while step t runs -- everything that replaces the reference's
+        torch.unique x3 (vfm-torch.py:190-192) is inside the loop."""
+        bt = setup.batches
+        t0 = step_no[0]
+        cur = model.plan(*bt[t0 % nbt], defer_readback=True)
+        nxt = model.plan_async(*bt[(t0 + 1) % nbt], pair_with=cur)
+        for _ in range(n):
+            s = step_no[0]
+            step_no[0] += 1
+            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 2) % nbt])
+            cur, nxt = nxt, model.prefetched
+
+    def run(plans, n, events, streamed=None):
+        if streamed is not None:
+            return run_streamed(streamed, n)
         for _ in range(n):
             s = step_no[0]
             step_no[0] += 1
@@ -330,9 +337,8 @@ def main():
                              next_plan=plans[(s + 1) % nbt] if (not multi or model.exchange == "rows") else None)
             if args.sync_each_step:
                 torch.cuda.synchronize()
-        model.replay = False
 
-    def measure(setup, mode, steps, warmup, with_events, replay=False, probe=False, settle=0):
+    def measure(setup, mode, steps, warmup, with_events, streamed=False, probe=False, settle=0):
         """warm-up, then `steps` timed steps bracketed by barrier + synchronize on both sides, MAX over ranks.  With
         `probe`, three steps are timed first and the candidate is dropped if it projects past --mode-budget-s."""
         doing[0] = f"measure {mode} B={setup.B}"
@@ -345,10 +351,12 @@ def main():
             run(plans, 3, None)
             barrier()
             per = max_over_ranks(time.perf_counter() - t0) / 3
-            if per * (steps + warmup) > args.mode_budget_s:
-                return {"skipped": f"probe: {per * 1e3:.2f} ms per step projects past --mode-budget-s {args.mode_budget_s}"}
-        if replay:
-            warmup = max(warmup, 2 * nbt + 2)      # every (batch, next batch) pair seen twice: first eagerly, then captured
+            left = max_over_ranks(args.total_budget_s - (time.perf_counter() - t_begin))     # (every rank takes the same decision)
+            need = per * (steps + warmup + (settle if settle else 0) + 2 * min(steps, 20))
+            if need > args.mode_budget_s or need > left:
+                return {"skipped": f"probe: {per * 1e3:.2f} ms per step projects {need:.1f} s: past --mode-budget-s "
+                                   f"{args.mode_budget_s} or the {left:.1f} s left of --total-budget-s {args.total_budget_s}"}
+        stm = setup if streamed else None          # (run(): the streamed loop when a Setup is given)
         cold = None
         if settle > 0:
             # The chip needs 10-50 ms of THIS work after an idle stretch before the backward kernel reaches its steady
@@ -357,25 +365,25 @@ def main():
             # so it is preceded by untimed settling steps -- real training steps, like the warm-up's -- and the same
             # region WITHOUT them is timed first and reported beside the headline as `settle.cold_ms_per_step`.
             kc = min(steps, 20)
-            run(plans, warmup, None, replay)
+            run(plans, warmup, None, stm)
             barrier()
             t0 = time.perf_counter()
-            run(plans, kc, None, replay)
+            run(plans, kc, None, stm)
             barrier()
             cold = {"steps": kc, "ms_per_step": max_over_ranks(time.perf_counter() - t0) / kc * 1e3}
             done, t0 = 0, time.perf_counter()
             while done < settle:
-                run(plans, 50, None, replay)
+                run(plans, 50, None, stm)
                 done += 50
                 torch.cuda.synchronize()
                 if max_over_ranks(time.perf_counter() - t0) >= args.settle_max_s:     # (every rank takes the same decision)
                     break
             cold["settle_steps"] = done
-        run(plans, warmup, None, replay)
+        run(plans, warmup, None, stm)
         barrier()
         events = [] if with_events else None
         t0 = time.perf_counter()
-        run(plans, steps, events, replay)
+        run(plans, steps, events, stm)
         t_host = time.perf_counter() - t0          # host time to enqueue all steps (before the sync)
         lazy_kind = model._lazy_kind               # which lazy exact form the timed steps ran in (None: every row every step)
         model.sync_lazy()                          # rows still lagging get their skipped updates INSIDE the timed region
@@ -396,15 +404,11 @@ def main():
     else:
         regimes = [(r, (B_global + world - 1) // world if r == "strong" else B_global)
                    for r in (("strong", "weak") if args.scaling == "both" else (args.scaling,))]
-        if args.exchange in ("north-star", "auto"):
+        if args.exchange == "north-star":
             cands = ["stats", "grads"]
             from vae_amd.dist import rows_supported
             if rows_supported(model.spec()):
                 cands.append("rows")
-            if args.exchange == "auto":       # opt-in: other parallelism than the north star's (never the default)
-                from vae_amd.dims import supported as dims_supported
-                table_bytes = 4 * model.T * (4 + (d + 3) // 4 * 4)
-                cands += (["sharded"] if table_bytes >= (4 << 20) else []) + (["dims"] if dims_supported(d, world) else [])
         else:
             cands = [args.exchange]
     init = model._flat.clone()
@@ -412,12 +416,9 @@ def main():
 
     def reset_state():
         model.sync_lazy()
-        if multi and getattr(model, "_stale_group", None) is not None:
-            model.sync_params(pg)
         model._flat.copy_(init)
         model._adam_m.zero_(); model._adam_v.zero_()
-        model._adam_t, model.global_step, model._stale_group, model._moments_scaled = 0, 0, None, False
-        model._dims = model._stale_kind = None
+        model._adam_t, model.global_step, model._moments_scaled = 0, 0, False
         model.params_changed()
 
     # the box's streaming rate (device-to-device copies of 1 GiB) -- measured before the timed regions, it touches
@@ -433,8 +434,9 @@ def main():
         for mode in use:
             reset_state()
             try:
-                m = measure(setup, mode, args.steps, args.warmup, with_events=not args.no_events and not (not multi and args.replay == "on"),
-                            replay=not multi and args.replay == "on", probe=multi, settle=args.settle_steps)
+                stream_head = not multi and args.plans == "stream"
+                m = measure(setup, mode, args.steps, args.warmup, with_events=not args.no_events and not stream_head,
+                            streamed=stream_head, probe=multi, settle=args.settle_steps)
             except Exception as exc:      # communication-pattern fallback only (never a compute fallback)
                 if len(use) == 1:
                     raise
@@ -451,27 +453,42 @@ def main():
     setup, B, U, dt, plans = head["setup"], head["B"], head["U"], head["dt"], head["plans"]
     events, lazy_kind, t_host = head["events"], head["lazy_kind"], head["t_host"]
     loss = float(model._gflat[model._n_flat].item())
-    if multi and model.exchange in ("sharded", "dims"):
-        model.sync_params(pg)
     nan_params = int(torch.isnan(model._flat).sum().item())
 
-    # ---- N = 1: figures over a long region next to the commanded one: `sustained` = the same eager steps without
-    # events, `replayed` = the same steps as replayed HIP graphs (what VFM.fit runs)
-    sustained = replayed = None
+    # ---- N = 1: figures next to the commanded region: `sustained` = the same steps over a long region without events;
+    # `streamed` = the regime in which no plan is kept (every step's plan built inside the timed region, two steps ahead on a
+    # side stream) -- with the GPU time of one plan build, measured alone, beside it
+    sustained = streamed = None
     if not multi and args.sustained_steps > 0:
         setup.activate()
-        for name, rp in (("sustained", False), ("replayed", True)):
-            m = measure(setup, "single", args.sustained_steps, nbt + 4 if rp else 4, with_events=False, replay=rp)
-            rec = {"steps": args.sustained_steps, "ms_per_step": round(m["dt"] / args.sustained_steps * 1e3, 4),
-                   "triples_per_s": round(args.sustained_steps * B / m["dt"], 1),
-                   "host_enqueue_ms_per_step": round(m["t_host"] / args.sustained_steps * 1e3, 4)}
-            if rp:
-                replayed = rec
-                replayed["graphs"] = sum(1 for v in model._graphs.values() if v is not None)
-            else:
-                sustained = rec
+        m = measure(setup, "single", args.sustained_steps, 4, with_events=False)
+        sustained = {"steps": args.sustained_steps, "ms_per_step": round(m["dt"] / args.sustained_steps * 1e3, 4),
+                     "triples_per_s": round(args.sustained_steps * B / m["dt"], 1),
+                     "host_enqueue_ms_per_step": round(m["t_host"] / args.sustained_steps * 1e3, 4)}
+    if not multi and args.streamed_steps > 0 and not args.unfused and eps_tables is None:
+        setup.activate()
+        m = measure(setup, "single", args.streamed_steps, nbt + 4, with_events=False, streamed=True)
+        # GPU time of ONE plan build (index + normalisers + the pair's row list), alone on the chip: HIP events around builds
+        # enqueued back to back on the current stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prev = model.plan(*setup.batches[0], defer_readback=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i_ in range(1, nbt + 1):
+            q_ = model.plan(*setup.batches[i_ % nbt], defer_readback=True)
+            if model.lookahead and model.lookahead_list:
+                prev.prepare_lookahead(q_)
+            prev = q_
+        e1.record()
+        torch.cuda.synchronize()
+        streamed = {"steps": args.streamed_steps, "ms_per_step": round(m["dt"] / args.streamed_steps * 1e3, 4),
+                    "triples_per_s": round(args.streamed_steps * B / m["dt"], 1),
+                    "host_enqueue_ms_per_step": round(m["t_host"] / args.streamed_steps * 1e3, 4),
+                    "plan_build_gpu_us_alone": round(e0.elapsed_time(e1) / nbt * 1e3, 2),
+                    "note": "every step builds the plan of the batch two steps ahead (inverted index, batch normalisers, look-ahead "
+                            "row list) on a side stream inside the timed region; nothing of a plan is reused"}
     if not multi and events is None and not args.no_events:
-        # (--replay on: nothing can be recorded inside a replayed step) per-kernel durations from an eager pass
+        # (--plans stream: the headline region carries no per-kernel events) per-kernel durations from a resident-plans pass
         m = measure(setup, "single", min(100, args.steps), 4, with_events=True)
         events, lazy_kind = m["events"], m["lazy_kind"]
 
@@ -532,11 +549,22 @@ def main():
 
     if rank == 0:
         def line_of(m, reg):
+            # what ONE rank's kernels handle per step in this form: a `rows` headline must not read as a data-parallel backward
+            rows_b = m["B"] * world if m["mode"] == "rows" else m["B"]
             return {"scaling": reg, "exchange": m["mode"] if multi else None, "batch_per_gpu": m["B"],
                     "global_batch": m["B"] * world, "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 4),
                     "value": round(m["steps"] * m["B"] * world / m["dt"], 1),
                     "host_enqueue_ms_per_step": round(m["t_host"] / m["steps"] * 1e3, 4),
-                    "allreduce_bytes_per_step": m.get("exchange_bytes")}
+                    "allreduce_bytes_per_step": m.get("exchange_bytes"),
+                    "rows_forward_per_rank": m["B"], "rows_backward_per_rank": rows_b,
+                    "table_rows_updated_per_rank": model.T,
+                    "per_rank_work": PARALLELISM[m["mode"] if multi else "single"]}
+        PARALLELISM = {
+            "single": "one rank: the whole batch",
+            "stats": "forward + statistics backward row-sharded (B/N rows per rank); Adam replicated (every rank updates all table rows)",
+            "grads": "forward + gradient backward row-sharded (B/N rows per rank); Adam replicated (every rank updates all table rows)",
+            "rows": "forward row-sharded (B/N rows per rank); backward + Adam REPLICATED (every rank walks all B rows of the global "
+                    "batch and updates all table rows)"}
         head_reg = regimes[0][0]
         cand_lines = {reg: {k: (line_of(v, reg) if "dt" in v else {"skipped": v["skipped"]}) for k, v in rs.items()}
                       for reg, rs in results.items()}
@@ -561,24 +589,24 @@ def main():
                        "lazy_exact_adam": {"list": "rows of the batch only + replay pass", "la": "look-ahead (this batch + next batch)",
                                            None: False}[lazy_kind],
                        "pipelined_step": piped, "packed_first_order_records": bool(model.use_wrec and not multi and not args.unfused),
-                       "timed_steps_replayed_as_graphs": bool(not multi and args.replay == "on"),
+                       "plans": ("built inside the timed region, two steps ahead on a side stream" if (not multi and args.plans == "stream")
+                                 else "resident: built once per batch before the timed region, reused every epoch (vfm-torch.py:121-122: no shuffling)"),
                        "exchange": model.exchange if multi else None, "exchange_note": exchange_note,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",
                                  "grads": "fwd+loss+bwd+allreduce(grads)+dense-adam",
                                  "rows": "sample(records of all the batch's entities)+fwd(own rows)+allreduce(row gradients: B_global+8 doubles)"
-                                         "+fused(loss+bwd+dense-adam) over the whole batch on every rank",
-                                 "sharded": "sample+all-to-all+fwd+bwd_acc+all-to-all+apply_adam(owned rows)",
-                                 "dims": "fwd(d/N coordinates, all rows)+allreduce(B+1 floats)+lik+fused(bwd+dense-adam) "
-                                         "on d/N coordinates"}[model.exchange]
+                                         "+fused(loss+bwd+dense-adam) over the whole batch on every rank"}[model.exchange]
                                 if multi else "fwd+loss+bwd+dense-adam") if
                                (multi or args.unfused) else ("fwd(records)+loss+fused(bwd+dense-adam+next batch's sampling)" if
                                                                  piped else "fwd+loss+fused(bwd+dense-adam)"),
-                       "parallelism": (f"embedding-dimension-sharded x{world} (every rank: all {B * world} rows, "
-                                       f"{d // world} of {d} coordinates)") if (multi and model.exchange == "dims")
-                       else (f"entity-sharded tables x{world} + row-sharded batch" if (multi and model.exchange == "sharded")
-                             else f"row-sharded dp{world}: {B} of {B * world} rows per rank, tables replicated, one all-reduce per step")},
+                       "parallelism": (f"x{world}, tables replicated, one all-reduce per step: forward row-sharded ({B} of {B * world} rows per "
+                                       f"rank); backward + Adam replicated (all {B * world} rows and all table rows on every rank)")
+                       if (multi and model.exchange == "rows") else
+                       f"row-sharded dp{world}: {B} of {B * world} rows per rank in forward and backward, tables replicated (Adam over all "
+                       f"table rows on every rank), one all-reduce per step"},
             "roofline": roof, "kernels": kern, "kernel_events_on_every_nth_step": max(1, args.event_every), "regions": regions,
-            "sustained": sustained, "replayed": replayed,
+            "sustained": sustained, "streamed": streamed,
+            "ms_per_step_streamed": streamed["ms_per_step"] if streamed else None,
             "settle": None if not head.get("cold") else {
                 "untimed_steps_before_warmup": head["cold"]["settle_steps"],
                 "cold_ms_per_step": round(head["cold"]["ms_per_step"], 4), "cold_steps": head["cold"]["steps"],
@@ -613,11 +641,7 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
         n_params = model._n_flat
         # ALGORITHMIC bytes per launch (fp32 params, ids as given, eps in-kernel):
         idb = 4 if args.id32 else 8
-        dims_mode = world > 1 and model.exchange == "dims"
-        if dims_mode:         # per rank: all B*world rows, d / world coordinates
-            d_k, B_k, n_params = d // world, B * world, model._dims.n_flat
-        else:
-            d_k, B_k = d, B
+        d_k, B_k = d, B
         rows_mode = world > 1 and model.exchange == "rows"
         if rows_mode:         # per rank: own rows in the forward, ALL rows (and their entities: U_all) in the sampling pass and the backward
             U_all = sum(p_.__dict__["_gplan"][1].U for p_ in getattr(args, "_plans", []) if "_gplan" in p_.__dict__) / max(1, len(getattr(args, "_plans", []))) or U
@@ -643,15 +667,11 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                            (8.0 * (model.T - U) * (2 * d_k + 2) if (model.scaled_moments and not model.sparse_adam) else 0.0)
                            # pipelined: + the next batch's records written, the other entities' records read once
                            + (2.0 * U * (4 * d_k + 16) if piped else 0.0)),
-               # dimension-sharded mode: the step's only exchange, and the per-row likelihood kernel after it
-               "allreduce_row_values": 4.0 * (B_k + 4096), "lik": 16.0 * B_k,
                # staged multi-rank form: statistics [T,d+2] written / all-reduced / read + Adam state
                "bwd_acc": B * F * (4 * d + 8) + 4.0 * model.T * (d + 2),
                # all-reduce of the statistics overlapped with the epilogue + dense Adam kernels
                "exchange_apply_adam": 4.0 * model.T * (d + 2) + 24.0 * n_params,
-               # entity-sharded form (per rank): records of the touched entities travel twice
-               "sample_a2a": U * (8 * d + 8) + 2 * 4.0 * U * (d + 4), "acc_a2a": B * F * (4 * d + 8) + 2 * 4.0 * U * (d + 4),
-               "apply_adam": 24.0 * n_params / max(world, 1) + 4.0 * U * (d + 4)}
+               }
         alg["allreduce"] = 4.0 * n_params
         if rows_mode:
             Bg = args._plans[0].B_global
@@ -661,7 +681,7 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
             alg["bwd_adam"] = (Bg * (idb * F + 8) + U_all * 16 + 24.0 * n_params
                                - (8.0 * (model.T - U_all) * (2 * d + 2) if model.scaled_moments else 0.0) + U_all * (4 * d + 16))
         forced = os.environ.get("VFM_FWD_KERNEL", "0")        # (use_fwd2 in csrc/vfm_abi.hip: k_fwd2 from d = 20 on)
-        fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and not dims_mode and \
+        fwd2 = F == 2 and d % 4 == 0 and d <= 512 and model.n_samples == 1 and model.link == "abs" and \
             forced != "1" and (d >= 20 or forced == "2")
         names = {"fwd": ("k_fwd2<ZREC> (pipelined step: gather of this step's sample records -> FM -> ELBO; the records were "
                          "written by the previous step's fused backward)") if piped else
@@ -675,14 +695,9 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
                  "catchup": "k_adam_catchup (lazy exact dense Adam: replay of the skipped zero-gradient updates on the batch's rows)",
                  "finalize": "k_finalize", "allreduce": "RCCL all-reduce of the flat exchange buffer",
                  "exchange": "RCCL all-reduce of every row's dloss/dpred + the six ELBO sums (B_global + 8 doubles), with its packing",
-                 "allreduce_row_values": "RCCL all-reduce of the B row values + 4096 KL shares (the dimension-sharded step's exchange)",
-                 "lik": "k_lik (likelihood terms + dloss/dpred of all rows)",
                  "bwd_acc": "k_bwd<ACC> (gradient statistics of the shard)",
                  "exchange_apply_adam": "RCCL all-reduce of the statistics, chunk-overlapped with "
-                                        "k_bwd<APPLY,ADAM> (epilogue + dense Adam)",
-                 "sample_a2a": "k_sample (owners) + all-to-all of (w | z) records",
-                 "acc_a2a": "k_bwd<ACC> over slots + all-to-all of statistics records",
-                 "apply_adam": "k_records_add + k_bwd<APPLY,ADAM> on owned rows + scalar all-reduce"}
+                                        "k_bwd<APPLY,ADAM> (epilogue + dense Adam)"}
         if rows_mode:
             names["fwd"] = "k_fwd2<ZREC> (the rank's own rows: gather of the sample records -> FM -> ELBO)"
             names["sample_rec"] = "k_sample_rec (records of ALL entities of the global batch, from this rank's replica of the tables)"

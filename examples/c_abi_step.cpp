@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -83,7 +84,8 @@ int main(int argc, char** argv) {
   auto bias = read_file<float>(dir + "/bias.f32", (size_t)(T * 2));
   auto scal = read_file<float>(dir + "/scalars.f32", 3);
 
-  vfm_problem_t p{};
+  vfm_problem_t p;
+  VFM_STRUCT_INIT(p);                                 // zeroes it, sets (struct_size, abi_version): checked by every entry point
   p.B = B; p.B_global = B; p.T = T; p.nb_train = nb_train; p.F = (int32_t)F; p.d = (int32_t)d;
   p.likelihood = (int32_t)likelihood; p.id_bits = 64; p.n_samples = 1; p.flags = VFM_FLAG_SCALED_MOMENTS;
   p.group_hi[0] = N + 1; p.group_hi[1] = T;          // the `<= N` test of vfm-torch.py:316
@@ -102,7 +104,7 @@ int main(int argc, char** argv) {
   int32_t* d_rows = device_zeros<int32_t>((size_t)(B * F));
   int32_t* d_hid = device_zeros<int32_t>((size_t)cap_h);
   int32_t* d_items = device_zeros<int32_t>((size_t)(4 * cap_i));
-  int32_t* d_counts = device_zeros<int32_t>(4);
+  int32_t* d_counts = device_zeros<int32_t>(8);
   char* d_ws = device_zeros<char>((size_t)vfm_index_workspace_bytes(B, (int32_t)F, T));
   float* d_inv = device_zeros<float>((size_t)T);
   double* d_W = device_zeros<double>((size_t)F);
@@ -118,16 +120,20 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamCreate(&st));
 
   VFM_OK(vfm_inv_occ_f32(d_occ, d_inv, T, st));                       // once per training set
-  VFM_OK(vfm_batch_norms(&p, d_x, d_inv, d_W, st));                   // once per batch
-  VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, nullptr, d_counts, st));
-  int32_t counts[4];
+  // once per batch: the index AND the batch normalisers W (vfm-torch.py:305-306), in the same launches
+  VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, nullptr,
+                         d_inv, d_W, d_counts, st));
+  int32_t counts[8];
   HIP_OK(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
   if (counts[0] != 0) { fprintf(stderr, "%d ids out of range\n", counts[0]); return 1; }
-  vfm_index_t idx{};
+  vfm_index_t idx;
+  VFM_STRUCT_INIT(idx);
   idx.occ_ptr = d_ptr; idx.occ_rows = d_rows;
+  idx.status = d_counts + 5;                                          // the kernels count clamped index entries here (zeroed by the build)
   if (counts[1] > 0) {                                                // lists longer than L: work items + scratch records
     idx.heavy_ids = d_hid; idx.heavy_items = d_items; idx.n_heavy = counts[1]; idx.n_items = counts[2];
+    idx.max_items = counts[4];
     idx.heavy_acc = device_zeros<float>((size_t)(counts[1] + counts[2]) * (size_t)(4 + (d + 3) / 4 * 4));
   }
   for (int s = 0; s < n_steps; ++s) {
@@ -139,6 +145,8 @@ int main(int argc, char** argv) {
                                  (int64_t)s + 1, d_loss + 3 * s, st));
   }
   HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipMemcpy(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost));
+  if (counts[5] != 0) { fprintf(stderr, "corrupted inverted index: %d entries clamped (vfm_index_t.status)\n", counts[5]); return 1; }
   std::vector<float> losses((size_t)(3 * n_steps));
   HIP_OK(hipMemcpy(losses.data(), d_loss, losses.size() * sizeof(float), hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(ent.data(), d_ent, ent.size() * sizeof(float), hipMemcpyDeviceToHost));

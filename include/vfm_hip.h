@@ -38,8 +38,15 @@
 extern "C" {
 #endif
 
-#define VFM_ABI_VERSION 4
+/* ABI version 5.  Every struct that crosses the boundary by pointer (vfm_problem_t, vfm_index_t, vfm_pipe_t) starts with
+ * (struct_size, abi_version): the caller sets them to sizeof(the struct it was COMPILED against) and VFM_ABI_VERSION
+ * (VFM_STRUCT_INIT does both after zeroing the struct), and every entry point that takes the struct returns VFM_E_INVALID
+ * when they differ from the library's own -- a binding built against another layout is refused instead of being read past
+ * its end (version 4 grew vfm_index_t by a field without a version bump; a 72-byte caller struct was then over-read). */
+#define VFM_ABI_VERSION 5
 #define VFM_MAX_FIELDS 64
+#define VFM_STRUCT_INIT(s) do { memset(&(s), 0, sizeof(s)); (s).struct_size = (uint32_t)sizeof(s); \
+                                (s).abi_version = VFM_ABI_VERSION; } while (0)      /* (needs <string.h>) */
 
 #define VFM_E_INVALID (-1)   /* bad argument (shape, null pointer, unsupported size)   */
 #define VFM_E_UNSUPPORTED (-2)
@@ -64,37 +71,15 @@ extern "C" {
                                      rounding.  Every VFM_MOMENT_PERIOD-th step writes the plain moments for all
                                      rows.  vfm_moments_rescale_f32 converts a buffer between the two forms.   */
 #define VFM_MOMENT_PERIOD 128
-#define VFM_FLAG_ROWS_UNTOUCHED 64 /* vfm_elbo_bwd_adam_f32: handle ONLY the table rows the batch does not contain.
-                                     Their update is pure Adam decay (zero gradient) and depends on nothing the
-                                     step's forward produces, and the forward reads none of those rows, so the
-                                     caller may run this call CONCURRENTLY with vfm_elbo_fwd_f32 on another stream
-                                     (memory-bound work beside the arithmetic-bound forward).  sumz, grow, partials,
-                                     inv_occ, W, loss may be NULL.                                              */
-#define VFM_FLAG_ROWS_TOUCHED 128  /* ... and the complement: the rows of the batch, the three scalars, the loss.
-                                     The two calls together equal one call without either flag.                */
-#define VFM_FLAG_PARTIAL_PRED 256   /* vfm_elbo_fwd_f32 (training, n_samples == 1): stop before the likelihood --
-                                     pred[r] receives this call's share  sum_f w_f + 1/2 sum_k[..]  of the row
-                                     value over ITS coordinates only (no global bias); sumz and the KL slots are
-                                     written as usual, and `pred` must hold B + VFM_MAX_FWD_BLOCKS floats: the
-                                     tail receives the workgroups' shares of the KL term (zero beyond the grid;
-                                     NaN where an id was out of range).  The embedding-dimension-sharded multi-rank
-                                     mode sums pred over ranks and finishes with vfm_elbo_lik_f32.             */
-#define VFM_FLAG_NO_BIAS 512        /* this call leaves the first-order weights (bias_params) out: no sum_f w_f,
-                                     no KL of them, no gradient / Adam update for them (dimension-sharded mode:
-                                     rank 0 alone carries them; bias_params and its moments must still point to
-                                     [T,2] tables -- read, never written)                                       */
-#define VFM_FLAG_ZPRE 8           /* vfm_elbo_fwd_f32: `entity_params` holds PRECOMPUTED samples, one record
-                                     (w, 0, 0, 0 | z[0..d-1]) of 4 + round4(d) floats per slot, and x holds
-                                     slot numbers (entity-sharded mode: the owner of an entity samples it
-                                     once -- vfm_shard_sample_f32 -- and ships z instead of mu and s); no
-                                     KL term is formed (the owner adds it), bias_params / inv_occ / W may be
-                                     NULL, eps_global alone may be given                                    */
+#define VFM_FLAG_ROWS_TOUCHED 128  /* vfm_elbo_bwd_adam_f32: handle ONLY the table rows the batch contains (+ the three scalars,
+                                     the loss) -- with vfm_index_t.touched_ids as a list: the row-list step of the lazy exact
+                                     Adam (the other rows are replayed later by vfm_adam_catchup_f32)            */
 #define VFM_FLAG_ZREC 1024        /* vfm_elbo_fwd_f32 (two fields, one sample, d % 4 == 0, d <= 512, training): `entity_params`
                                      holds this step's SAMPLES, one record (w, weighted KL, 0, 0 | z[0..d-1]) of 4 + d
                                      floats per ENTITY ID (vfm_sample_records_f32 / vfm_elbo_bwd_adam_pipe_f32 write them);
                                      x holds entity ids as usual.  Nothing is sampled and no sumz is written (the
                                      pipelined backward gathers the samples themselves): bias_params, inv_occ, W, sumz
-                                     may be NULL.  Half the gather bytes of the (mu | s) rows, no RNG.             */
+                                     may be NULL.  Half the gather bytes of the (mu | s) rows, no RNG.  |.| link only. */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 #define VFM_FLAG_LINK_SOFTPLUS 16 /* LINK = softplus instead of |.| (vfm-torch.py:125-126; applies to alpha,
@@ -105,7 +90,10 @@ extern "C" {
 #define VFM_P_LL 0      /* sum_r log p(y_r | pred_r)                                    */
 #define VFM_P_KL 1      /* sum over occurrences of KL_e/occ(e) * n_g/W_g (kl_rescaled)  */
 #define VFM_P_G 2       /* sum_r dloss/dpred_r                                          */
-#define VFM_P_ALPHA 3   /* sum_r [(y-pred)^2/2 - 1/(2|alpha|)]                          */
+#define VFM_P_ALPHA 3   /* Normal likelihood.  In a workgroup SLOT: sum_r (y-pred)^2/2 of its rows -- positive terms only;
+                           slot entry [6] holds the number of terms.  After the reduction (partials[3]):
+                           sum_r (y-pred)^2/2 - n_terms/(2|alpha|), the difference formed ONCE, in fp64 -- the gradient of
+                           alpha is a cancelling sum and a per-row fp32 difference lost three digits of it */
 #define VFM_P_BADID 4   /* number of ids outside [0,T) met (they are clamped to 0)      */
 #define VFM_P_GE0 5     /* n_samples > 1: sum_s eps0^s * sum_r dloss/dpred[s,r]         */
 #define VFM_P_REDUCED 6 /* 1.0 once the slots were reduced into [0..5] (vfm_elbo_finalize_f32, or the fused
@@ -114,7 +102,9 @@ extern "C" {
 #define VFM_N_PARTIALS 8
 /* `partials` is a caller-owned fp64 workspace of VFM_PARTIALS_LEN entries: [0..7] the sums
  * above (valid after vfm_elbo_finalize_f32; [7] = number of forward blocks), followed by one
- * 8-entry slot per forward workgroup (written with plain stores: deterministic sums, no atomics) */
+ * 8-entry slot per forward workgroup (written with plain stores: deterministic sums, no atomics;
+ * slot entries [0..5] as VFM_P_*, [6] = VFM_SLOT_NTERMS: Normal-likelihood terms summed into the slot's [3]) */
+#define VFM_SLOT_NTERMS 6
 #define VFM_MAX_FWD_BLOCKS 4096
 #define VFM_PARTIALS_LEN (VFM_N_PARTIALS * (1 + VFM_MAX_FWD_BLOCKS))
 
@@ -158,6 +148,8 @@ int vfm_dev_step_set(vfm_dev_step_t* dev_step, uint64_t philox_step, int64_t ada
 
 /* Problem description shared by all kernels of one step (host memory). */
 typedef struct vfm_problem {
+  uint32_t struct_size;   /* sizeof(vfm_problem_t) of the caller's build; checked by every entry point (VFM_STRUCT_INIT) */
+  uint32_t abi_version;   /* VFM_ABI_VERSION of the caller's build                                                       */
   int64_t B;          /* rows handled by THIS call (this rank's shard of the batch)       */
   int64_t B_global;   /* rows of the whole batch over all ranks (loss uses nb_train/B_global) */
   int64_t T;          /* rows of the two tables (N + M in the reference)                 */
@@ -184,14 +176,6 @@ typedef struct vfm_problem {
    * multi-rank step cut the table in chunks and overlap the exchange of one chunk with the kernels
    * of its neighbours.  The forward ignores it. */
   int64_t e_lo, e_hi;
-  /* entity-sharded mode (tables partitioned over N ranks by e mod N): vfm_elbo_apply_adam_f32 then
-   * handles the owned entities e = own_rank + li * own_mod, li in [e_lo, e_hi) (LOCAL indices; the
-   * statistics records are indexed by li).  own_mod <= 1: not sharded. */
-  int32_t own_mod, own_rank;
-  /* embedding-dimension-sharded mode: the tables of this call hold the coordinates
-   * [coord_off, coord_off + d) of a wider model; only the Philox coordinate index is shifted by it
-   * (eps tables, if given, are local like the parameter tables).  Multiple of 8; 0 otherwise. */
-  int32_t coord_off, reserved0;
   /* optional device-side extensions (NULL = off) */
   vfm_dev_step_t* dev_step;   /* replayable step: see vfm_dev_step_t above.  Honoured by vfm_elbo_fwd_f32 (training, Philox
                                  eps), vfm_elbo_bwd_adam_f32, _lookahead_f32 and _pipe_f32; other entry points reject it.  */
@@ -224,6 +208,8 @@ int vfm_wrec_build_f32(const float* bias_params, const float* inv_occ, int64_t T
 #define VFM_HEAVY_MIN 8
 #define VFM_HEAVY_DIRECT 8      /* an entity of at most this many work items is summed by the main kernel itself */
 typedef struct vfm_index {
+  uint32_t struct_size;   /* sizeof(vfm_index_t) of the caller's build (VFM_STRUCT_INIT) */
+  uint32_t abi_version;
   const int32_t* occ_ptr;
   const int32_t* occ_rows;
   const int32_t* heavy_ids;
@@ -241,6 +227,11 @@ typedef struct vfm_index {
    * VFM_HEAVY_DIRECT the main kernel adds every entity's item records itself and the k_heavy_sum launch -- which would
    * find nothing to do -- is left out (ML-100K shape: one launch of three per backward). */
   int32_t max_items;
+  /* optional DEVICE word (e.g. vfm_build_index's counts[5]; zero it once): the kernels that walk the index BOUND what they
+   * read -- a list length outside [0, B*F], a row number outside [0, B) or an entity outside [0, T) is clamped -- and add 1
+   * here whenever a clamp fires, so a corrupted index shows up at the caller's next look at this word (vae_amd: end of every
+   * epoch, BatchPlan.check_status) as an error instead of a hang or a fault.  NULL: clamps still apply, nothing is reported. */
+  int32_t* status;
 } vfm_index_t;
 
 int vfm_abi_version(void);
@@ -260,9 +251,16 @@ const char* vfm_last_error(void);
  *             contains (the row list of the lazy Adam step, vfm_index_t.touched_ids)
  *   occ_other NULL, or (F == 2 only) [B*2] int32: for every entry of occ_rows the entity in the OTHER column of
  *             that row (vfm_index_t.occ_other: the software-pipelined step gathers that entity's sample)
- *   counts    [4] int32, DEVICE: (ids outside [0,T) met -- they are indexed as id 0, like the forward
- *             clamps them --, n_heavy, n_items, n_touched = entities in the batch): the caller reads them
- *             back once to fill vfm_index_t */
+ *   inv_occ, W  both NULL, or the [T] reciprocal occurrence counts and room for F doubles: the batch normalisers
+ *             W[f] = sum_r inv_occ[x[r,f]] (what vfm_batch_norms computes; vfm-torch.py:305-306) come out of the same
+ *             launches (the ids are read once).  Fixed summation order: bitwise reproducible.
+ *   counts    [8] int32, DEVICE: (ids outside [0,T) met -- they are indexed as id 0, like the forward
+ *             clamps them --, n_heavy, n_items, n_touched = entities in the batch, max_items = the most work items one
+ *             heavy entity has (vfm_index_t.max_items), 0 = a zeroed word for vfm_index_t.status, 0, 0): the caller reads
+ *             them back once to fill vfm_index_t
+ * Launches (B*F <= 2^31 keys, T < 2^32): one memset, key extraction (+ the first pass's digit counts, W), one stable scatter
+ * per ceil(log2 T / 9) radix passes (each also counts the next pass's digits and, once, the occurrences per entity), and two
+ * compaction launches -- six at the ML-20M shape (was sixteen). */
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
 /* The heavy lists of an index once more, with a LOWER threshold than their work-item length: entities with more than
  * `threshold` occurrences (VFM_HEAVY_MIN <= threshold <= heavy_list) become heavy, their lists still cut in items of up to
@@ -271,11 +269,11 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T);
  * for; pre-reduced, such a list is one work item with eight in flight (data-file order at the ML-20M shape: backward 103 ->
  * 94 us, step 0.130 -> 0.112 ms; with users spread over the table it costs 3 %, with 10^6 rows covering the table 10 %, so
  * the caller decides: vae_amd does it for plans with B >= 4 U and U <= T / 4 on tables of >= 8,192 rows).  occ_ptr: of the built index; ws: a workspace as for
- * vfm_build_index; counts [4]: (0, n_heavy, n_items, n_touched) again.  Capacities that always suffice:
+ * vfm_build_index; counts [8]: (0, n_heavy, n_items, n_touched, max_items, 0, 0, 0) again.  Capacities that always suffice:
  * cap_heavy = B*F / threshold + 1, cap_items = B*F / heavy_list + B*F / threshold + 2.
  * vfm_heavy_threshold(heavy_list) = the threshold vae_amd uses: heavy_list / 4, at least VFM_HEAVY_MIN. */
 int vfm_rebuild_heavy(int64_t T, const int32_t* occ_ptr, void* ws, int32_t heavy_list, int32_t threshold, int32_t* heavy_ids,
-                      int64_t cap_heavy, int32_t* heavy_items, int64_t cap_items, int32_t* counts, void* stream);
+                      int64_t cap_heavy, int32_t* heavy_items, int64_t cap_items, int32_t* counts /*[8]*/, void* stream);
 int32_t vfm_heavy_threshold(int32_t heavy_list);
 /* The heavy-list length to build an index with: VFM_HEAVY_LIST when the table has at least VFM_HEAVY_UNITS rows
  * (one lane group per row already fills the chip and only the really long lists need cutting), else about
@@ -285,8 +283,8 @@ int32_t vfm_heavy_threshold(int32_t heavy_list);
 int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T);
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other, int32_t* counts,
-                    void* stream);
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other,
+                    const float* inv_occ, double* W, int32_t* counts, void* stream);
 
 /* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
  * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */
@@ -337,9 +335,8 @@ int vfm_elbo_finalize_f32(const vfm_problem_t* p, double* partials, const float*
 /* Backward (replaces autograd through vfm-torch.py:189-324,359; :368-369).  Entity-centric:
  * one lane group per table row e sums grow[r] * sumz[r,:] over the rows that contain e
  * (inverted index `idx`), then writes the DENSE gradient row (zeros for rows not in the batch, like
- * the reference's dense nn.Embedding gradients).  No atomics and bitwise reproducible for a
- * fixed index, except for the few entities on the index's heavy list (float atomics in their
- * pre-reduction).  grad_out [1] = dL/dloss (device).  g_scalars [3] = grads of alpha,
+ * the reference's dense nn.Embedding gradients).  No atomics: bitwise reproducible for a
+ * fixed index, heavy lists included.  grad_out [1] = dL/dloss (device).  g_scalars [3] = grads of alpha,
  * global_bias_mean, global_bias_scale from the (rank-summed) partials. */
 int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                      const float* entity_params, const float* bias_params,
@@ -387,8 +384,7 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
-                            const int32_t* rec_pos, void* stream);
+                            float beta2, float eps_adam, int64_t step, void* stream);
 /* The apply stage over a LIST of rows -- the multi-rank step's lazy exact dense Adam (replaces, per rank of a
  * data-parallel run, `optimizer.step()` of vfm-torch.py:370 on the gradients of :368-369 summed over ranks; the
  * reference itself is single-process).  With the statistics exchange
@@ -411,31 +407,6 @@ int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const
                                  const float* inv_occ, const double* W, float* m_entity, float* v_entity, float* m_bias,
                                  float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1, float beta2,
                                  float eps_adam, int64_t step, void* stream);
-/* rec_ptr / rec_pos (both or neither; rec_pos may be NULL when no record exists at all): GATHER form for the entity-sharded mode -- `acc` is the raw
- * receive buffer of the statistics all-to-all and the records of local entity li are those at positions
- * rec_pos[rec_ptr[li] .. rec_ptr[li+1]) (one per rank that had the entity in its rows); the kernel sums
- * them itself, so no dense table, no vfm_records_add_f32 pass and no atomics are needed. */
-
-/* Entity-sharded multi-rank mode (tables partitioned by e mod N; every rank keeps rows of the batch).
- * Per step: (1) every owner samples the entities other ranks asked for -- vfm_shard_sample_f32 writes one
- * record (w, 0, 0, 0 | z) per requested id -- and the records travel in an all-to-all; (2) the forward
- * runs on slot numbers with VFM_FLAG_ZPRE; (3) vfm_elbo_bwd_acc_f32 over the slots gives the statistics
- * records, which travel back in a second all-to-all; (4) the owner adds the records of each source rank
- * into its dense table of local records with vfm_records_add_f32 and (5) calls
- * vfm_elbo_apply_adam_f32 with own_mod / own_rank set (kl_ws, 1 + 4096 doubles, receives in [0] the
- * owner's share of the KL term: sum of c_e * KL_e over its entities in the batch). */
-int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
-                         const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
-                         void* stream);
-/* atomic == 0: plain adds, idx must not repeat inside one call (one call per source rank: deterministic);
- * atomic != 0: float atomics, idx may repeat (all source ranks in one launch). */
-int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, int32_t atomic,
-                        void* stream);
-/* glue of the sharded step, one thread each: small[2..4] <- (loss_local[1], loss_local[2], kl_ws[0]) before
- * the 8-float all-reduce; loss3 <- (nll + kl, nll, kl) from the summed vector after it. */
-int vfm_shard_pack_f32(float* small, const float* loss_local, const double* kl_ws, void* stream);
-int vfm_shard_loss_f32(const float* small, float* loss3, void* stream);
-
 /* Dense Adam step, torch.optim.Adam defaults and single-tensor op order (vfm-torch.py:339,370:
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).  `step` is the 1-based count of
  * this update (bias corrections are formed on the host in fp64).  In place on p, m, v; all four
@@ -464,6 +435,8 @@ int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
  * kernel) -- with idx->touched_ids, if given, as the list of rows to visit.  The rows of the next batch are then current
  * when their records are written, which is all the next forward reads. */
 typedef struct vfm_pipe {
+  uint32_t struct_size;   /* sizeof(vfm_pipe_t) of the caller's build (VFM_STRUCT_INIT) */
+  uint32_t abi_version;
   const float* zrec;
   float* zrec_next;
   const int32_t* next_occ_ptr;
@@ -529,21 +502,6 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
                                     float* m_scalars, float* v_scalars,
                                     float lr, float beta1, float beta2, float eps_adam, int64_t step, float* loss,
                                     int32_t* last_step, const int32_t* next_occ_ptr, float* step_tab, void* stream);
-
-/* Embedding-dimension-sharded multi-rank mode (every rank holds ALL rows of the batch and d/N coordinates of
- * both tables; the only per-step exchange is one all-reduce of B + VFM_MAX_FWD_BLOCKS floats):
- *   1. vfm_elbo_fwd_f32 with VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_PRIOR_TERMS (+ coord_off; + VFM_FLAG_NO_BIAS on
- *      all ranks but one) -> pred[0..B) = this rank's share of the row values, pred[B..B+VFM_MAX_FWD_BLOCKS) = its
- *      workgroups' shares of the entity KL term; sumz;
- *   2. all-reduce (sum) of pred[0 .. B + VFM_MAX_FWD_BLOCKS);
- *   3. vfm_elbo_lik_f32: pred[r] <- w0 + pred[r] (the predictions), grow[r] = dloss/dpred_r, and a `partials`
- *      workspace as a full forward would have left it (likelihood sums per workgroup slot; the KL slot = the sum
- *      of the tail, in a fixed order);
- *   4. vfm_elbo_bwd_adam_f32 / vfm_elbo_finalize_f32 + vfm_elbo_bwd_f32 on the local coordinates with those
- *      partials and WITHOUT VFM_FLAG_NO_PRIOR_TERMS: KL(q(w0)) enters the loss and the scalars' gradients once, on
- *      every rank alike (the three scalars are replicated: every rank applies the same update). */
-int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,
-                     float* pred, float* grow, double* partials, void* stream);
 
 /* Convert Adam moment buffers (n floats each) between the plain form and the scaled form of
  * VFM_FLAG_SCALED_MOMENTS, `step` = number of Adam steps applied so far: to_scaled != 0 divides m by

@@ -26,40 +26,122 @@ def test_header_symbols_are_exported():
     assert lib.vfm_abi_version() == _lib.ABI_VERSION
 
 
-def test_problem_struct_layout_matches_header(tmp_path):
-    """sizeof / field offsets of the ctypes mirror == what a C compiler makes of include/vfm_hip.h."""
+def _gcc_layouts(tmp_path):
+    """{struct: (sizeof, {field: offset})} as gcc lays out include/vfm_hip.h -- every struct, every field."""
     import subprocess
-    from vae_amd._lib import Problem
-    src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_problem_t), offsetof(vfm_problem_t, F),'
-                   'offsetof(vfm_problem_t, group_hi), offsetof(vfm_problem_t, group_n), offsetof(vfm_problem_t, seed),'
-                   'offsetof(vfm_problem_t, e_lo), offsetof(vfm_problem_t, flags), offsetof(vfm_problem_t, n_samples),'
-                   'offsetof(vfm_problem_t, coord_off));'
-                   'printf("%zu %zu\\n", offsetof(vfm_problem_t, dev_step), offsetof(vfm_problem_t, wrec));return 0;}\n')
-    exe = tmp_path / "sz"
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_bindings as G
+    _, structs = G.parse(open(G.HEADER).read())
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <string.h>', '#include "vfm_hip.h"', 'int main(){']
+    for cname, fields in structs:
+        lines.append(f'printf("S {cname} %zu\\n", sizeof({cname}));')
+        for name, _, _ in fields:
+            lines.append(f'printf("F {cname} {name} %zu\\n", offsetof({cname}, {name}));')
+    lines.append("return 0;}")
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert got == [C.sizeof(Problem), Problem.F.offset, Problem.group_hi.offset, Problem.group_n.offset,
-                   Problem.seed.offset, Problem.e_lo.offset, Problem.flags.offset, Problem.n_samples.offset,
-                   Problem.coord_off.offset, Problem.dev_step.offset, Problem.wrec.offset]
+    out = {}
+    for ln in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        t = ln.split()
+        if t[0] == "S":
+            out[t[1]] = (int(t[2]), {})
+        else:
+            out[t[1]][1][t[2]] = int(t[3])
+    return out, structs, G
 
 
-def test_step_state_struct_layouts_match_header(tmp_path):
-    """vfm_step_consts_t (64 bytes, 16 floats per table row) and vfm_dev_step_t (64 bytes = the int64[8] device tensor)."""
+def _check_mirrors(ns, layouts, structs, G):
+    for cname, fields in structs:
+        cls = ns[G.CLASS[cname]]
+        size, offs = layouts[cname]
+        assert C.sizeof(cls) == size, cname
+        assert [n for n, _ in cls._fields_] == [n for n, _, _ in fields], cname       # every member, in order
+        for name, _, _ in fields:
+            assert getattr(cls, name).offset == offs[name], (cname, name)
+
+
+def test_every_struct_mirror_matches_gcc(tmp_path):
+    """sizeof and EVERY field offset of the package's ctypes mirrors (vae_amd/_abi_gen.py, generated) == what a C compiler
+    makes of include/vfm_hip.h -- vfm_problem_t, vfm_index_t (occ_other, max_items, status included), vfm_pipe_t
+    (last_step, step_tab included), vfm_step_consts_t, vfm_dev_step_t."""
+    from vae_amd import _lib
+    layouts, structs, G = _gcc_layouts(tmp_path)
+    ns = {"Problem": _lib.Problem, "Index": _lib.Index, "Pipe": _lib.Pipe, "StepConsts": _lib.StepConsts, "DevStep": _lib.DevStep}
+    _check_mirrors(ns, layouts, structs, G)
+    assert C.sizeof(_lib.StepConsts) == 64 and C.sizeof(_lib.DevStep) == 64      # (table rows of 16 floats; an int64[8] device tensor)
+    p, ix, pp = _lib.Problem(), _lib.Index(), _lib.Pipe()
+    assert (p.struct_size, p.abi_version) == (C.sizeof(_lib.Problem), _lib.ABI_VERSION)
+    assert (ix.struct_size, pp.struct_size) == (C.sizeof(_lib.Index), C.sizeof(_lib.Pipe))
+
+
+def test_the_published_binding_in_INTEGRATION_md_matches_gcc(tmp_path):
+    """The ctypes block a maintainer would paste from INTEGRATION.md is extracted from the DOCUMENT, executed, and checked
+    field by field against gcc -- the round-3 defect was exactly a stale hand-typed mirror there."""
+    layouts, structs, G = _gcc_layouts(tmp_path)
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index(G.BEGIN): md.index(G.END)]
+    code = block[block.index("```python") + len("```python"): block.rindex("```")]
+    ns = {}
+    exec(code, ns)
+    _check_mirrors(ns, layouts, structs, G)
+    assert ns["VFM_ABI_VERSION"] == 5 and ns["Index"]().struct_size == layouts["vfm_index_t"][0]
+
+
+def test_generated_bindings_are_up_to_date():
+    """vae_amd/_abi_gen.py and the INTEGRATION.md block are what tools/gen_bindings.py makes of the header today."""
     import subprocess
-    from vae_amd._lib import StepConsts, DevStep
-    src = tmp_path / "st.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_step_consts_t), offsetof(vfm_step_consts_t, store_true),'
-                   'offsetof(vfm_step_consts_t, k), offsetof(vfm_step_consts_t, lr), sizeof(vfm_dev_step_t),'
-                   'offsetof(vfm_dev_step_t, adam_step_bwd), offsetof(vfm_dev_step_t, tab), offsetof(vfm_dev_step_t, error));return 0;}\n')
-    exe = tmp_path / "st"
-    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert got == [C.sizeof(StepConsts), StepConsts.store_true.offset, StepConsts.k.offset, StepConsts.lr.offset,
-                   C.sizeof(DevStep), DevStep.adam_step_bwd.offset, DevStep.tab.offset, DevStep.error.offset]
-    assert C.sizeof(StepConsts) == 64 and C.sizeof(DevStep) == 64
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_a_struct_of_another_layout_is_refused():
+    """ABI 5: a caller built against another layout is REFUSED (VFM_E_INVALID), not read past its end.  The 72-byte
+    vfm_index_t of the round-3 document (ten fields, no max_items) is the regression case; also a wrong version, a
+    zeroed header, a vfm_problem_t and a vfm_pipe_t of the wrong size."""
+    from vae_amd import _lib
+    lib = _lib.load()
+
+    class OldIndex(C.Structure):              # INTEGRATION.md as of round 3: 72 bytes
+        _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
+                    ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
+                    ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64),
+                    ("occ_other", C.c_void_p)]
+    assert C.sizeof(OldIndex) == 72
+    p = _lib.Problem()
+    p.B, p.B_global, p.T, p.F, p.d, p.id_bits, p.n_samples = 4, 4, 10, 2, 8, 64, 1
+    old = OldIndex(0x1000, 0x1000, None, None, None, 0, 0)
+    bwd = lib.vfm_elbo_bwd_f32
+    keep = bwd.argtypes
+    bwd.argtypes = [C.POINTER(_lib.Problem), C.c_void_p] + list(keep[2:])
+    try:
+        rc = bwd(C.byref(p), C.cast(C.pointer(old), C.c_void_p), *([None] * 16))
+    finally:
+        bwd.argtypes = keep
+    assert rc == -1 and b"vfm_index_t" in lib.vfm_last_error() and b"struct_size" in lib.vfm_last_error()
+    ix = _lib.Index()
+    ix.occ_ptr = ix.occ_rows = 0x1000
+    ix.abi_version = 4
+    assert lib.vfm_elbo_bwd_f32(C.byref(p), C.byref(ix), *([None] * 16)) == -1 and b"abi_version" in lib.vfm_last_error()
+    ix.abi_version, ix.struct_size = _lib.ABI_VERSION, C.sizeof(_lib.Index) - 8
+    assert lib.vfm_elbo_bwd_adam_f32(C.byref(p), C.byref(ix), *([None] * 17), 0.1, 0.9, 0.999, 1e-8, 1, None, None) == -1
+    assert b"vfm_index_t" in lib.vfm_last_error()
+    ix.struct_size = C.sizeof(_lib.Index)
+    assert lib.vfm_elbo_bwd_f32(C.byref(p), C.byref(ix), *([None] * 16)) == -1 and b"NULL pointer" in lib.vfm_last_error()
+    p.struct_size = 0
+    assert lib.vfm_elbo_fwd_f32(C.byref(p), *([None] * 15)) == -1 and b"vfm_problem_t" in lib.vfm_last_error()
+    assert lib.vfm_batch_norms(C.byref(p), None, None, None, None) == -1
+    assert lib.vfm_variant_fwd_f32(C.byref(p), 0, *([None] * 18)) == -1 and b"struct_size" in lib.vfm_last_error()
+    p.struct_size = C.sizeof(_lib.Problem)
+    p.F, p.d, p.flags = 2, 8, 32
+    pipe = _lib.Pipe()
+    pipe.zrec = 0x1000
+    pipe.struct_size -= 16                      # (vfm_pipe_t before last_step / step_tab were added)
+    assert lib.vfm_elbo_bwd_adam_pipe_f32(C.byref(p), C.byref(ix), C.byref(pipe), *([None] * 13), 0.1, 0.9, 0.999, 1e-8, 1,
+                                          None, None) == -1
+    assert b"vfm_pipe_t" in lib.vfm_last_error()
 
 
 def test_step_consts_host_helper_and_dev_step_rejections():
@@ -93,21 +175,6 @@ def test_step_consts_host_helper_and_dev_step_rejections():
     assert b"n_lr" in lib.vfm_last_error()
 
 
-def test_index_struct_layout_matches_header(tmp_path):
-    import subprocess
-    from vae_amd._lib import Index
-    src = tmp_path / "ix.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfm_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(vfm_index_t), offsetof(vfm_index_t, heavy_acc),'
-                   'offsetof(vfm_index_t, n_items), offsetof(vfm_index_t, touched_ids), offsetof(vfm_index_t, n_touched));'
-                   'return 0;}\n')
-    exe = tmp_path / "ix"
-    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    assert got == [C.sizeof(Index), Index.heavy_acc.offset, Index.n_items.offset, Index.touched_ids.offset,
-                   Index.n_touched.offset]
-
-
 def test_problem_mirror_has_every_header_field_and_rejects_unknown_names():
     """Every member of vfm_problem_t is a ctypes field of the same name (ctypes would otherwise keep an
     assignment as a plain Python attribute and pass 0 to the library), and a flag set through the mirror
@@ -125,11 +192,11 @@ def test_problem_mirror_has_every_header_field_and_rejects_unknown_names():
         p.flagz = 3
     # everything ops._problem sets is a real field, and a non-zero flag is seen by the C side
     spec = ops.Spec(T=10, F=2, d=8, group_hi=(5, 10), group_n=(5.0, 5.0), likelihood=0, n_samples=2)
-    q = ops._problem(spec, 4, 4, 64, flags=ops.FLAG_PARTIAL_PRED)
-    assert q.flags == ops.FLAG_PARTIAL_PRED and q.n_samples == 2
+    q = ops._problem(spec, 4, 4, 64, flags=256)       # (a bit no flag of this ABI uses: VFM_FLAG_PARTIAL_PRED of ABI 4)
+    assert q.flags == 256 and q.n_samples == 2
     lib = _lib.load()
-    assert lib.vfm_elbo_fwd_f32(C.byref(q), *([None] * 15)) == -2      # rejected BECAUSE of the flag (S > 1)
-    assert b"VFM_FLAG_PARTIAL_PRED" in lib.vfm_last_error()
+    assert lib.vfm_elbo_fwd_f32(C.byref(q), *([None] * 15)) == -1      # rejected BECAUSE of the flag
+    assert b"unknown bit" in lib.vfm_last_error()
     q.flags = 0
     assert lib.vfm_elbo_fwd_f32(C.byref(q), *([None] * 15)) == -1      # same call without it: NULL pointers
 

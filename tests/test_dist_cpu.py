@@ -85,65 +85,6 @@ def test_shard_rows_partitions_every_batch():
             assert sum(b - a for a, b in spans) == hi - lo
 
 
-def _dims_worker(rank, world, port, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from vae_amd.model import VFM
-    from vae_amd.dims import DimsState
-    torch.manual_seed(3)
-    m = VFM(7, 5, 16, device="cpu")
-    m._ensure_opt_state()
-    m._adam_m.copy_(torch.arange(m._n_flat, dtype=torch.float32))
-    full0 = m._flat.clone()
-    st = DimsState(m, dist.group.WORLD)
-    ent, bia, scal = m._views(full0)
-    e, b, s = st.views(st.flat)
-    dl = 16 // world
-    # the slice holds this rank's coordinates of the means and of the scales, all first-order weights, the scalars
-    assert torch.equal(e[:, :dl], ent[:, rank * dl:(rank + 1) * dl])
-    assert torch.equal(e[:, dl:], ent[:, 16 + rank * dl: 16 + (rank + 1) * dl])
-    assert torch.equal(b, bia) and torch.equal(s, scal)
-    # every rank changes its slice (rank 0 also the first-order weights); the gather assembles them
-    e.mul_(rank + 2.0)
-    if rank == 0:
-        b.add_(1.0)
-    else:
-        b.fill_(-7.0)            # stale copies on the other ranks must not survive the gather
-    m._flat.zero_()
-    st.gather(m)
-    np.save(os.path.join(out_dir, f"dims_full_{rank}.npy"), m._flat.numpy())
-    np.save(os.path.join(out_dir, f"dims_m_{rank}.npy"), m._adam_m.numpy())
-    if rank == 0:
-        np.save(os.path.join(out_dir, "dims_full0.npy"), full0.numpy())
-    dist.destroy_process_group()
-
-
-def test_dimension_sharded_scatter_gather_roundtrip(tmp_path):
-    """vae_amd.dims.DimsState (the host logic of exchange='dims'): slicing of the tables by coordinate,
-    all-gather back into the full layout, first-order weights from rank 0 -- gloo, world 2, CPU tensors."""
-    from vae_amd.dims import supported
-    assert supported(128, 8) and supported(16, 2) and not supported(20, 2) and not supported(128, 8, n_samples=2)
-    assert not supported(128, 1)
-    world = 2
-    mp.spawn(_dims_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    f0, f1 = np.load(tmp_path / "dims_full_0.npy"), np.load(tmp_path / "dims_full_1.npy")
-    assert np.array_equal(f0, f1)
-    full0 = np.load(tmp_path / "dims_full0.npy")
-    T, d, dl = 12, 16, 8
-    ent0 = full0[: T * 2 * d].reshape(T, 2 * d)
-    ent = f0[: T * 2 * d].reshape(T, 2 * d)
-    for r in range(world):
-        for half in (0, d):
-            lo = half + r * dl
-            assert np.array_equal(ent[:, lo:lo + dl], ent0[:, lo:lo + dl] * (r + 2.0))
-    off_bias = (T * 2 * d + 3) // 4 * 4
-    assert np.array_equal(f0[off_bias: off_bias + 2 * T], full0[off_bias: off_bias + 2 * T] + 1.0)
-    # the moments travel the same way (unchanged here)
-    m0 = np.load(tmp_path / "dims_m_0.npy")
-    assert np.array_equal(m0[: T * 2 * d], np.arange(T * 2 * d, dtype=np.float32))
-
-
 class _FakePlan:
     """What vae_amd.dist.global_touched needs of a plan: the sorted ids of the entities its shard contains."""
 

@@ -580,44 +580,6 @@ def test_scaled_moments_equal_plain_dense_adam(n_steps):
     assert rel(a._adam_m, b._adam_m) < tol_m and rel(a._adam_v, b._adam_v) < tol_m
 
 
-def test_untouched_rows_split_equals_single_launch():
-    """VFM_FLAG_ROWS_UNTOUCHED + VFM_FLAG_ROWS_TOUCHED (two launches of the fused backward + Adam) == one launch
-    over all rows: same arithmetic per row, so bitwise equal parameters and moments -- also across a period
-    boundary of the scaled moment form."""
-    from vae_amd import ops
-    from vae_amd.model import VFM
-    from vae_amd.data import synthetic_triples
-    X, y = synthetic_triples([300, 200], 2000, seed=3)
-
-    def run(split):
-        torch.manual_seed(9)
-        m = VFM(300, 200, 12, device="cuda", rng_seed=4)
-        m.set_training_data(X, nb_train=2000)
-        m._ensure_opt_state()
-        m._moments_scaled = True
-        plans = [m.plan(X[i:i + 100], y[i:i + 100]) for i in range(0, 2000, 100)]
-        ent, bia, scal = m._views(m._flat)
-        mv, vv = m._views(m._adam_m), m._views(m._adam_v)
-        loss3 = torch.zeros(3, device="cuda")
-        for s in range(140):
-            plan = plans[s % 20]
-            st = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, seed=4, step=s)
-            if split:      # the untouched rows need nothing from the forward: any order / stream works
-                ops.elbo_backward_adam(plan, st, ent, bia, scal, m.inv_occ, mv, vv, 0.02, s + 1, scaled_moments=True,
-                                       rows="untouched")
-                ops.elbo_backward_adam(plan, st, ent, bia, scal, m.inv_occ, mv, vv, 0.02, s + 1, loss_out=loss3,
-                                       scaled_moments=True, rows="touched")
-            else:
-                ops.elbo_backward_adam(plan, st, ent, bia, scal, m.inv_occ, mv, vv, 0.02, s + 1, loss_out=loss3,
-                                       scaled_moments=True)
-        torch.cuda.synchronize()
-        return m, loss3.clone()
-
-    (a, la), (b, lb) = run(True), run(False)
-    assert torch.equal(la, lb)
-    assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)
-
-
 def test_step_is_capturable_in_a_hip_graph():
     """include/vfm_hip.h: launch-only, safe under hipGraph capture.  The forward + fused backward of a skewed batch in a
     large table (the long-list pre-reduction forks to the library's side stream and joins again by events) captured

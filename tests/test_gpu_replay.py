@@ -1,8 +1,7 @@
-"""GPU: the REPLAYABLE training step (step-dependent constants in device memory, launches captured once per (batch, next
-batch, step form) in a HIP graph and replayed -- include/vfm_hip.h: vfm_dev_step_t) and the packed first-order records
-(vfm_problem_t.wrec) against the eager step with host-side constants: the trajectory must be the eager one BIT FOR BIT --
-parameters, Adam moments, losses -- across moment-period boundaries, learning-rate changes, predictions in between (they
-consume Philox steps), an un-announced batch (eager catch-up in the middle of replays) and a checkpoint round trip.
+"""GPU: the device-resident step state (include/vfm_hip.h: vfm_dev_step_t -- step-dependent constants in device memory, so a
+captured HIP graph of forward + fused backward replays as consecutive training steps) and the packed first-order records
+(vfm_problem_t.wrec), both against the eager step with host-side constants: the trajectory must be the eager one BIT FOR
+BIT -- parameters, Adam moments, losses -- across moment-period boundaries and learning-rate changes.
 Reference loop: vfm-torch.py:351-370."""
 import pytest
 import torch
@@ -24,48 +23,62 @@ def _setup(sizes, d, B, nb, output="reg", **attrs):
     return m, plans, X
 
 
-FORMS = {
-    # name: (field sizes, d, B, batches, attributes, the step form the replayed run must be in)
-    "lookahead_F3": ((900, 700, 400), 16, 48, 6, dict(pipeline=False), "la"),
-    "lookahead_F2_d128": ((1500, 500), 128, 200, 5, dict(pipeline=False), "la"),
-    "lookahead_scan": ((900, 700, 400), 16, 48, 6, dict(pipeline=False, lookahead_list=False), "la"),
-    "dense_small_table": ((60, 40), 20, 400, 4, dict(pipeline=False, lookahead=False), "dense"),
-    "dense_heavy_lists": ((3000, 40), 32, 600, 4, dict(pipeline=False, lookahead=False), "dense"),
-    "pipelined": ((300, 200), 32, 2000, 4, dict(pipeline=True), "pipe"),
-    "criteo_like_class": ((500,) * 12, 32, 64, 5, dict(pipeline=False), "la"),
-}
+def test_device_step_state_replays_consecutive_steps_bitwise():
+    """The ONE capturability test of the device-resident step state (vfm_dev_step_t, ops.StepState): forward + fused
+    backward/Adam captured ONCE with the Philox step and the Adam constants in device memory, replayed as consecutive
+    training steps (the kernels advance the counters themselves) == the same steps launched eagerly with host-side
+    arguments, bit for bit -- across a learning-rate change (table refill; the error flag survives it) and a moment-period
+    boundary.  (`VFM.fit` itself launches eagerly: a graph launch measured slower than two direct launches on ROCm 7.2.)"""
+    from vae_amd import ops
+    dev = torch.device("cuda:0")
+    eager, plans_e, _ = _setup((1500, 500), 64, 200, 1, pipeline=False)
+    rep, plans_r, _ = _setup((1500, 500), 64, 200, 1, pipeline=False)
+    plan_e, plan_r = plans_e[0], plans_r[0]
+    for m in (eager, rep):
+        m._ensure_opt_state()
+        m._set_moment_form(True)
 
+    def launch(m, plan, bufs, lr, step, dev_step=None):
+        sumz, grow, pred, loss3 = bufs
+        ent, bia, scal = m._views(m._flat)
+        st = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, seed=11, step=step, train=True, out_pred=pred, out_sumz=sumz,
+                              out_grow=grow, out_partials=m._partials, dev_step=dev_step)
+        ops.elbo_backward_adam(plan, st, ent, bia, scal, m.inv_occ, m._views(m._adam_m), m._views(m._adam_v), lr, step + 1,
+                               loss_out=loss3, scaled_moments=True, dev_step=dev_step)
 
-@pytest.mark.parametrize("name", sorted(FORMS))
-def test_replayed_steps_are_bitwise_the_eager_trajectory(name, monkeypatch):
-    import vae_amd.model as M
-    monkeypatch.setattr(M, "_CHECK_WREC", True)           # every step also checks the packed records against the tables
-    sizes, d, B, nb, attrs, form = FORMS[name]
-    out = "class" if "class" in name else "reg"
-    eager, plans_e, X = _setup(sizes, d, B, nb, out, replay=False, **attrs)
-    rep, plans_r, _ = _setup(sizes, d, B, nb, out, replay=True, **attrs)
-    n_steps = 300                                         # two moment-period boundaries (128, 256)
-    order = [s % nb for s in range(n_steps + 1)]
-    for s in range(n_steps):
-        lr = 0.05 if (s // 60) % 2 == 0 else 0.02         # the learning rate changes now and then (table refill)
-        i, j = order[s], order[s + 1]
-        if s == 99:
-            j = (j + 2) % nb                              # step 100 does not take the batch step 99 announced
-        le, pe = eager.train_step(plans_e[i], lr=lr, next_plan=plans_e[j])
-        lr_, pr = rep.train_step(plans_r[i], lr=lr, next_plan=plans_r[j])
-        if s % 25 == 17 or s in (127, 128, 129, 255, 256):
-            assert torch.equal(le, lr_), (name, s)
-            assert torch.equal(pe, pr), (name, s)
-        if s in (140, 141, 200):                          # predictions consume Philox steps: the device counter is re-set
-            assert torch.equal(eager.predict(X[:100])["y_pred"], rep.predict(X[:100])["y_pred"])
-    captured = [k for k, v in rep._graphs.items() if v is not None]
-    assert captured and all(k[0] == form for k in captured), (form, [k[0] for k in rep._graphs])
-    assert not rep._step_state.error()
-    assert eager._step_state is None and not eager._graphs
-    eager.sync_lazy(); rep.sync_lazy()
-    assert torch.equal(eager._flat, rep._flat)
-    assert torch.equal(eager._adam_m, rep._adam_m) and torch.equal(eager._adam_v, rep._adam_v)
-    assert eager._adam_t == rep._adam_t == n_steps and eager.global_step == rep.global_step
+    def buffers(m):
+        return (torch.empty(200, m.d, device=dev), torch.empty(200, device=dev), torch.empty(200, device=dev),
+                torch.empty(3, device=dev))
+    be, br = buffers(eager), buffers(rep)
+    st8 = ops.StepState(dev)
+    plan_r.index_tensors()
+    launch(rep, plan_r, br, 0.05, 0)                # warm-up outside the capture (lazily made streams, the allocator) ...
+    launch(eager, plan_e, be, 0.05, 0)              # ... mirrored on the eager model: both are at step 1 now
+    st8.cover(2, 0.05, 0.9, 0.999, 1e-8, True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            launch(rep, plan_r, br, 0.0, 0, dev_step=st8.dev)      # (host-side lr / step are ignored with dev_step)
+    losses_e, losses_r = [], []
+    st8.set(1, 2)
+    for step in range(1, 140):                      # Adam steps 2 .. 140: across the period boundary at 128
+        lr = 0.05 if step < 70 else 0.02
+        st8.cover(step + 1, lr, 0.9, 0.999, 1e-8, True)
+        st8.set(step, step + 1)
+        g.replay()
+        st8.advanced()
+        launch(eager, plan_e, be, lr, step)
+        losses_e.append(be[3].clone()); losses_r.append(br[3].clone())
+    torch.cuda.synchronize()
+    assert not st8.error()
+    assert all(torch.equal(a, b) for a, b in zip(losses_e, losses_r))
+    assert torch.equal(eager._flat, rep._flat) and torch.equal(eager._adam_m, rep._adam_m) and torch.equal(eager._adam_v, rep._adam_v)
+    # a step the table does not cover raises the sticky error flag -- and a later refill must not erase it
+    st8.set(5000, 5000)
+    g.replay()
+    st8.cover(1, 0.05, 0.9, 0.999, 1e-8, True)
+    assert st8.error()
 
 
 def test_packed_first_order_records_do_not_change_the_trajectory(monkeypatch):
@@ -98,42 +111,3 @@ def test_packed_first_order_records_do_not_change_the_trajectory(monkeypatch):
     assert not a._wrec_ok
     a.train_step(pa[1], lr=0.04, next_plan=pa[2])           # (rebuilt from the tables: the debug check holds again)
     assert a._wrec_ok
-
-
-def test_fit_replays_and_matches_the_eager_fit():
-    """VFM.fit with replay on (one graph per (batch, next batch) pair, replayed every epoch) == the same fit with
-    replay off (the default): history, parameters, the epoch-averaged snapshots, the predictors."""
-    from vae_amd.model import VFM
-    from vae_amd.data import synthetic_triples
-    sizes = (943, 1682)
-    X, y = synthetic_triples(list(sizes), 6000, seed=9, device="cuda")
-    Xt, yt = synthetic_triples(list(sizes), 500, seed=10, device="cuda")
-    runs = []
-    for replay in (False, True):
-        torch.manual_seed(5)
-        m = VFM(sizes[0], sizes[1], 20, device="cuda", rng_seed=3)
-        m.replay = replay
-        h = m.fit(X, y, n_epochs=6, batch_size=1500, X_test=Xt, y_test=yt, verbose=False)
-        runs.append((m, h))
-    (m0, h0), (m1, h1) = runs
-    assert [k for k, v in m1._graphs.items() if v is not None] and not m0._graphs
-    assert h0["elbo"] == h1["elbo"] and h0["train_rmse"] == h1["train_rmse"] and h0["test"] == h1["test"]
-    assert torch.equal(m0._flat, m1._flat) and torch.equal(m0._mean_flat, m1._mean_flat)
-    assert m1.replay is True and m0.replay is False
-
-
-def test_replay_survives_a_checkpoint_round_trip():
-    rep, plans, X = _setup((900, 700, 400), 16, 48, 6, pipeline=False, replay=True)
-    ref, plans_f, _ = _setup((900, 700, 400), 16, 48, 6, pipeline=False, replay=False)
-    for s in range(30):
-        rep.train_step(plans[s % 6], lr=0.03, next_plan=plans[(s + 1) % 6])
-        ref.train_step(plans_f[s % 6], lr=0.03, next_plan=plans_f[(s + 1) % 6])
-    sd = rep.training_state_dict()
-    for s in range(30, 50):
-        rep.train_step(plans[s % 6], lr=0.03, next_plan=plans[(s + 1) % 6])
-    rep.load_training_state_dict(sd)                       # back to step 30: the device counters must follow
-    for s in range(30, 60):
-        rep.train_step(plans[s % 6], lr=0.03, next_plan=plans[(s + 1) % 6])
-        ref.train_step(plans_f[s % 6], lr=0.03, next_plan=plans_f[(s + 1) % 6])
-    rep.sync_lazy(); ref.sync_lazy()
-    assert torch.equal(rep._flat, ref._flat) and torch.equal(rep._adam_m, ref._adam_m)

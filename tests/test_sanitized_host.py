@@ -58,14 +58,27 @@ for g in range(64):
     p.group_hi[g], p.group_n[g] = g + 1, 1.0
 # every entry point that takes the problem: argument errors, never a crash
 for name, n in (("vfm_elbo_fwd_f32", 15), ("vfm_elbo_bwd_f32", 17), ("vfm_elbo_finalize_f32", 4), ("vfm_batch_norms", 4),
-                ("vfm_elbo_bwd_acc_f32", 7), ("vfm_elbo_lik_f32", 7), ("vfm_philox_eps_f32", 4)):
+                ("vfm_elbo_bwd_acc_f32", 7), ("vfm_philox_eps_f32", 4)):
     assert getattr(lib, name)(C.byref(p), *([None] * n)) != 0, name
     assert len(lib.vfm_last_error()) > 0
+one = 0x1000
 q = _lib.Problem()
 q.B, q.B_global, q.T, q.F, q.d, q.id_bits, q.n_samples, q.flags = 8, 8, 100, 2, 16, 64, 1, 32
 q.group_hi[0], q.group_hi[1], q.group_n[0], q.group_n[1] = 50, 100, 50.0, 50.0
 ix = _lib.Index()
 assert lib.vfm_elbo_bwd_acc_rows_f32(C.byref(q), C.byref(ix), None, 3, None, None, None, None, None, None) != 0
+# the struct guards of ABI 5 (a caller built against another layout is refused, never read past its end) and the index counts
+ix.struct_size -= 8
+assert lib.vfm_elbo_bwd_f32(C.byref(q), C.byref(ix), *([one] * 16)) == -1 and b"vfm_index_t" in lib.vfm_last_error()
+ix.struct_size += 8
+ix.occ_ptr = ix.occ_rows = one
+ix.n_heavy = -3
+assert lib.vfm_elbo_bwd_f32(C.byref(q), C.byref(ix), *([one] * 16)) == -1 and b"negative count" in lib.vfm_last_error()
+ix.n_heavy, ix.n_items, ix.heavy_ids, ix.heavy_items, ix.heavy_acc = 101, 1, one, one, one      # more heavy entities than table rows
+q.flags = 0
+assert lib.vfm_elbo_bwd_f32(C.byref(q), C.byref(ix), *([one] * 16)) == -1 and b"more heavy entities" in lib.vfm_last_error()
+q.flags = 32
+ix = _lib.Index()
 assert lib.vfm_elbo_apply_adam_rows_f32(C.byref(q), None, None, None, 0, 1, *([None] * 11), 0.1, 0.9, 0.999, 1e-8, 1, None) != 0
 one = 0x1000
 ids = (C.c_int32 * 4)(1, 2, 3, 4)

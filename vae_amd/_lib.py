@@ -18,22 +18,22 @@ LIB_DIR = os.environ.get("VFM_LIB_DIR") or HERE
 LIB_PATH = os.path.join(LIB_DIR, "libvfm_hip.so")
 OPS_PATH = os.path.join(LIB_DIR, "libvfm_torch_ops.so")
 
-ABI_VERSION = 4
-MAX_FWD_BLOCKS = 4096
-MAX_FIELDS = 64
-N_PARTIALS = 8
-MAX_FWD_BLOCKS = 4096
-PARTIALS_LEN = N_PARTIALS * (1 + MAX_FWD_BLOCKS)
-P_LL, P_KL, P_G, P_ALPHA, P_BADID = 0, 1, 2, 3, 4
-LIK_NORMAL, LIK_BERNOULLI = 0, 1
-OBJ_SAMPLED, OBJ_CLOSED_FORM = 0, 1
+from . import _abi_gen as _gen      # GENERATED from include/vfm_hip.h (tools/gen_bindings.py): constants + struct mirrors
+
+ABI_VERSION = _gen.VFM_ABI_VERSION
+MAX_FWD_BLOCKS = _gen.VFM_MAX_FWD_BLOCKS
+MAX_FIELDS = _gen.VFM_MAX_FIELDS
+N_PARTIALS = _gen.VFM_N_PARTIALS
+PARTIALS_LEN = _gen.VFM_PARTIALS_LEN
+P_LL, P_KL, P_G, P_ALPHA, P_BADID = _gen.VFM_P_LL, _gen.VFM_P_KL, _gen.VFM_P_G, _gen.VFM_P_ALPHA, _gen.VFM_P_BADID
+LIK_NORMAL, LIK_BERNOULLI = _gen.VFM_LIK_NORMAL, _gen.VFM_LIK_BERNOULLI
+OBJ_SAMPLED, OBJ_CLOSED_FORM = _gen.VFM_OBJ_SAMPLED, _gen.VFM_OBJ_CLOSED_FORM
 
 EXPORTS = (
     "vfm_abi_version", "vfm_last_error", "vfm_inv_occ_f32", "vfm_batch_norms",
     "vfm_elbo_fwd_f32", "vfm_elbo_finalize_f32", "vfm_elbo_bwd_f32", "vfm_philox_eps_f32",
     "vfm_adam_f32", "vfm_elbo_bwd_adam_f32", "vfm_elbo_bwd_acc_f32", "vfm_elbo_apply_adam_f32",
-    "vfm_shard_sample_f32", "vfm_records_add_f32", "vfm_shard_pack_f32", "vfm_shard_loss_f32",
-    "vfm_moments_rescale_f32", "vfm_elbo_lik_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
+    "vfm_moments_rescale_f32", "vfm_index_workspace_bytes", "vfm_build_index", "vfm_heavy_list_for",
     "vfm_variant_fwd_f32", "vfm_variant_bwd_f32", "vfm_variant_workspace_elems", "vfm_adam_catchup_f32", "vfm_union_rows", "vfm_union_workspace_bytes",
     "vfm_sample_records_f32", "vfm_elbo_bwd_adam_pipe_f32", "vfm_elbo_bwd_adam_lookahead_f32",
     "vfm_step_consts", "vfm_dev_step_set", "vfm_wrec_build_f32", "vfm_elbo_apply_adam_rows_f32",
@@ -41,57 +41,31 @@ EXPORTS = (
 )
 
 
-class Problem(C.Structure):
-    """Mirror of `vfm_problem_t`."""
-    _fields_ = [
-        ("B", C.c_int64), ("B_global", C.c_int64), ("T", C.c_int64), ("nb_train", C.c_int64),
-        ("F", C.c_int32), ("d", C.c_int32), ("likelihood", C.c_int32), ("id_bits", C.c_int32),
-        ("n_samples", C.c_int32), ("flags", C.c_int32),
-        ("group_hi", C.c_int64 * MAX_FIELDS), ("group_n", C.c_double * MAX_FIELDS),
-        ("seed", C.c_uint64), ("step", C.c_uint64), ("e_lo", C.c_int64), ("e_hi", C.c_int64),
-        ("own_mod", C.c_int32), ("own_rank", C.c_int32),
-        ("coord_off", C.c_int32), ("reserved0", C.c_int32),
-        ("dev_step", C.c_void_p), ("wrec", C.c_void_p),
-    ]
+class _Strict:
+    """ctypes accepts ANY attribute name and silently keeps it as a Python attribute: a misspelt or missing field
+    would leave the struct member 0 without an error."""
 
     def __setattr__(self, name, value):
-        # ctypes accepts ANY attribute name and silently keeps it as a Python attribute: a misspelt or
-        # missing field would leave the struct member 0 without an error
         if name not in type(self)._names:
-            raise AttributeError(f"vfm_problem_t has no field {name!r}")
+            raise AttributeError(f"{type(self).__name__} has no field {name!r}")
         super().__setattr__(name, value)
 
 
-Problem._names = frozenset(n for n, _ in Problem._fields_)
+class Problem(_Strict, _gen.Problem):
+    """`vfm_problem_t` (struct_size / abi_version are set by the generated __init__)."""
 
 
-class Index(C.Structure):
-    """Mirror of `vfm_index_t`."""
-    _fields_ = [("occ_ptr", C.c_void_p), ("occ_rows", C.c_void_p), ("heavy_ids", C.c_void_p),
-                ("heavy_items", C.c_void_p), ("heavy_acc", C.c_void_p), ("n_heavy", C.c_int32),
-                ("n_items", C.c_int32), ("touched_ids", C.c_void_p), ("n_touched", C.c_int64),
-                ("occ_other", C.c_void_p), ("max_items", C.c_int32)]
+class Index(_Strict, _gen.Index):
+    """`vfm_index_t`."""
 
 
-class StepConsts(C.Structure):
-    """Mirror of `vfm_step_consts_t` (64 bytes: the constants of one Adam step, made by vfm_step_consts)."""
-    _fields_ = [("step_size", C.c_float), ("bc2_sqrt", C.c_float), ("a1", C.c_float), ("q2", C.c_float),
-                ("c1", C.c_float), ("c2", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
-                ("store_true", C.c_int32), ("k", C.c_int32), ("scaled", C.c_int32), ("reserved", C.c_int32),
-                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+class Pipe(_Strict, _gen.Pipe):
+    """`vfm_pipe_t`."""
 
 
-class DevStep(C.Structure):
-    """Mirror of `vfm_dev_step_t` (64 bytes, lives in DEVICE memory: an int64[8] tensor)."""
-    _fields_ = [("philox_step", C.c_uint64), ("adam_step", C.c_int64), ("philox_step_bwd", C.c_uint64),
-                ("adam_step_bwd", C.c_int64), ("tab_first", C.c_int64), ("tab_len", C.c_int64), ("tab", C.c_void_p),
-                ("error", C.c_int64)]
-
-
-class Pipe(C.Structure):
-    """Mirror of `vfm_pipe_t`."""
-    _fields_ = [("zrec", C.c_void_p), ("zrec_next", C.c_void_p), ("next_occ_ptr", C.c_void_p), ("next_W", C.c_void_p),
-                ("next_step", C.c_uint64), ("last_step", C.c_void_p), ("step_tab", C.c_void_p)]
+StepConsts, DevStep = _gen.StepConsts, _gen.DevStep
+for _c in (Problem, Index, Pipe):
+    _c._names = frozenset(n for n, _ in _c._fields_)
 
 
 def heavy_list_for(n_occ: int, T: int) -> int:
@@ -134,19 +108,14 @@ def load():
                                  i64, vp]
     lib.vfm_elbo_bwd_acc_f32.argtypes = [PP] + [vp] * 7
     lib.vfm_elbo_apply_adam_f32.argtypes = ([PP] + [vp] * 16 +
-                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp, vp, vp, vp])
+                                            [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
     lib.vfm_elbo_bwd_acc_rows_f32.argtypes = [PP, C.POINTER(Index), vp, i64] + [vp] * 6
     lib.vfm_elbo_apply_adam_rows_f32.argtypes = ([PP, vp, vp, vp, i64, i32] + [vp] * 11 +
                                                  [C.c_float, C.c_float, C.c_float, C.c_float, i64, vp])
-    lib.vfm_shard_sample_f32.argtypes = [PP, vp, i64, vp, vp, vp, vp, vp, vp]
-    lib.vfm_records_add_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp]
-    lib.vfm_shard_pack_f32.argtypes = [vp, vp, vp, vp]
-    lib.vfm_shard_loss_f32.argtypes = [vp, vp, vp]
-    lib.vfm_elbo_lik_f32.argtypes = [PP, vp, vp, vp, vp, vp, vp, vp]
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_heavy_list_for.argtypes = [i64, i64]
-    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     lib.vfm_rebuild_heavy.argtypes = [i64, vp, vp, i32, i32, vp, i64, vp, i64, vp, vp]
     lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), i64, C.c_float, C.c_float, C.c_float,
                                          i64, i64, vp, vp]
@@ -169,7 +138,8 @@ def load():
         fn = getattr(lib, name)
         if name != "vfm_last_error":
             fn.restype = C.c_int
-    lib.vfm_index_workspace_bytes.restype = i64
+    for name in ("vfm_index_workspace_bytes", "vfm_union_workspace_bytes", "vfm_variant_workspace_elems"):
+        getattr(lib, name).restype = i64
     if lib.vfm_abi_version() != ABI_VERSION:
         raise VfmLibraryError(f"ABI mismatch: library {lib.vfm_abi_version()}, package {ABI_VERSION}")
     _lib = lib

@@ -39,12 +39,18 @@ def _stale(target, sources):
 # hipcc's default ("fast": fusion across statements, decided after inlining) two template instances of k_bwd rounded
 # the same source differently in the last bit, and the lazy / look-ahead step forms are specified as BITWISE the dense one.
 _EXACT = ["-ffp-contract=" + os.environ.get("VFM_FP_CONTRACT", "on")]      # (the variable: A/B builds only)
+# The softplus link (the reference's own dead assignment, vfm-torch.py:125) is served by the GENERAL kernels only (k_fwd,
+# k_bwd); the specialised forward kernels and the record step are built for |.| (:126, the assignment in effect).  vfm_bwd.hip
+# is compiled in two parts per link (VFM_BWD_PART: gradient / statistics forms, fused-Adam forms) so that no single unit
+# dominates the wall time of a clean build.
 _UNITS = [("vfm_abi.hip", "", _EXACT), ("vfm_index.hip", "", []), ("vfm_variants.hip", "", []),
           ("vfm_fwd.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd.hip", "_softplus", ["-DVFM_LINK=1"]),
-          ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2.hip", "_softplus", ["-DVFM_LINK=1"]),
-          ("vfm_fwd2m.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2m.hip", "_softplus", ["-DVFM_LINK=1"]),
-          ("vfm_fwdg.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwdg.hip", "_softplus", ["-DVFM_LINK=1"]),
-          ("vfm_bwd.hip", "_abs", ["-DVFM_LINK=0"] + _EXACT), ("vfm_bwd.hip", "_softplus", ["-DVFM_LINK=1"] + _EXACT)]
+          ("vfm_fwd2.hip", "_abs", ["-DVFM_LINK=0"]), ("vfm_fwd2m.hip", "_abs", ["-DVFM_LINK=0"]),
+          ("vfm_fwdg.hip", "_abs", ["-DVFM_LINK=0"]),
+          ("vfm_bwd.hip", "0_abs", ["-DVFM_LINK=0", "-DVFM_BWD_PART=0"] + _EXACT),
+          ("vfm_bwd.hip", "1_abs", ["-DVFM_LINK=0", "-DVFM_BWD_PART=1"] + _EXACT),
+          ("vfm_bwd.hip", "0_softplus", ["-DVFM_LINK=1", "-DVFM_BWD_PART=0"] + _EXACT),
+          ("vfm_bwd.hip", "1_softplus", ["-DVFM_LINK=1", "-DVFM_BWD_PART=1"] + _EXACT)]
 
 
 def build_hip_library(force=False, verbose=False):
@@ -61,16 +67,26 @@ def build_hip_library(force=False, verbose=False):
     common = [HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden",
               "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
     jobs, objs = [], []
+    shared = [hdr, os.path.abspath(__file__)] + [f for f in parts if f.endswith(".hpp")]      # what every unit depends on
     for src, suffix, extra in _UNITS:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + suffix + ".o")
+        objs.append(obj)
+        if not force and not _stale(obj, shared + [os.path.join(csrc, src)]):
+            continue                      # (a change to one .hip recompiles that unit only)
         cmd = common + extra + ["-c", os.path.join(csrc, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         jobs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+    n_inst = 0                            # kernel instances in the library (host-side launch stubs of the objects)
+    for obj in objs:
+        try:
+            n_inst += subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout.count("__device_stub__")
+        except OSError:
+            pass
+    print(f"libvfm_hip.so: {len(jobs)} of {len(objs)} translation units compiled, {n_inst} kernel instances", file=sys.stderr)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -53,7 +53,6 @@ namespace {
 #include "vfm_reduce.hpp"
 #include "vfm_small_kernels.hpp"
 #include "vfm_heavy.hpp"
-#include "vfm_shard.hpp"
 #include "vfm_adam.hpp"
 
 // ---------------------------------------------------------------------------------------
@@ -64,7 +63,7 @@ bool pick_shape(int d, Shape* s) {
   if (d % 4 == 0) {
     const int C = d / 4;
     s->vec = 4;
-    s->lpe = pow2ceil(C) < 64 ? pow2ceil(C) : 64;
+    s->lpe = pow2ceil(C) < 64 ? (pow2ceil(C) < 4 ? 4 : pow2ceil(C)) : 64;      // (d = 4, 8: the 4-lane shape, idle lanes)
     const int cpl = (C + s->lpe - 1) / s->lpe;
     s->cpl = cpl <= 1 ? 1 : (cpl <= 2 ? 2 : 4);
     return cpl <= 4;
@@ -76,8 +75,18 @@ bool pick_shape(int d, Shape* s) {
   return d <= 256;
 }
 
+// a struct built against another layout is refused, not read past its end (VFM_STRUCT_INIT in include/vfm_hip.h)
+int check_struct(uint32_t size, uint32_t abi, size_t want, const char* name) {
+  if (size == (uint32_t)want && abi == (uint32_t)VFM_ABI_VERSION) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: struct_size %u / abi_version %u, this library expects %zu / %d (set them with "
+           "VFM_STRUCT_INIT; a binding generated from another version of include/vfm_hip.h must be regenerated)",
+           name, size, abi, want, VFM_ABI_VERSION);
+  return VFM_E_INVALID;
+}
+
 int check_problem(const vfm_problem_t* p, bool dev_ok = false) {
   if (!p) return fail(VFM_E_INVALID, "problem is NULL");
+  if (int rc = check_struct(p->struct_size, p->abi_version, sizeof(vfm_problem_t), "vfm_problem_t")) return rc;
   if (p->dev_step && !dev_ok)
     return fail(VFM_E_UNSUPPORTED, "vfm_problem_t.dev_step: only the training forward and the fused backward+Adam entry points read the step from device memory");
   if (p->dev_step && p->n_samples != 1) return fail(VFM_E_UNSUPPORTED, "vfm_problem_t.dev_step: one variational sample");
@@ -91,19 +100,18 @@ int check_problem(const vfm_problem_t* p, bool dev_ok = false) {
     return fail(VFM_E_INVALID, "unknown likelihood");
   if (p->n_samples < 1 || p->n_samples > MAX_SAMPLES) return fail(VFM_E_INVALID, "n_samples out of range [1,64]");
   if (p->n_samples > 1 && (p->step >> 48) != 0) return fail(VFM_E_INVALID, "step must stay below 2^48 when n_samples > 1");
-  if (p->n_samples > 1 && (p->flags & VFM_FLAG_ZPRE)) return fail(VFM_E_UNSUPPORTED, "n_samples > 1 with VFM_FLAG_ZPRE (entity-sharded mode)");
   if (p->B_global < p->B) return fail(VFM_E_INVALID, "B_global < B");
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
   if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
-  if (p->own_mod > 1 && (p->own_rank < 0 || p->own_rank >= p->own_mod)) return fail(VFM_E_INVALID, "bad ownership (own_rank, own_mod)");
-  if (p->coord_off < 0 || (p->coord_off & 7) != 0) return fail(VFM_E_INVALID, "coord_off must be a non-negative multiple of 8");
-  if (p->coord_off != 0 && (p->d & 3) != 0) return fail(VFM_E_INVALID, "coord_off needs d % 4 == 0");
-  if ((p->flags & VFM_FLAG_PARTIAL_PRED) && (p->n_samples != 1 || (p->flags & VFM_FLAG_ZPRE)))
-    return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_PARTIAL_PRED needs n_samples == 1 and no VFM_FLAG_ZPRE");
+  if (p->flags & ~(VFM_FLAG_NO_PRIOR_TERMS | VFM_FLAG_EPS_ZERO | VFM_FLAG_SPARSE_ADAM | VFM_FLAG_LINK_SOFTPLUS |
+                   VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_ROWS_TOUCHED | VFM_FLAG_ZREC))
+    return fail(VFM_E_INVALID, "unknown bit in vfm_problem_t.flags");
   Shape s;
   if (!pick_shape(p->d, &s)) return fail(VFM_E_UNSUPPORTED, "embedding size d not supported (d%4==0: d<=1024, else d<=256)");
   return 0;
 }
+
+bool softplus(const vfm_problem_t* p) { return (p->flags & VFM_FLAG_LINK_SOFTPLUS) != 0; }
 
 // the multi-rank stages exchange single-sample statistics
 int single_sample_only(const vfm_problem_t* p, const char* who) {
@@ -112,12 +120,10 @@ int single_sample_only(const vfm_problem_t* p, const char* who) {
   return VFM_E_UNSUPPORTED;
 }
 
-bool softplus(const vfm_problem_t* p) { return (p->flags & VFM_FLAG_LINK_SOFTPLUS) != 0; }
 
 // eps source of a call: VFM_FLAG_EPS_ZERO > tables > Philox
 int eps_mode(const vfm_problem_t* p, const float* ee, const float* eb, const float* eg, int* mode) {
   const int neps = (ee != nullptr) + (eb != nullptr) + (eg != nullptr);
-  if ((p->flags & VFM_FLAG_ZPRE) && neps <= 1 && (neps == 0 || eg)) { *mode = EPS_ZPRE; return 0; }
   if (neps != 0 && neps != 3) return fail(VFM_E_INVALID, "give all three eps tables or none");
   *mode = (p->flags & VFM_FLAG_EPS_ZERO) ? EPS_ZERO : (neps == 3 ? EPS_TABLE : EPS_PHILOX);
   return 0;
@@ -137,13 +143,12 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
   }
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.lik = p->likelihood;
   a.e_lo = p->e_lo; a.e_hi = (p->e_hi > 0 && p->e_hi < p->T) ? p->e_hi : p->T;
-  a.own_mod = p->own_mod > 1 ? p->own_mod : 1; a.own_rank = p->own_mod > 1 ? p->own_rank : 0;
   a.id64 = p->id_bits == 64; a.G = p->F; a.flags = p->flags;
   a.ll_scale_d = (double)p->nb_train / ((double)(p->B_global > 0 ? p->B_global : 1) * (double)p->n_samples);
   a.ll_scale = (float)a.ll_scale_d;
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
   a.key.step_lo = (uint32_t)p->step; a.key.step_hi = (uint32_t)(p->step >> 32);
-  a.key.chunk_off = (uint32_t)(p->coord_off / 4);
+  a.key.chunk_off = 0;
   a.x = x; a.y = y; a.entity = entity; a.bias = bias; a.inv_occ = inv_occ; a.scalars = scalars;
   a.W = W; a.eps_entity = ee; a.eps_bias = eb; a.eps_global = eg;
   a.dev = p->dev_step; a.wrec = p->wrec;
@@ -158,8 +163,7 @@ KArgs make_args(const vfm_problem_t* p, const void* x, const float* y, const flo
 bool use_fwd2(const vfm_problem_t* p, int eps, bool multi = false) {
   if (p->F != 2 || (p->d & 3) != 0 || p->d > 512) return false;
   if (multi ? (p->n_samples < 2 || p->n_samples > 4 || eps == EPS_ZERO) : p->n_samples != 1) return false;
-  if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS)) return false;
-  if (eps == EPS_ZPRE) return false;
+  if (softplus(p)) return false;          // (the softplus link runs through the general kernel: vfm_args.hpp)
   // below d = 20 a lane group is two lanes wide and the row-parallel k_fwd is the faster kernel (d = 16, 800 K rows:
   // 46.6 vs 60.1 us; from d = 20 on k_fwd2 wins: 17.7 vs 20.8 at d = 20, 40.2 vs 43.2 at d = 128).  VFM_FWD_KERNEL=2
   // forces k_fwd2 wherever it is defined, =1 k_fwd (A/B runs, tests); the record gather always runs in k_fwd2.
@@ -173,30 +177,41 @@ bool use_fwd2(const vfm_problem_t* p, int eps, bool multi = false) {
 // the multi-rank forms (slots / partial row values / no first-order weights) stay with k_fwd; VFM_FWD_KERNEL=1 forces it.
 bool use_fwdg(const vfm_problem_t* p, int eps, int mode) {
   if (p->F == 2 || (p->d & 3) != 0 || p->d < 16 || p->d > 512 || p->n_samples != 1) return false;
-  if (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_PARTIAL_PRED | VFM_FLAG_NO_BIAS | VFM_FLAG_ZREC)) return false;
+  if ((p->flags & VFM_FLAG_ZREC) || softplus(p)) return false;
   if (!(eps == EPS_PHILOX || (eps == EPS_ZERO && mode == MODE_PREDICT))) return false;
-  if (p->coord_off != 0) return false;
   return env_int("VFM_FWD_KERNEL", 0) != 1;
 }
 
 int dispatch_fwd(const vfm_problem_t* p, const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,
                  hipStream_t st) {
-  if (use_fwdg(p, eps, mode)) return softplus(p) ? launch_fwdg_softplus(eps, mode, a, o, st) : launch_fwdg_abs(eps, mode, a, o, st);
+  if (use_fwdg(p, eps, mode)) return launch_fwdg_abs(eps, mode, a, o, st);
   if (use_fwd2(p, eps)) {
     // VFM_FWD_AB_NORNG=1 (profiling only, wrong results): eps = 0 in the training forward, i.e. the kernel
     // without its Philox / Box-Muller arithmetic
     if (mode == MODE_TRAIN && eps == EPS_PHILOX && env_int("VFM_FWD_AB_NORNG", 0) == 1) eps = EPS_ZERO;
-    return softplus(p) ? launch_fwd2_softplus(eps, mode, a, o, st) : launch_fwd2_abs(eps, mode, a, o, st);
+    return launch_fwd2_abs(eps, mode, a, o, st);
   }
   return softplus(p) ? launch_fwd_softplus(s, eps, mode, ff, a, o, st) : launch_fwd_abs(s, eps, mode, ff, a, o, st);
 }
 int dispatch_bwd(const vfm_problem_t* p, const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,
                  const AdamArgs& ad, hipStream_t st) {
-  return softplus(p) ? launch_bwd_softplus(s, eps, adam, a, b, ad, st) : launch_bwd_abs(s, eps, adam, a, b, ad, st);
+  // (the gradient / statistics forms and the fused-Adam forms sit in two translation units per link: vfm_bwd.hip)
+  if (adam == 0 || adam == 10)
+    return softplus(p) ? launch_bwd0_softplus(s, eps, adam, a, b, ad, st) : launch_bwd0_abs(s, eps, adam, a, b, ad, st);
+  return softplus(p) ? launch_bwd1_softplus(s, eps, adam, a, b, ad, st) : launch_bwd1_abs(s, eps, adam, a, b, ad, st);
+}
+
+// what every backward-family launch starts from: the index, the bounds of what it may name, its status word
+BwdArgs bwd_args(const vfm_problem_t* p, const vfm_index_t* idx) {
+  BwdArgs b;
+  memset(&b, 0, sizeof(b));
+  if (idx) { b.occ_ptr = idx->occ_ptr; b.occ_rows = idx->occ_rows; b.status = idx->status; }
+  b.n_occ = (int32_t)(p->B * (int64_t)p->F);
+  return b;
 }
 
 template <int LPE, int CPL, int VEC>
-int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow, float* hacc, int d,
+int launch_heavy_t(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz, const float* grow, float* hacc, int d,
                    hipStream_t st, const float* zrec = nullptr) {
   constexpr int GPB = BLOCK / LPE;
   const size_t xs = 4 + (((size_t)d + 3) & ~(size_t)3);
@@ -204,7 +219,8 @@ int launch_heavy_t(const vfm_index_t* idx, const float* sumz, const float* grow,
   int64_t nb = ((int64_t)idx->n_items + GPB - 1) / GPB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL((k_heavy<LPE, CPL, VEC>), dim3((unsigned)nb), dim3(BLOCK), 0, st, idx->heavy_items,
-                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec, hacc);
+                     (int)idx->n_items, idx->occ_rows, sumz, grow, item_acc, d, zrec ? idx->occ_other : nullptr, zrec, hacc,
+                     (int)idx->n_heavy, (int)(p->B * (int64_t)p->F), (int)p->B, p->T, idx->status);
   if (idx->max_items > 0 && idx->max_items <= VFM_HEAVY_DIRECT) return 0;      // (every entity's items are added by the main kernel)
   nb = idx->n_heavy;                                             // one workgroup per heavy entity
   if (nb > 4096) nb = 4096;
@@ -220,6 +236,8 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
   if (idx->n_heavy <= 0 || idx->n_items <= 0) return 0;
   if (!idx->heavy_ids || !idx->heavy_items || !idx->heavy_acc)
     return fail(VFM_E_INVALID, "index: heavy_ids / heavy_items / heavy_acc missing");
+  if ((int64_t)idx->n_heavy > p->T || (int64_t)idx->n_items > p->B * (int64_t)p->F + idx->n_heavy)
+    return fail(VFM_E_INVALID, "index: more heavy entities than table rows, or more work items than occurrences");
   const size_t xs = 4 + (((size_t)p->d + 3) & ~(size_t)3);
   const size_t per_sample = xs * ((size_t)idx->n_heavy + (size_t)idx->n_items);   // records of one sample
   Shape s;
@@ -228,7 +246,7 @@ int run_heavy(const vfm_problem_t* p, const vfm_index_t* idx, const float* sumz,
     const float* sz = sumz ? sumz + (size_t)sm * (size_t)p->B * (size_t)p->d : nullptr;
     float* hacc = idx->heavy_acc + (size_t)sm * per_sample;
 #define X(L_, C_, V_) \
-    if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(idx, sz, grow, hacc, p->d, st, zrec);
+    if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) launch_heavy_t<L_, C_, V_>(p, idx, sz, grow, hacc, p->d, st, zrec);
     VFM_FOR_SHAPES(X)
 #undef X
   }
@@ -292,8 +310,14 @@ int bwd_adam_overlapped(const vfm_problem_t* p, const vfm_index_t* idx, const Sh
 }
 
 int check_index(const vfm_problem_t* p, const vfm_index_t* idx, const char* who) {
-  if (!idx || !idx->occ_ptr || (p->B > 0 && !idx->occ_rows)) {
+  if (!idx) { snprintf(g_err, sizeof(g_err), "%s: inverted index missing", who); return VFM_E_INVALID; }
+  if (int rc = check_struct(idx->struct_size, idx->abi_version, sizeof(vfm_index_t), "vfm_index_t")) return rc;
+  if (!idx->occ_ptr || (p->B > 0 && !idx->occ_rows)) {
     snprintf(g_err, sizeof(g_err), "%s: inverted index missing", who);
+    return VFM_E_INVALID;
+  }
+  if (idx->n_heavy < 0 || idx->n_items < 0 || idx->n_touched < 0 || idx->max_items < 0) {
+    snprintf(g_err, sizeof(g_err), "%s: negative count in vfm_index_t", who);
     return VFM_E_INVALID;
   }
   return 0;
@@ -341,6 +365,18 @@ int scaled_moment_consts(const vfm_problem_t* p, float beta1, float beta2, int64
 }  // namespace vfm
 
 using namespace vfm;
+
+// the stand-alone batch normalisers (vfm_batch_norms; vfm_build_index with more than four fields)
+int vfm::launch_norms(int64_t B, int F, int64_t T, int id_bits, const void* x, const float* inv_occ, double* W, hipStream_t st) {
+  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, F);      // (all-zero bits: 0.0 and integer 0)
+  if (B == 0) return after_launch("vfm_batch_norms");                  // empty shard: W = 0
+  int64_t nbx = (B + BLOCK * 8 - 1) / (BLOCK * 8);
+  if (nbx > 1024) nbx = 1024;
+  hipLaunchKernelGGL(k_norms, dim3((unsigned)nbx, (unsigned)F), dim3(BLOCK), 0, st, x, (int)(id_bits == 64), inv_occ, B, F, T,
+                     reinterpret_cast<unsigned long long*>(W));
+  hipLaunchKernelGGL(k_norms_fix, dim3(1), dim3(64), 0, st, W, F);
+  return after_launch("vfm_batch_norms");
+}
 
 extern "C" {
 
@@ -391,15 +427,7 @@ int vfm_batch_norms(const vfm_problem_t* p, const void* x, const float* inv_occ,
                     void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!W || (p->B > 0 && (!x || !inv_occ))) return fail(VFM_E_INVALID, "vfm_batch_norms: NULL pointer");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st, W, (int)p->F);      // (all-zero bits: 0.0 and integer 0)
-  if (p->B == 0) return after_launch("vfm_batch_norms");                        // empty shard: W = 0
-  int64_t nbx = (p->B + BLOCK * 8 - 1) / (BLOCK * 8);
-  if (nbx > 1024) nbx = 1024;
-  hipLaunchKernelGGL(k_norms, dim3((unsigned)nbx, (unsigned)p->F), dim3(BLOCK), 0, st, x, (int)(p->id_bits == 64),
-                     inv_occ, p->B, (int)p->F, p->T, reinterpret_cast<unsigned long long*>(W));
-  hipLaunchKernelGGL(k_norms_fix, dim3(1), dim3(64), 0, st, W, (int)p->F);
-  return after_launch("vfm_batch_norms");
+  return launch_norms(p->B, p->F, p->T, p->id_bits, x, inv_occ, W, (hipStream_t)stream);
 }
 
 int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
@@ -409,39 +437,32 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
                      float* pred, double* partials, float* sumz, float* grow, void* stream) {
   if (int rc = check_problem(p, true)) return rc;
   if (!partials) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: partials is NULL");
-  if (p->dev_step && (eps_entity || eps_bias || eps_global || (p->flags & (VFM_FLAG_ZPRE | VFM_FLAG_EPS_ZERO))))
+  if (p->dev_step && (eps_entity || eps_bias || eps_global || (p->flags & VFM_FLAG_EPS_ZERO)))
     return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: dev_step goes with the in-kernel Philox eps stream only");
   hipStream_t st0 = (hipStream_t)stream;
   if (p->B == 0) {  // empty shard (a rank without rows): zero sums, zero blocks; buffers may be NULL
     hipLaunchKernelGGL(k_zero_f64, dim3(1), dim3(64), 0, st0, partials, (int)VFM_N_PARTIALS);
     return after_launch("vfm_elbo_fwd_f32");
   }
-  const bool zpre = (p->flags & VFM_FLAG_ZPRE) != 0;
   const bool zrec = (p->flags & VFM_FLAG_ZREC) != 0;
   if (zrec) {       // the forward of the software-pipelined step: a gather of this step's sample records
-    if (!use_fwd2(p, EPS_ZREC)) return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_ZREC: two fields, one sample, d % 4 == 0, d <= 512, no other mode flag");
+    if (!use_fwd2(p, EPS_ZREC)) return fail(VFM_E_UNSUPPORTED, "VFM_FLAG_ZREC: two fields, one sample, d % 4 == 0, d <= 512, |.| link");
     if (!x || !y || !entity_params || !scalars || !pred || !grow || eps_entity || eps_bias || eps_global)
       return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32 (VFM_FLAG_ZREC): x, y, the record table, scalars, pred, grow; no eps tables");
     KArgs a = make_args(p, x, y, entity_params, nullptr, nullptr, scalars, nullptr, nullptr, nullptr, nullptr, 0);
     FwdOut o{pred, partials, nullptr, grow};
-    if (int rc = softplus(p) ? launch_fwd2_softplus(EPS_ZREC, MODE_TRAIN, a, o, (hipStream_t)stream)
-                             : launch_fwd2_abs(EPS_ZREC, MODE_TRAIN, a, o, (hipStream_t)stream))
-      return rc;
+    if (int rc = launch_fwd2_abs(EPS_ZREC, MODE_TRAIN, a, o, (hipStream_t)stream)) return rc;
     return after_launch("vfm_elbo_fwd_f32");
   }
-  if (!x || !entity_params || (!bias_params && !zpre) || !scalars || !pred)
+  if (!x || !entity_params || !bias_params || !scalars || !pred)
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: NULL pointer");
   const bool train = y != nullptr;
-  if (train && (((!inv_occ || !W) && !zpre) || !sumz || !grow))
+  if (train && (!inv_occ || !W || !sumz || !grow))
     return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: y given, so inv_occ, W, sumz and grow are required");
-  if (zpre && !train) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_ZPRE needs y (training forward)");
-  if ((p->flags & VFM_FLAG_PARTIAL_PRED) && !train)
-    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_PARTIAL_PRED needs y (training forward)");
   if (!train && (sumz || grow)) return fail(VFM_E_INVALID, "vfm_elbo_fwd_f32: sumz / grow need y");
   int eps;
   if (int rc = eps_mode(p, eps_entity, eps_bias, eps_global, &eps)) return rc;
   if (train && eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_fwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
-  if (zpre) eps = EPS_ZPRE;
   hipStream_t st = (hipStream_t)stream;
   FwdOut o{pred, partials, sumz, grow};
   Shape s;
@@ -449,7 +470,7 @@ int vfm_elbo_fwd_f32(const vfm_problem_t* p, const void* x, const float* y,
   if (use_fwd2(p, eps, true)) {        // two fields, 2..4 samples: ONE launch, the sample loop runs inside the kernel
     KArgs a = make_args(p, x, y, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias, eps_global, 0);
     const int md = train ? MODE_TRAIN : MODE_PREDICT;
-    if (int rc = softplus(p) ? launch_fwd2m_softplus(eps, md, a, o, st) : launch_fwd2m_abs(eps, md, a, o, st)) return rc;
+    if (int rc = launch_fwd2m_abs(eps, md, a, o, st)) return rc;
     return after_launch("vfm_elbo_fwd_f32");
   }
   for (int sm = 0; sm < p->n_samples; ++sm) {      // one launch per variational sample (vfm_fwd.hpp)
@@ -487,8 +508,9 @@ int vfm_elbo_bwd_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), grad_out, g_entity, g_bias,
-            g_scalars, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  BwdArgs b = bwd_args(p, idx);
+  b.sumz = sumz; b.grow = grow; b.partials = const_cast<double*>(partials); b.grad_out = grad_out;
+  b.g_entity = g_entity; b.g_bias = g_bias; b.g_scalars = g_scalars;
   if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad;
   memset(&ad, 0, sizeof(ad));
@@ -510,19 +532,16 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (int rc = check_problem(p, true)) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_f32")) return rc;
   if (p->dev_step) {      // replayable step: lr / betas / step come from the device table (the host values are ignored)
-    if (p->flags & (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_SPARSE_ADAM) || eps_entity || eps_bias || eps_global)
-      return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: dev_step excludes VFM_FLAG_ROWS_UNTOUCHED, VFM_FLAG_SPARSE_ADAM and eps tables");
+    if ((p->flags & VFM_FLAG_SPARSE_ADAM) || eps_entity || eps_bias || eps_global)
+      return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: dev_step excludes VFM_FLAG_SPARSE_ADAM and eps tables");
     step = 1; lr = 0.f;
   }
-  const int rows_flags = p->flags & (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED);
-  if (rows_flags == (VFM_FLAG_ROWS_UNTOUCHED | VFM_FLAG_ROWS_TOUCHED))
-    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: VFM_FLAG_ROWS_UNTOUCHED and VFM_FLAG_ROWS_TOUCHED exclude each other");
+  const int rows_flags = p->flags & VFM_FLAG_ROWS_TOUCHED;
   if (rows_flags && (p->flags & VFM_FLAG_SPARSE_ADAM))
-    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: the row filters do not combine with VFM_FLAG_SPARSE_ADAM");
-  const bool untouched_only = rows_flags == VFM_FLAG_ROWS_UNTOUCHED;     // pure Adam decay: no forward state needed
+    return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: VFM_FLAG_ROWS_TOUCHED does not combine with VFM_FLAG_SPARSE_ADAM");
   if (!entity_params || !bias_params || !scalars || !m_entity ||
       !v_entity || !m_bias || !v_bias || !m_scalars || !v_scalars || step < 1 ||
-      (!untouched_only && (!inv_occ || !W || !partials || (p->B > 0 && (!sumz || !grow)))))
+      !inv_occ || !W || !partials || (p->B > 0 && (!sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: bad argument");
   if (p->flags & VFM_FLAG_NO_PRIOR_TERMS)
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_f32: single-rank only (gradients never leave the kernel)");
@@ -531,11 +550,11 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity,
                       eps_bias, eps_global);
-  a.row_filter = untouched_only ? 1 : (rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0);
-  BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
-  Side* sd = (!untouched_only && !(p->flags & VFM_FLAG_SPARSE_ADAM) && heavy_overlap(p, idx)) ? side_of_device() : nullptr;
-  if (!untouched_only && !sd)
+  a.row_filter = rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0;
+  BwdArgs b = bwd_args(p, idx);
+  b.sumz = sumz; b.grow = grow; b.partials = partials; b.loss = loss;
+  Side* sd = (!(p->flags & VFM_FLAG_SPARSE_ADAM) && heavy_overlap(p, idx)) ? side_of_device() : nullptr;
+  if (!sd)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
   adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
@@ -543,7 +562,7 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   Shape s;
   pick_shape(p->d, &s);
   int adam = (p->flags & VFM_FLAG_SPARSE_ADAM) ? 2 : 1;
-  if (rows_flags == VFM_FLAG_ROWS_TOUCHED && idx->touched_ids && idx->n_touched >= 0 && env_int("VFM_ROWS_LIST", 1) != 0) {
+  if (rows_flags == VFM_FLAG_ROWS_TOUCHED && idx->touched_ids && idx->n_touched <= p->T && env_int("VFM_ROWS_LIST", 1) != 0) {
     // the rows of the batch as a LIST (lazy exact Adam): the kernel walks it instead of scanning all T rows -- the
     // same instance as the dense step, so both agree bit for bit on the rows they share
     b.row_ids = idx->touched_ids; b.n_rows = idx->n_touched;
@@ -568,8 +587,8 @@ static int bwd_acc_impl(const vfm_problem_t* p, const vfm_index_t* idx, const in
   if (!partials || !acc || !sums || (p->B > 0 && (!sumz || !grow)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_f32: NULL pointer");
   KArgs a = make_args(p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, const_cast<double*>(partials), nullptr, nullptr, nullptr,
-            nullptr, nullptr, acc, sums, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  BwdArgs b = bwd_args(p, idx);
+  b.sumz = sumz; b.grow = grow; b.partials = const_cast<double*>(partials); b.acc = acc; b.sums = sums;
   if (row_ids) {        // the listed rows only, their records written COMPACTLY (record i <-> row_ids[i])
     if (n_rows < 0 || n_rows > p->T || p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T))
       return fail(VFM_E_INVALID, "vfm_elbo_bwd_acc_rows_f32: 0 <= n_rows <= T, whole entity range");
@@ -610,9 +629,8 @@ static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float
                            const double* W, const float* eps_entity, const float* eps_bias,
                            const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                            float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                           float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
-                           const int32_t* rec_pos, const int32_t* row_ids, int64_t n_rows, int32_t compact, void* stream,
-                           const char* who) {
+                           float beta2, float eps_adam, int64_t step, const int32_t* row_ids, int64_t n_rows,
+                           int32_t compact, void* stream, const char* who) {
   if (int rc = check_problem(p)) return rc;
   if (int rc = single_sample_only(p, who)) return rc;
   if (!acc || !sums || !entity_params || !bias_params || !scalars || !inv_occ || !W || !m_entity ||
@@ -623,15 +641,10 @@ static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float
   if (eps == EPS_ZERO) return fail(VFM_E_UNSUPPORTED, "vfm_elbo_apply_adam_f32: VFM_FLAG_EPS_ZERO is prediction-only");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, eps_entity, eps_bias,
                       eps_global);
-  if (rec_pos != nullptr && rec_ptr == nullptr)      // (rec_pos may be NULL when rec_ptr lists no record at all)
-    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: rec_pos without rec_ptr");
-  BwdArgs b{rec_ptr, rec_pos, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-            const_cast<float*>(acc), const_cast<float*>(sums), nullptr, nullptr, 0, 0, kl_ws, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
-  if (kl_ws && (p->e_lo != 0 || (p->e_hi != 0 && p->e_hi != p->T && p->own_mod <= 1)))
-    return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_f32: kl_ws needs a single launch over the whole range");
+  BwdArgs b = bwd_args(p, nullptr);
+  b.acc = const_cast<float*>(acc); b.sums = const_cast<float*>(sums);
   if (row_ids) {
-    if (rec_ptr || p->own_mod > 1 || n_rows < 0 || n_rows > p->T)
-      return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: a row list excludes the gather form and entity sharding; 0 <= n_rows <= T");
+    if (n_rows < 0 || n_rows > p->T) return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: 0 <= n_rows <= T");
     b.row_ids = row_ids; b.n_rows = n_rows; b.rec_by_slot = compact ? 1 : 0;
   }
   AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
@@ -643,7 +656,6 @@ static int apply_adam_impl(const vfm_problem_t* p, const float* acc, const float
   Shape s;
   pick_shape(p->d, &s);
   if (int rc = dispatch_bwd(p, s, eps, 11, a, b, ad, (hipStream_t)stream)) return rc;
-  if (kl_ws) hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(BLOCK), 0, (hipStream_t)stream, kl_ws);
   return after_launch(who);
 }
 
@@ -652,11 +664,10 @@ int vfm_elbo_apply_adam_f32(const vfm_problem_t* p, const float* acc, const floa
                             const double* W, const float* eps_entity, const float* eps_bias,
                             const float* eps_global, float* m_entity, float* v_entity, float* m_bias,
                             float* v_bias, float* m_scalars, float* v_scalars, float lr, float beta1,
-                            float beta2, float eps_adam, int64_t step, double* kl_ws, const int32_t* rec_ptr,
-                            const int32_t* rec_pos, void* stream) {
+                            float beta2, float eps_adam, int64_t step, void* stream) {
   return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, eps_entity, eps_bias, eps_global,
-                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, kl_ws,
-                         rec_ptr, rec_pos, nullptr, 0, 0, stream, "vfm_elbo_apply_adam_f32");
+                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step,
+                         nullptr, 0, 0, stream, "vfm_elbo_apply_adam_f32");
 }
 
 int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const float* sums, const int32_t* row_ids,
@@ -667,58 +678,9 @@ int vfm_elbo_apply_adam_rows_f32(const vfm_problem_t* p, const float* acc, const
   if (!row_ids && n_rows != 0) return fail(VFM_E_INVALID, "vfm_elbo_apply_adam_rows_f32: row_ids is NULL");
   static const int32_t none = 0;
   return apply_adam_impl(p, acc, sums, entity_params, bias_params, scalars, inv_occ, W, nullptr, nullptr, nullptr,
-                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step, nullptr,
-                         nullptr, nullptr, row_ids ? row_ids : &none, n_rows, compact_records, stream,
+                         m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, lr, beta1, beta2, eps_adam, step,
+                         row_ids ? row_ids : &none, n_rows, compact_records, stream,
                          "vfm_elbo_apply_adam_rows_f32");
-}
-
-int vfm_shard_sample_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n, const float* entity_params,
-                         const float* bias_params, const float* eps_entity, const float* eps_bias, float* out,
-                         void* stream) {
-  if (int rc = check_problem(p)) return rc;
-  if (int rc = single_sample_only(p, "vfm_shard_sample_f32")) return rc;
-  if (n < 0 || n > 0x7FFFFFFFLL || (n > 0 && (!ids || !entity_params || !bias_params || !out)))
-    return fail(VFM_E_INVALID, "vfm_shard_sample_f32: bad argument");
-  if ((eps_entity == nullptr) != (eps_bias == nullptr))
-    return fail(VFM_E_INVALID, "vfm_shard_sample_f32: give both eps tables or none");
-  if (n == 0) return 0;
-  KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, nullptr, nullptr, nullptr, eps_entity,
-                      eps_bias, nullptr);
-  Shape s;
-  pick_shape(p->d, &s);
-  hipStream_t st = (hipStream_t)stream;
-  const int em = eps_entity ? EPS_TABLE : EPS_PHILOX;
-  if (int rc = softplus(p) ? launch_sample_softplus(s, em, a, ids, (int)n, out, st)
-                           : launch_sample_abs(s, em, a, ids, (int)n, out, st))
-    return rc;
-  return after_launch("vfm_shard_sample_f32");
-}
-
-int vfm_records_add_f32(float* dst, const int32_t* idx, const float* src, int64_t n, int32_t d, int32_t atomic,
-                        void* stream) {
-  if (n < 0 || d < 1 || (n > 0 && (!dst || !idx || !src))) return fail(VFM_E_INVALID, "vfm_records_add_f32: bad argument");
-  if (n == 0) return 0;
-  const int xs4 = 1 + (d + 3) / 4;
-  int64_t nb = (n * xs4 * (atomic ? 4 : 1) + BLOCK - 1) / BLOCK;
-  if (nb > 4096) nb = 4096;
-  if (atomic)
-    hipLaunchKernelGGL(k_records_add_atomic, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n,
-                       4 * xs4);
-  else
-    hipLaunchKernelGGL(k_records_add, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, dst, idx, src, n, xs4);
-  return after_launch("vfm_records_add_f32");
-}
-
-int vfm_shard_pack_f32(float* small, const float* loss_local, const double* kl_ws, void* stream) {
-  if (!small || !loss_local || !kl_ws) return fail(VFM_E_INVALID, "vfm_shard_pack_f32: NULL pointer");
-  hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, (hipStream_t)stream, small, loss_local, kl_ws);
-  return after_launch("vfm_shard_pack_f32");
-}
-
-int vfm_shard_loss_f32(const float* small, float* loss3, void* stream) {
-  if (!small || !loss3) return fail(VFM_E_INVALID, "vfm_shard_loss_f32: NULL pointer");
-  hipLaunchKernelGGL(k_shard_loss, dim3(1), dim3(64), 0, (hipStream_t)stream, small, loss3);
-  return after_launch("vfm_shard_loss_f32");
 }
 
 int vfm_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
@@ -742,16 +704,14 @@ int vfm_sample_records_f32(const vfm_problem_t* p, const int32_t* ids, int64_t n
                            const float* bias_params, const float* inv_occ, const double* W, float* zrec, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (int rc = single_sample_only(p, "vfm_sample_records_f32")) return rc;
-  if ((p->d & 3) != 0) return fail(VFM_E_UNSUPPORTED, "vfm_sample_records_f32: d % 4 == 0");
+  if ((p->d & 3) != 0 || softplus(p)) return fail(VFM_E_UNSUPPORTED, "vfm_sample_records_f32: d % 4 == 0, |.| link");
   if (n < 0 || n > 0x7FFFFFFFLL || (n > 0 && (!ids || !entity_params || !bias_params || !inv_occ || !W || !zrec)))
     return fail(VFM_E_INVALID, "vfm_sample_records_f32: bad argument");
   if (n == 0) return 0;
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, nullptr, W, nullptr, nullptr, nullptr);
   Shape s;
   pick_shape(p->d, &s);
-  if (int rc = softplus(p) ? launch_sample_rec_softplus(s, a, ids, (int)n, zrec, (hipStream_t)stream)
-                           : launch_sample_rec_abs(s, a, ids, (int)n, zrec, (hipStream_t)stream))
-    return rc;
+  if (int rc = launch_sample_rec_abs(s, a, ids, (int)n, zrec, (hipStream_t)stream)) return rc;
   return after_launch("vfm_sample_records_f32");
 }
 
@@ -768,9 +728,11 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
   if (p->F != 2 || (p->d & 3) != 0 || p->d > 512)
     return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: two fields, d % 4 == 0, d <= 512");
-  if (p->flags & ~(VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_LINK_SOFTPLUS))
-    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: only VFM_FLAG_SCALED_MOMENTS / VFM_FLAG_LINK_SOFTPLUS");
-  if (!pipe || !pipe->zrec || (p->B > 0 && !idx->occ_other) ||
+  if (p->flags & ~VFM_FLAG_SCALED_MOMENTS)
+    return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: only VFM_FLAG_SCALED_MOMENTS (the record step exists for the |.| link)");
+  if (!pipe) return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: pipe is NULL");
+  if (int rc = check_struct(pipe->struct_size, pipe->abi_version, sizeof(vfm_pipe_t), "vfm_pipe_t")) return rc;
+  if (!pipe->zrec || (p->B > 0 && !idx->occ_other) ||
       (pipe->zrec_next && (!pipe->next_occ_ptr || !pipe->next_W)))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: pipe / idx->occ_other incomplete");
   if (pipe->last_step) {      // look-ahead form
@@ -783,8 +745,8 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
       !v_scalars || step < 1 || !inv_occ || !W || !partials || (p->B > 0 && !grow))
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: bad argument");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
-  BwdArgs b{idx->occ_ptr, idx->occ_rows, nullptr, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  BwdArgs b = bwd_args(p, idx);
+  b.grow = grow; b.partials = partials; b.loss = loss;
   if (int rc = run_heavy(p, idx, nullptr, grow, (hipStream_t)stream, &b, pipe->zrec)) return rc;
   b.zrec = pipe->zrec; b.occ_other = idx->occ_other;
   b.zrec_next = pipe->zrec_next; b.next_occ_ptr = pipe->next_occ_ptr; b.next_W = pipe->next_W;
@@ -829,8 +791,8 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: the last step of a moment period is a dense one "
                                "(bring every row up to date, then vfm_elbo_bwd_adam_f32)");
   KArgs a = make_args(p, nullptr, nullptr, entity_params, bias_params, inv_occ, scalars, W, nullptr, nullptr, nullptr);
-  BwdArgs b{idx->occ_ptr, idx->occ_rows, sumz, grow, partials, nullptr, nullptr, nullptr, nullptr, loss, nullptr,
-            nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, {}, nullptr, nullptr, 0, 0};
+  BwdArgs b = bwd_args(p, idx);
+  b.sumz = sumz; b.grow = grow; b.partials = partials; b.loss = loss;
   Side* sd = heavy_overlap(p, idx) ? side_of_device() : nullptr;
   if (!sd)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;
@@ -891,21 +853,6 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
                        m_entity, v_entity, m_bias, v_bias, last_step, ids, n, (int)d, (int32_t)pstart, (int32_t)upto,
                        (int32_t)mark, eps_adam, tab, wrec);
   return after_launch("vfm_adam_catchup_f32");
-}
-
-int vfm_elbo_lik_f32(const vfm_problem_t* p, const float* y, const float* scalars, const float* eps_global,
-                     float* pred, float* grow, double* partials, void* stream) {
-  if (int rc = check_problem(p)) return rc;
-  if (int rc = single_sample_only(p, "vfm_elbo_lik_f32")) return rc;
-  if (!scalars || !pred || !partials || (p->B > 0 && (!y || !grow)))
-    return fail(VFM_E_INVALID, "vfm_elbo_lik_f32: NULL pointer");
-  KArgs a = make_args(p, nullptr, y, nullptr, nullptr, nullptr, scalars, nullptr, nullptr, nullptr, eps_global);
-  FwdOut o{pred, partials, nullptr, grow};
-  int64_t nb = (p->B + BLOCK - 1) / BLOCK;
-  if (nb > 1024) nb = 1024;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_lik, dim3((unsigned)nb), dim3(BLOCK), 0, (hipStream_t)stream, a, o);
-  return after_launch("vfm_elbo_lik_f32");
 }
 
 int vfm_moments_rescale_f32(float* m, float* v, int64_t n, float beta1, float beta2, int64_t step, int32_t to_scaled,

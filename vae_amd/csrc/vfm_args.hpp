@@ -2,10 +2,13 @@
 // units of libvfm_hip.so:
 //   vfm_abi.hip  C ABI (include/vfm_hip.h), argument checks, small / Adam / shard glue kernels, k_heavy
 //   vfm_fwd.hip  k_fwd instances + dispatch            (compiled once per link function, -DVFM_LINK=0|1)
-//   vfm_fwd2.hip k_fwd2 instances + dispatch           (two fields, task-stream form; once per link function)
-//   vfm_fwd2m.hip k_fwd2m instances + dispatch         (the same with 2..4 variational samples inside the kernel)
-//   vfm_fwdg.hip k_fwdg instances + dispatch           (general F, a row's fields split over lane groups; once per link)
-//   vfm_bwd.hip  k_bwd, k_sample instances + dispatch  (compiled once per link function)
+//   vfm_fwd2.hip k_fwd2 instances + dispatch           (two fields, task-stream form; |.| link)
+//   vfm_fwd2m.hip k_fwd2m instances + dispatch         (the same with 2..4 variational samples inside the kernel; |.| link)
+//   vfm_fwdg.hip k_fwdg instances + dispatch           (general F, a row's fields split over lane groups; |.| link)
+//   vfm_bwd.hip  k_bwd instances + dispatch            (compiled per link function and per family: -DVFM_BWD_PART=0 the
+//                                                       gradient / statistics forms, =1 the fused-Adam forms)
+// The softplus link (vfm-torch.py:125, overwritten by :126 in the reference itself) runs through the GENERAL kernels only
+// (k_fwd, k_bwd without the pipelined forms): the specialised forward kernels and the record step exist for |.|.
 // Splitting keeps every kernel family in its own object (built in parallel by vae_amd/build.py); a
 // kernel is always launched from the unit that defines it, so no relocatable device code is needed.
 #pragma once
@@ -32,10 +35,9 @@ struct RngKey {
 struct KArgs {
   int64_t B, T;
   int64_t e_lo, e_hi;   // entity range of a backward launch (chunked multi-rank pipeline)
-  int32_t own_mod, own_rank;   // entity-sharded apply: this rank owns e = own_rank (mod own_mod)
   int32_t F, d, lik, id64, G, flags;
   int32_t S, sample;    // variational samples: S of them; the forward runs one launch per sample
-  int32_t row_filter;   // fused backward+Adam: 0 all rows, 1 rows not in the batch only, 2 rows in the batch only,
+  int32_t row_filter;   // fused backward+Adam: 0 all rows, 2 rows in the batch only,
                         // 3 heavy entities only (listed), 4 all but the heavy entities
   float inv_S;
   float ll_scale;  // nb_train / (B_global * S)
@@ -84,7 +86,6 @@ struct BwdArgs {
   const float* heavy_acc;     // per sample: n_heavy entity records (sum grow, count, 0, 0 | A_e) [+ the work items' records]
   int32_t n_heavy;
   int32_t heavy_stride;       // records per sample in heavy_acc (n_heavy + n_items)
-  double* kl_slots;           // STAGE_APPLY: [0] = blocks, [1 + b] = block b's sum of c_e * KL_e (NULL: not wanted)
   // fused-Adam instances: the sorted ids of the rows to visit; NULL = scan all table rows.  The lazy exact-Adam
   // step (VFM_FLAG_ROWS_TOUCHED + vfm_index_t.touched_ids) walks this list.
   const int32_t* row_ids;
@@ -107,6 +108,10 @@ struct BwdArgs {
   // multi-rank stages with a row list: 1 = the statistics records form a COMPACT buffer, record i belongs to row_ids[i]
   // (what the compacted exchange all-reduces); 0 = records sit in the dense [T] table at the entity's own index
   int32_t rec_by_slot;
+  // bounds of what the index may name (a corrupted index is clamped, never followed): list lengths in [0, n_occ], row
+  // numbers in [0, B); `status` (device, may be NULL) counts the clamps that fired (vfm_index_t.status)
+  int32_t n_occ;
+  int32_t* status;
 };
 
 struct AdamArgs {
@@ -161,7 +166,7 @@ struct Shape {
   int lpe, cpl, vec;
 };
 
-enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZPRE = 3, EPS_ZREC = 4 };
+enum { EPS_PHILOX = 0, EPS_TABLE = 1, EPS_ZERO = 2, EPS_ZREC = 4 };
 enum { MODE_PREDICT = 0, MODE_TRAIN = 1 };
 enum { STAGE_FULL = 0, STAGE_ACC = 1, STAGE_APPLY = 2 };
 enum { LINK_ABS = 0, LINK_SOFTPLUS = 1 };
@@ -171,25 +176,30 @@ constexpr int MAX_SAMPLES = 64;
 VFM_INTERNAL int fail(int code, const char* msg);
 VFM_INTERNAL int fail_hip(hipError_t e, const char* where);
 VFM_INTERNAL int env_int(const char* name, int dflt);
+// W[f] = sum_r inv_occ[x[r,f]] with the stand-alone kernels (vfm_abi.hip)
+VFM_INTERNAL int launch_norms(int64_t B, int F, int64_t T, int id_bits, const void* x, const float* inv_occ, double* W,
+                              hipStream_t st);
 
-// per-link-function launchers (vfm_fwd.hip / vfm_bwd.hip, one object per link)
+// per-link-function launchers (vfm_fwd.hip / vfm_bwd.hip, one object per link; vfm_bwd.hip in two parts: `adam` 0 / 10
+// (gradients, statistics) in part 0, the fused-Adam forms 1 / 2 / 11 in part 1)
 #define VFM_DECLARE_LAUNCHERS(SUFFIX)                                                                          \
   VFM_INTERNAL int launch_fwd_##SUFFIX(const Shape& s, int eps, int mode, int ff, KArgs& a, const FwdOut& o,   \
                                        hipStream_t st);                                                        \
-  VFM_INTERNAL int launch_fwd2_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
-  VFM_INTERNAL int launch_fwd2m_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);         \
-  VFM_INTERNAL int launch_fwdg_##SUFFIX(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);          \
-  VFM_INTERNAL int launch_bwd_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,          \
-                                       const AdamArgs& ad, hipStream_t st);                                    \
-  VFM_INTERNAL int launch_sample_##SUFFIX(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n,        \
-                                          float* out, hipStream_t st);                                         \
-  VFM_INTERNAL int launch_sample_rec_##SUFFIX(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, \
-                                              hipStream_t st);
+  VFM_INTERNAL int launch_bwd0_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,         \
+                                        const AdamArgs& ad, hipStream_t st);                                   \
+  VFM_INTERNAL int launch_bwd1_##SUFFIX(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b,         \
+                                        const AdamArgs& ad, hipStream_t st);
 VFM_DECLARE_LAUNCHERS(abs)
 VFM_DECLARE_LAUNCHERS(softplus)
+// |.| link only: the specialised forward kernels and the record sampler of the pipelined step
+VFM_INTERNAL int launch_fwd2_abs(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);
+VFM_INTERNAL int launch_fwd2m_abs(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);
+VFM_INTERNAL int launch_fwdg_abs(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);
+VFM_INTERNAL int launch_sample_rec_abs(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st);
 
+// (d = 4 and d = 8 run the 4-lane shape with idle lanes: two instance families fewer in every kernel)
 #define VFM_FOR_SHAPES(X)                                                                      \
-  X(1, 1, 4) X(2, 1, 4) X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(32, 1, 4) X(64, 1, 4) X(64, 2, 4) \
+  X(4, 1, 4) X(8, 1, 4) X(16, 1, 4) X(32, 1, 4) X(64, 1, 4) X(64, 2, 4) \
   X(64, 4, 4) X(8, 1, 1) X(64, 1, 1) X(64, 4, 1)
 
 }  // namespace vfm

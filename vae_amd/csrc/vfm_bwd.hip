@@ -1,5 +1,8 @@
-// vfm_bwd.hip -- k_bwd (entity-centric gradients / fused Adam / multi-rank stages) and k_sample
-// instances with their dispatch.  Compiled once per link function: -DVFM_LINK=0 (|.|) / 1 (softplus).
+// vfm_bwd.hip -- k_bwd (entity-centric gradients / fused Adam / multi-rank stages) and k_sample_rec
+// instances with their dispatch.  Compiled once per link function -- -DVFM_LINK=0 (|.|) / 1 (softplus) -- and per
+// kernel family: -DVFM_BWD_PART=0 the gradient and statistics forms (`adam` 0, 10), =1 the fused-Adam forms (1, 2, 11;
+// with the pipelined / look-ahead instances and the record sampler, |.| link only for the pipelined ones): four objects
+// of similar compile time instead of two long ones.
 // gfx950 only, wave = 64.  See vfm_args.hpp for how libvfm_hip.so is split into translation units.
 #include <math.h>
 
@@ -7,6 +10,9 @@
 
 #ifndef VFM_LINK
 #error "compile with -DVFM_LINK=0 (abs) or -DVFM_LINK=1 (softplus)"
+#endif
+#ifndef VFM_BWD_PART
+#error "compile with -DVFM_BWD_PART=0 (gradient / statistics forms) or =1 (fused-Adam forms)"
 #endif
 
 namespace vfm {
@@ -23,14 +29,13 @@ constexpr int LINK = VFM_LINK;
 template <int LPE, int CPL, int VEC, int EPS, int ADAM, int STAGE = STAGE_FULL>
 int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   constexpr int GPB = BLOCK / LPE;
-  // (the untouched-rows launch shares the chip with the forward kernel: a small grid by default)
-  const int per_cu = a.row_filter == 1 ? env_int("VFM_ADAMU_BLOCKS_PER_CU", 1) : env_int("VFM_BWD_BLOCKS_PER_CU", 8);
+  const int per_cu = env_int("VFM_BWD_BLOCKS_PER_CU", 8);
   int64_t nb = (a.e_hi - a.e_lo + GPB - 1) / GPB;
   if (ADAM != 0 && b.row_ids) nb = (b.n_rows + GPB - 1) / GPB;     // the listed rows only
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
-  if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX && VEC == 4) {
+  if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX && VEC == 4 && LINK == LINK_ABS) {
     if (b.zrec != nullptr) {      // software-pipelined step: gathers samples, writes the next step's records
       if (a.S > 1) return fail(VFM_E_UNSUPPORTED, "pipelined step: one variational sample");
       if (b.last_step != nullptr)     // ... in the look-ahead form: rows in neither this batch nor the next are skipped
@@ -40,7 +45,7 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
       return 0;
     }
   }
-  if (b.zrec != nullptr) return fail(VFM_E_UNSUPPORTED, "pipelined step: fused Adam, Philox eps, d % 4 == 0 only");
+  if (b.zrec != nullptr) return fail(VFM_E_UNSUPPORTED, "pipelined step: fused Adam, Philox eps, d % 4 == 0, |.| link only");
   if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX) {
     if (b.last_step != nullptr) {     // look-ahead lazy Adam
       if (a.S > 1) return fail(VFM_E_UNSUPPORTED, "look-ahead lazy Adam: one variational sample");
@@ -62,16 +67,19 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
 // adam: 0 gradients, 1 dense Adam fused, 2 row-sparse Adam fused, 10 statistics (STAGE_ACC), 11 apply (STAGE_APPLY)
 template <int LPE, int CPL, int VEC>
 int launch_bwd_s(int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+#if VFM_BWD_PART == 0
   if (eps == EPS_PHILOX && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 0>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 0) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 0>(a, b, ad, st);
+  if (adam == 10) return launch_bwd_t<LPE, CPL, VEC, EPS_ZERO, 0, STAGE_ACC>(a, b, ad, st);
+#else
   if (eps == EPS_PHILOX && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 1) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1>(a, b, ad, st);
   if (eps == EPS_PHILOX && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 2>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 2) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 2>(a, b, ad, st);
-  if (adam == 10) return launch_bwd_t<LPE, CPL, VEC, EPS_ZERO, 0, STAGE_ACC>(a, b, ad, st);
   if (eps == EPS_PHILOX && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_PHILOX, 1, STAGE_APPLY>(a, b, ad, st);
   if (eps == EPS_TABLE && adam == 11) return launch_bwd_t<LPE, CPL, VEC, EPS_TABLE, 1, STAGE_APPLY>(a, b, ad, st);
-  return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source");
+#endif
+  return fail(VFM_E_UNSUPPORTED, "backward: unsupported eps source / form in this translation unit");
 }
 
 int dispatch_bwd(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad,
@@ -83,23 +91,7 @@ int dispatch_bwd(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, 
   return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
 }
 
-int dispatch_sample(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
-#define X(L_, C_, V_)                                                                                   \
-  if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                      \
-    constexpr int GPB = BLOCK / L_;                                                                     \
-    int64_t nb = ((int64_t)n + GPB - 1) / GPB;   /* one record per lane group: latency is hidden by occupancy */ \
-    if (nb > 65535) nb = 65535;                                                                         \
-    if (eps == EPS_TABLE)                                                                               \
-      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_TABLE, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, n, out); \
-    else                                                                                                \
-      hipLaunchKernelGGL((k_sample<L_, C_, V_, EPS_PHILOX, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, ids, n, out); \
-    return 0;                                                                                           \
-  }
-  VFM_FOR_SHAPES(X)
-#undef X
-  return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
-}
-
+#if VFM_BWD_PART == 1 && VFM_LINK == 0
 int dispatch_sample_rec(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
 #define X(L_, C_, V_)                                                                                   \
   if (s.lpe == L_ && s.cpl == C_ && s.vec == V_) {                                                      \
@@ -114,31 +106,25 @@ int dispatch_sample_rec(const Shape& s, KArgs& a, const int32_t* ids, int n, flo
   return fail(VFM_E_UNSUPPORTED, "no kernel instance for this embedding size");
 }
 
+#endif
+
 }  // namespace
 
-#if VFM_LINK == 0
+#if VFM_BWD_PART == 1 && VFM_LINK == 0
 int launch_sample_rec_abs(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
-  return dispatch_sample_rec(s, a, ids, n, zrec, st);
-}
-#else
-int launch_sample_rec_softplus(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
   return dispatch_sample_rec(s, a, ids, n, zrec, st);
 }
 #endif
 
+#define VFM_CAT3(a, b, c) a##b##c
+#define VFM_BWD_NAME(part, suffix) VFM_CAT3(launch_bwd, part, suffix)
 #if VFM_LINK == 0
-int launch_bwd_abs(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+int VFM_BWD_NAME(VFM_BWD_PART, _abs)(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   return dispatch_bwd(s, eps, adam, a, b, ad, st);
-}
-int launch_sample_abs(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
-  return dispatch_sample(s, eps, a, ids, n, out, st);
 }
 #else
-int launch_bwd_softplus(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
+int VFM_BWD_NAME(VFM_BWD_PART, _softplus)(const Shape& s, int eps, int adam, KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st) {
   return dispatch_bwd(s, eps, adam, a, b, ad, st);
-}
-int launch_sample_softplus(const Shape& s, int eps, KArgs& a, const int32_t* ids, int n, float* out, hipStream_t st) {
-  return dispatch_sample(s, eps, a, ids, n, out, st);
 }
 #endif
 

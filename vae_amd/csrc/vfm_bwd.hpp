@@ -70,20 +70,20 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   int32_t la_step = b.la_step, la_k = b.la_k;
   if constexpr (ADAM == 1 && STAGE == STAGE_FULL)
     load_dev_step(a, key, ad, la_step, la_k, next_key,
-                  blockIdx.x == 0 && threadIdx.x == 0 && a.row_filter != 1 && a.row_filter != 3 && a.e_hi == a.T);
+                  blockIdx.x == 0 && threadIdx.x == 0 && a.row_filter != 3 && a.e_hi == a.T);
   static_assert(!PIPE || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "the pipelined step is the fused single-sample one");
   static_assert(!LA || (ADAM == 1 && STAGE == STAGE_FULL && !MULTI), "look-ahead lazy Adam is a form of the fused dense step");
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ float sh_cs_next[PIPE ? VFM_MAX_FIELDS : 1];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
-  __shared__ double sh_fin[6][BLOCK / 64];
+  __shared__ double sh_fin[7][BLOCK / 64];
   __shared__ float2 sh_tab[LA ? VFM_MOMENT_PERIOD + 1 : 1];      // LA: (a1, q2) of the period's earlier steps, for replays
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int d = a.d;
   const int C = (d + VEC - 1) / VEC;
   if (STAGE != STAGE_ACC && tid < a.G) {
-    sh_cs[tid] = a.W ? (float)(a.group_n[tid] / a.W[tid]) : 0.f;     // (W == NULL: untouched-rows launch)
+    sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
     if constexpr (PIPE) sh_cs_next[tid] = b.zrec_next ? (float)(a.group_n[tid] / b.next_W[tid]) : 0.f;
   }
@@ -95,15 +95,12 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     if (blockIdx.x == 0 && tid == 0) b.step_tab[la_k] = make_float2(ad.a1, ad.q2);     // for later replays of this step
   }
   const float gout = (ADAM || STAGE == STAGE_ACC) ? 1.0f : b.grad_out[0];
-  const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);     // (dimension-sharded mode: one rank carries bias_params)
 
   double fin[6] = {0, 0, 0, 0, 0, 0};
-  // a.row_filter (fused Adam, STAGE_FULL): 0 = every row; 1 = only the rows the batch does NOT touch (pure Adam
-  // decay, independent of this step's forward: the caller runs it concurrently with the forward kernel on
-  // another stream); 2 = only the touched rows (+ the scalars and the loss)
+  // a.row_filter (fused Adam, STAGE_FULL): 0 = every row; 2 = only the rows of the batch (+ the scalars and the loss);
   // 3 / 4 (the long-list pre-reduction overlapped with this kernel, vfm_abi.hip): 4 = every row but the heavy
   // entities (+ the scalars and the loss), 3 = the heavy entities only, listed
-  const bool duty = a.row_filter != 1 && a.row_filter != 3;      // this launch forms the loss and moves the scalars
+  const bool duty = a.row_filter != 3;      // this launch forms the loss and moves the scalars
   const bool fold = STAGE == STAGE_FULL && b.loss != nullptr && duty;   // uniform: fold vfm_elbo_finalize_f32 in
   if (blockIdx.x == 0 && fold)
     reduce_slots_and_loss(b.partials, a.scalars, a.ll_scale_d, a.flags, b.loss, sh_fin, fin);
@@ -154,10 +151,6 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
 
   const int64_t stride = (int64_t)gridDim.x * GPB;
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);          // floats per exchange record
-  // entity-sharded apply (own_mod > 1): this rank owns the entities e = own_rank + li * own_mod; the
-  // loop runs over the local index li and the statistics records are indexed by li
-  const bool sharded = STAGE == STAGE_APPLY && a.own_mod > 1;
-  float klacc = 0.f;                                   // sum of c_e * KL_e over this thread's entities
   // fused Adam with a row list (the lazy exact-Adam step): li runs over the list (the batch's entities), not over
   // the table.  The SAME instance serves the dense step, so the two agree bit for bit on the rows they share
   // (different template instances are compiled with different fma contractions).
@@ -166,39 +159,48 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
   // (the multi-rank stages take a list too -- vfm_elbo_bwd_acc_rows_f32 / vfm_elbo_apply_adam_rows_f32: the rows some
   // rank's shard contains; their records sit in the DENSE statistics table at the entity's own index, or, with
   // b.rec_by_slot, in a COMPACT buffer at the row's position in the list)
-  const bool listed = b.row_ids != nullptr &&
-                      (STAGE == STAGE_FULL ? ADAM != 0
-                                           : (STAGE == STAGE_ACC || (!sharded && b.occ_ptr == nullptr)));
+  const bool listed = b.row_ids != nullptr && (STAGE == STAGE_FULL ? ADAM != 0 : true);
+  // a corrupted index is clamped, never followed: list offsets to [0, n_occ], row numbers to [0, B), listed entities to
+  // [0, T); every clamp that fires is counted in b.status (vfm_index_t.status) for the caller's next look
+  int nclamp = 0;
+  const int n_occ = b.n_occ;
+  const int Bm1 = a.B > 0 ? (int)a.B - 1 : 0;
+  auto ent_ok = [&](int64_t v) -> int64_t {
+    const bool ok = v >= 0 && v < a.T;
+    nclamp += ok ? 0 : 1;
+    return ok ? v : 0;
+  };
+  auto span_ok = [&](int2 v) -> int2 {
+    const bool ok = v.x >= 0 && v.y >= v.x && v.y <= n_occ;
+    nclamp += ok ? 0 : 1;
+    return ok ? v : make_int2(0, 0);
+  };
+  auto row_ok = [&](int v) -> int {
+    const bool ok = (unsigned)v <= (unsigned)Bm1;
+    nclamp += ok ? 0 : 1;
+    return ok ? v : 0;
+  };
   const int64_t li_end = listed ? b.n_rows : a.e_hi;
   int64_t li = (listed ? 0 : a.e_lo) + (int64_t)blockIdx.x * GPB + tid / LPE;
   int64_t e_cur = li;
-  if (listed && li < li_end) e_cur = b.row_ids[li];
+  if (listed && li < li_end) e_cur = ent_ok(b.row_ids[li]);
   int2 pq = make_int2(0, 0);
-  if (STAGE != STAGE_APPLY && li < li_end) pq = make_int2(b.occ_ptr[e_cur], b.occ_ptr[e_cur + 1]);
+  if (STAGE != STAGE_APPLY && li < li_end) pq = span_ok(make_int2(b.occ_ptr[e_cur], b.occ_ptr[e_cur + 1]));
   for (; li < li_end; li += stride) {
-    const int64_t e = listed ? e_cur : (sharded ? (int64_t)a.own_rank + li * a.own_mod : li);
+    const int64_t e = listed ? e_cur : li;
     const int64_t rec = (listed && !b.rec_by_slot) ? e : li;      // where this row's statistics record sits (multi-rank stages)
     int beg = pq.x, end = pq.y;
     const int64_t en = li + stride;
     float2 gc = make_float2(0.f, 0.f);
-    int rbeg = 0, rend = 0;
     if constexpr (STAGE == STAGE_APPLY) {
-      if (b.occ_ptr) {     // gather form: the records of entity li sit at positions occ_rows[rbeg..rend) of b.acc
-        rbeg = b.occ_ptr[li]; rend = b.occ_ptr[li + 1];
-        for (int q = rbeg; q < rend; ++q) {
-          const float2 t2 = *reinterpret_cast<const float2*>(b.acc + (size_t)b.occ_rows[q] * xs);
-          gc.x += t2.x; gc.y += t2.y;
-        }
-      } else {
-        gc = *reinterpret_cast<const float2*>(b.acc + (size_t)rec * xs);   // (sum of grow, occurrences) over ALL ranks
-      }
-      if (listed && en < li_end) e_cur = b.row_ids[en];
+      gc = *reinterpret_cast<const float2*>(b.acc + (size_t)rec * xs);   // (sum of grow, occurrences) over ALL ranks
+      if (listed && en < li_end) e_cur = ent_ok(b.row_ids[en]);
       beg = 0; end = 0;
     } else {
       if (en < li_end) {                                                    // next entity's offsets, early
-        const int64_t e_next = listed ? (int64_t)b.row_ids[en] : en;
+        const int64_t e_next = listed ? ent_ok(b.row_ids[en]) : en;
         e_cur = e_next;
-        pq = make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]);
+        pq = span_ok(make_int2(b.occ_ptr[e_next], b.occ_ptr[e_next + 1]));
       }
     }
     bool in_next = false;          // PIPE: e is in the next batch -> its next-step record is written below
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       la_gap = (la_step - 1) - b.last_step[e];
     }
     if (ADAM == 2 && !touched) continue;   // opt-in row-sparse Adam: rows not in the batch stay as they are
-    if (ADAM == 1 && STAGE == STAGE_FULL && (a.row_filter == 1 || a.row_filter == 2) && (a.row_filter == 1) == touched) continue;
+    if (ADAM == 1 && STAGE == STAGE_FULL && a.row_filter == 2 && !touched) continue;
 
     // loads that do not depend on the index chain
     Chunk<VEC> mu[CPL], s[CPL], ep[CPL], mm[CPL], ms[CPL], vm[CPL], vs[CPL];
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       int o = beg;
       if (hslot >= 0) {      // pre-reduced by k_heavy: read the record(s), skip the walk
         const float* rec = hacc + (size_t)hslot * xs;
-        const int4 hd = *reinterpret_cast<const int4*>(rec);      // (sum grow, count, first item, last item + 1)
+        int4 hd = *reinterpret_cast<const int4*>(rec);      // (sum grow, count, first item, last item + 1)
+        if (hd.z < 0 || hd.w < hd.z || hd.w > b.heavy_stride - b.n_heavy) { hd.z = hd.w = 0; ++nclamp; }
         if (hd.w - hd.z <= VFM_HEAVY_DIRECT) {      // few work items: add their records here, in item order
           for (int it = hd.z; it < hd.w; ++it) {
             const float* ir = hacc + ((size_t)b.n_heavy + (size_t)it) * xs;
@@ -291,11 +294,11 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       }
       // PIPE: the sample of the OTHER entity of the row (this step's records) stands in for the sumz row
       auto src = [&](int oo, int r) -> const float* {
-        if constexpr (PIPE) return b.zrec + (size_t)b.occ_other[oo] * xs + 4;
+        if constexpr (PIPE) return b.zrec + (size_t)ent_ok(b.occ_other[oo]) * xs + 4;
         return sz + (size_t)r * d;
       };
       for (; o + 1 < end; o += 2) {       // two occurrences in flight
-        const int r0 = b.occ_rows[o], r1 = b.occ_rows[o + 1];
+        const int r0 = row_ok(b.occ_rows[o]), r1 = row_ok(b.occ_rows[o + 1]);
         const float g0 = b.grow[r0], g1 = b.grow[r1];
         const float* p0 = src(o, r0);
         const float* p1 = src(o + 1, r1);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         }
       }
       if (o < end) {
-        const int r0 = b.occ_rows[o];
+        const int r0 = row_ok(b.occ_rows[o]);
         const float g0 = b.grow[r0];
         const float* p0 = src(o, r0);
         gs += g0;
@@ -343,25 +346,10 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
     if constexpr (STAGE == STAGE_APPLY) {
       gs = gc.x;
       if (touched) {
-        if (b.occ_ptr) {
-          for (int q = rbeg; q < rend; ++q) {
-            const float* rec = b.acc + (size_t)b.occ_rows[q] * xs + 4;
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-              const int j = lig + i * LPE;
-              if (j < C) {
-                const Chunk<VEC> t4 = ld_chunk<VEC>(rec + (size_t)j * VEC);
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) A[i].v[t] += t4.v[t];
-              }
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < CPL; ++i) {
-            const int j = lig + i * LPE;
-            if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)rec * xs + 4 + (size_t)j * VEC);
-          }
+        for (int i = 0; i < CPL; ++i) {
+          const int j = lig + i * LPE;
+          if (j < C) A[i] = ld_chunk<VEC>(b.acc + (size_t)rec * xs + 4 + (size_t)j * VEC);
         }
       }
     }
@@ -378,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
           st_chunk_nt<VEC>(grow_e + d + (size_t)j * VEC, zc);
         }
       }
-      if (lig == 0 && has_bias) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
+      if (lig == 0) *reinterpret_cast<float2*>(b.g_bias + 2 * (size_t)e) = make_float2(0.f, 0.f);
       continue;
     }
 
@@ -465,7 +453,6 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
             const float gz = PIPE ? A[i].v[t] : A[i].v[t] - z * gs;
             gm.v[t] = gout * (gz + c * mu[i].v[t]);
             gv.v[t] = gout * dlink_f<LINK>(s[i].v[t]) * (gz * epc.v[t] + c * (sg - inv_sigma(sg)));
-            if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(mu[i].v[t], sg), klacc);
           }
         } else {
 #pragma unroll
@@ -522,7 +509,7 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         }
       }
     }
-    if (lig == 0 && has_bias) {
+    if (lig == 0) {
       float g0 = 0.f, g1 = 0.f;
       if (touched) {
         if constexpr (EPS == EPS_TABLE)
@@ -530,7 +517,6 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
         const float sg = link_f<LINK>(th.y);
         g0 = gout * (gs + c * th.x);
         g1 = gout * dlink_f<LINK>(th.y) * (gs * nb_eps + c * (sg - inv_sigma(sg)));
-        if (STAGE == STAGE_APPLY && b.kl_slots) klacc = fmaf(c, kl_std_normal(th.x, sg), klacc);
       }
       if constexpr (LA) {
         if (la_gap > 0) {
@@ -573,13 +559,5 @@ __global__ __launch_bounds__(BLOCK, (PIPE && CPL == 1) ? 4 : 1) void k_bwd(const
       }
     }
   }
-  if (STAGE == STAGE_APPLY && b.kl_slots) {       // uniform; per-block KL partial for the owner's loss term
-    __shared__ float sh_kl[4];
-    float v1[1] = {klacc};
-    block_sum<1>(v1, sh_kl);
-    if (tid == 0) {
-      b.kl_slots[1 + blockIdx.x] = (double)v1[0];
-      if (blockIdx.x == 0) b.kl_slots[0] = (double)gridDim.x;
-    }
-  }
+  if (nclamp != 0 && b.status) atomicAdd(b.status, nclamp);       // (integer: the total does not depend on the order)
 }

@@ -153,14 +153,18 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV * 4] 
   }
 }
 
-// log-likelihood of one (row, sample) and its derivative wrt the prediction
+// log-likelihood of one (row, sample) and its derivative wrt the prediction.  aterm: the POSITIVE half of the row's
+// share of dloss/d|alpha| = (y - pred)^2 / 2 - 1 / (2 |alpha|): the lanes add up positive terms only, the constant
+// n_terms / (2 |alpha|) is taken off the total once, in fp64, when the slots are reduced (VFM_P_ALPHA, vfm_reduce.hpp).
+// (Per row, in fp32, the difference cancels -- at the optimum the sum is zero -- and the gradient of alpha came out
+//  with three digits fewer than every other number of the step.)
 __device__ __forceinline__ void lik_terms(int lik, float y, float pred, float aabs, float half_log_a, float& ll,
                                           float& dll, float& aterm) {
   if (lik == VFM_LIK_NORMAL) {
     const float diff = y - pred;
     ll = -0.5f * aabs * diff * diff + half_log_a - LOG_SQRT_2PI;
     dll = aabs * diff;
-    aterm = 0.5f * diff * diff - 0.5f / aabs;
+    aterm = 0.5f * diff * diff;
   } else {
     // log-sigmoid on the hardware exp2/log2 units: softplus(x) = max(x,0) + ln(1 + e^-|x|)
     const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(pred));
@@ -171,3 +175,9 @@ __device__ __forceinline__ void lik_terms(int lik, float y, float pred, float aa
   }
 }
 
+
+// what a forward workgroup writes into its slot's VFM_SLOT_NTERMS entry: the number of Normal-likelihood terms the
+// LAUNCH summed into the slots' VFM_P_ALPHA entries (B rows x S samples), carried by workgroup 0 alone
+__device__ __forceinline__ double slot_nterms(const KArgs& a, bool train_final) {
+  return (train_final && blockIdx.x == 0 && a.lik == VFM_LIK_NORMAL) ? (double)a.B * (double)a.S : 0.0;
+}

@@ -46,7 +46,7 @@ int launch_fwd_s(int eps, int mode, int ff, KArgs& a, const FwdOut& o, hipStream
     }                                                                                          \
     return launch_fwd_t<LPE, CPL, VEC, E_, M_, 0, true>(a, o, st);                             \
   }
-  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN) FWD(EPS_ZPRE, MODE_TRAIN)
+  FWD(EPS_PHILOX, MODE_TRAIN) FWD(EPS_TABLE, MODE_TRAIN)
   FWD(EPS_PHILOX, MODE_PREDICT) FWD(EPS_TABLE, MODE_PREDICT) FWD(EPS_ZERO, MODE_PREDICT)
 #undef FWD
   return fail(VFM_E_UNSUPPORTED, "forward: unsupported eps source / mode combination");

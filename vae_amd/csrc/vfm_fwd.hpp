@@ -14,9 +14,6 @@
 // KL arithmetic of the previous row runs.  FF = 2 keeps both fields of a row in registers
 // (the reference's user/item case); FF = 0 streams a runtime number of fields.
 // ---------------------------------------------------------------------------------------
-// EPS_ZPRE: the "table" holds precomputed samples, one record (w, 0, 0, 0 | z[0..d-1]) per slot
-// (entity-sharded multi-rank mode: the owner of an entity samples it once and ships z, not mu / s)
-//
 // Variational samples S > 1 (the reference's global N_VARIATIONAL_SAMPLES, vfm-torch.py:19,238-245,265):
 // one launch per sample s.  Launch s draws its own eps (RngKey::step_hi carries s), stores sumz[s] and
 // adds its row value  b_r^s + q_r^s  to a running sum kept in pred[0..B); the LAST launch turns the mean
@@ -38,20 +35,6 @@ __device__ __forceinline__ void load_field(const KArgs& a, uint32_t e, int lig, 
                                            FieldRegs<CPL, VEC, EPS>& R) {
   const int d = a.d;
   R.e = e;
-  if constexpr (EPS == EPS_ZPRE) {
-    const float* rec = a.entity + (size_t)e * (4 + (((size_t)d + 3) & ~(size_t)3));
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      int j = lig + i * LPE;
-      j = j < C ? j : C - 1;
-      R.mu[i] = ld_chunk<VEC>(rec + 4 + (size_t)j * VEC);     // z itself
-#pragma unroll
-      for (int t = 0; t < VEC; ++t) R.s[i].v[t] = 0.f;
-    }
-    R.th = make_float2(rec[0], 0.f);                           // the sampled first-order weight
-    R.io = 0.f;                                                // KL is the owner's business
-    return;
-  }
   const float* row = a.entity + (size_t)e * (2 * (size_t)d);
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -155,7 +138,7 @@ __device__ __forceinline__ void bias_math(const float2 th, float epw, bool owner
 
 // arithmetic of one occurrence (generic path): every lane draws its own chunk's eps
 template <int LPE, int CPL, int VEC, int EPS, int MODE, int LINK>
-__device__ __forceinline__ void consume_field(const RngKey& key, bool has_bias, const FieldRegs<CPL, VEC, EPS>& R,
+__device__ __forceinline__ void consume_field(const RngKey& key, const FieldRegs<CPL, VEC, EPS>& R,
                                               int lig, int C, float cs, RowAcc<CPL, VEC>& acc) {
   float klv = 0.f;
   float epw = 0.f;
@@ -168,7 +151,7 @@ __device__ __forceinline__ void consume_field(const RngKey& key, bool has_bias, 
     if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
       for (int t = 0; t < VEC; ++t) ep[t] = R.ep[i].v[t];
-    } else if constexpr (EPS == EPS_ZERO || EPS == EPS_ZPRE) {
+    } else if constexpr (EPS == EPS_ZERO) {
 #pragma unroll
       for (int t = 0; t < VEC; ++t) ep[t] = 0.f;
     } else {
@@ -179,7 +162,7 @@ __device__ __forceinline__ void consume_field(const RngKey& key, bool has_bias, 
     chunk_math<VEC, MODE, LINK>(R.mu[i], R.s[i], ep, valid, acc.sz[i], acc.zz, klv);
   }
   if constexpr (EPS == EPS_TABLE) epw = R.epw;
-  bias_math<MODE, LINK>(R.th, epw, lig == 0 && has_bias, acc.part, klv);
+  bias_math<MODE, LINK>(R.th, epw, lig == 0, acc.part, klv);
   if constexpr (MODE == MODE_TRAIN) acc.kl = fmaf(cs * R.io, klv, acc.kl);
 }
 
@@ -189,7 +172,7 @@ __device__ __forceinline__ void consume_field(const RngKey& key, bool has_bias, 
 // [1,0,3,2]).  Lane 0 / lane 1 own the first-order weights of field 0 / field 1 (their calls have
 // p == 0 and carry the bias normal).
 template <int LPE, int CPL, int EPS, int MODE, int LINK>
-__device__ __forceinline__ void consume_row2(const RngKey& key, bool has_bias, const FieldRegs<CPL, 4, EPS>& R0,
+__device__ __forceinline__ void consume_row2(const RngKey& key, const FieldRegs<CPL, 4, EPS>& R0,
                                              const FieldRegs<CPL, 4, EPS>& R1, int lig, int C, float cs0,
                                              float cs1, RowAcc<CPL, 4>& acc) {
   static_assert(LPE >= 2, "lane pairing needs at least two lanes per row");
@@ -204,7 +187,7 @@ __device__ __forceinline__ void consume_row2(const RngKey& key, bool has_bias, c
     if constexpr (EPS == EPS_TABLE) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) { ep0[t] = R0.ep[i].v[t]; ep1[t] = R1.ep[i].v[t]; }
-    } else if constexpr (EPS == EPS_ZERO || EPS == EPS_ZPRE) {
+    } else if constexpr (EPS == EPS_ZERO) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) { ep0[t] = 0.f; ep1[t] = 0.f; }
     } else {
@@ -225,7 +208,7 @@ __device__ __forceinline__ void consume_row2(const RngKey& key, bool has_bias, c
   }
   if constexpr (EPS == EPS_TABLE) epw = odd ? R1.epw : R0.epw;
   float klb = 0.f;
-  bias_math<MODE, LINK>(odd ? R1.th : R0.th, epw, lig < 2 && has_bias, acc.part, klb);
+  bias_math<MODE, LINK>(odd ? R1.th : R0.th, epw, lig < 2, acc.part, klb);
   if constexpr (MODE == MODE_TRAIN) {
     const float c0 = cs0 * R0.io, c1 = cs1 * R1.io;
     acc.kl = fmaf(c0, kl0, fmaf(c1, kl1, fmaf(odd ? c1 : c0, klb, acc.kl)));
@@ -260,10 +243,6 @@ __device__ __forceinline__ void finish_row(const KArgs& a, const FwdOut& out, in
       const int j = lig + i * LPE;
       if (j < C) st_chunk<VEC>(srow + (size_t)j * VEC, acc.sz[i]);
     }
-  }
-  if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED)) {   // uniform: dimension-sharded mode, the row value
-    if (lig == 0) out.pred[r] = val;                               // over this rank's coordinates; no likelihood
-    return;
   }
   if (a.S > 1) {                      // uniform: one launch per sample, see the header comment
     if (lig == 0) {
@@ -321,24 +300,19 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
 
   if (MODE == MODE_TRAIN && tid < a.G) {
     // (S > 1: the KL term is formed by the last sample's launch only)
-    sh_cs[tid] = (EPS == EPS_ZPRE || a.sample + 1 < a.S) ? 0.f : (float)(a.group_n[tid] / a.W[tid]);
+    sh_cs[tid] = (a.sample + 1 < a.S) ? 0.f : (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
   }
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = link_f<LINK>(alpha);
   const RngKey key0 = key_of_step(a, blockIdx.x == 0 && tid == 0);     // (replayable step: the step lives in device memory)
   const RngKey key = key_of_sample(key0, a.sample);   // this launch's sample (key0: sample 0)
-  const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);
   float e0 = 0.f;
   if constexpr (EPS == EPS_TABLE) e0 = a.eps_global[0];
-  if constexpr (EPS == EPS_PHILOX || EPS == EPS_ZPRE) {     // (ZPRE: the scalars are replicated, w0 is local)
-    if (EPS == EPS_ZPRE && a.eps_global) {
-      e0 = a.eps_global[0];
-    } else {
-      float n[8], nb;
-      normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
-      e0 = n[0];
-    }
+  if constexpr (EPS == EPS_PHILOX) {
+    float n[8], nb;
+    normal8b(key, 0xFFFFFFFFu, 0u, n, nb);
+    e0 = n[0];
   }
   const float w0 = fmaf(link_f<LINK>(s0), e0, m0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
@@ -403,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
         }
         // stage 2: arithmetic of row r from A while B's loads are in flight
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, has_bias, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, A0, A1, lig, C, ((int64_t)A0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)A1.e < hi0) ? cs0 : cs1, acc);
         finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yA, acc, tot);
         r = rn;
@@ -424,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           if constexpr (MODE == MODE_TRAIN) yA = a.y[rc];
         }
         acc.reset();
-        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, has_bias, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
+        consume_row2<LPE, CPL, EPS, MODE, LINK>(key, B0, B1, lig, C, ((int64_t)B0.e < hi0) ? cs0 : cs1,
                                           ((int64_t)B1.e < hi0) ? cs0 : cs1, acc);
         finish_row<LPE, CPL, VEC, MODE>(a, out, r, lig, C, rc, yB, acc, tot);
         r = rn;
@@ -474,7 +448,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, Bq);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, has_bias, A, lig, C, cs_of(A.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, A, lig, C, cs_of(A.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];
@@ -494,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
           nid = raw(r2 < rend ? r2 * F + f2 : last);
           load_field<LPE, CPL, VEC, EPS, MODE>(a, en, lig, C, A);
         }
-        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, has_bias, Bq, lig, C, cs_of(Bq.e, f), acc);
+        consume_field<LPE, CPL, VEC, EPS, MODE, LINK>(key, Bq, lig, C, cs_of(Bq.e, f), acc);
         if (f == F - 1) {
           float y = 0.f;
           if constexpr (MODE == MODE_TRAIN) y = a.y[r];
@@ -515,16 +489,10 @@ __global__ __launch_bounds__(BLOCK) void k_fwd(const KArgs a, const FwdOut out) 
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
-    if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED)) {
-      // dimension-sharded mode: this workgroup's share of the KL term travels behind the row values
-      // (pred[B + b]; NaN when an id was out of range); workgroup 0 clears the unused tail
-      out.pred[a.B + blockIdx.x] = (tot[4] != 0.f) ? __builtin_nanf("") : tot[1];
-    }
+    slot[VFM_SLOT_NTERMS] = slot_nterms(a, MODE == MODE_TRAIN && a.sample + 1 == a.S);
     if (blockIdx.x == 0) {
       out.partials[7] = (double)gridDim.x;
       out.partials[VFM_P_REDUCED] = 0.0;       // the sums [0..5] are stale until the slots are reduced
     }
   }
-  if (MODE == MODE_TRAIN && (a.flags & VFM_FLAG_PARTIAL_PRED) && blockIdx.x == 0)
-    for (int b = gridDim.x + tid; b < VFM_MAX_FWD_BLOCKS; b += BLOCK) out.pred[a.B + b] = 0.f;
 }

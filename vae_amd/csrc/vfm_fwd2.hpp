@@ -206,8 +206,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const float aabs = link_f<LINK>(alpha);
   const float w0 = fmaf(link_f<LINK>(s0), sh_e0, m0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
-  const bool has_bias = !(a.flags & VFM_FLAG_NO_BIAS);
-  const bool owns_bias = (lig == 0) && has_bias;
+  const bool owns_bias = lig == 0;
   float cs0 = 0.f, cs1 = 0.f;
   uint32_t hi0 = 0u;                 // ids below hi0 belong to group 0 (ids are below 2^32)
   if constexpr (MODE == MODE_TRAIN && EPS != EPS_ZREC) {
@@ -325,6 +324,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    slot[VFM_SLOT_NTERMS] = slot_nterms(a, MODE == MODE_TRAIN);
     if (blockIdx.x == 0) {
       out.partials[7] = (double)gridDim.x;
       out.partials[VFM_P_REDUCED] = 0.0;       // the sums [0..5] are stale until the slots are reduced

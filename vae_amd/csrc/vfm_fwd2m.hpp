@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd2m(const KArgs a, const FwdOut out
   const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
   const float aabs = link_f<LINK>(alpha), sg0 = link_f<LINK>(s0);
   const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
-  const bool owns_bias = (lig == 0) && !(a.flags & VFM_FLAG_NO_BIAS);
+  const bool owns_bias = lig == 0;
   float cs0 = 0.f, cs1 = 0.f;
   uint32_t hi0 = 0u;
   if constexpr (MODE == MODE_TRAIN) {
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(BLOCK) void k_fwd2m(const KArgs a, const FwdOut out
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    slot[VFM_SLOT_NTERMS] = slot_nterms(a, MODE == MODE_TRAIN);
     if (blockIdx.x == 0) {
       out.partials[7] = (double)gridDim.x;
       out.partials[VFM_P_REDUCED] = 0.0;

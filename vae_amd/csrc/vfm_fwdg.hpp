@@ -182,6 +182,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwdg(const KArgs a, const FwdOut o
     double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    slot[VFM_SLOT_NTERMS] = slot_nterms(a, MODE == MODE_TRAIN);
     if (blockIdx.x == 0) {
       out.partials[7] = (double)gridDim.x;
       out.partials[VFM_P_REDUCED] = 0.0;       // the sums [0..5] are stale until the slots are reduced

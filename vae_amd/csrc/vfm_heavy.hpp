@@ -19,13 +19,17 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
                                                  const float* __restrict__ sumz, const float* __restrict__ grow,
                                                  float* __restrict__ item_acc, int d,
                                                  const int32_t* __restrict__ occ_other, const float* __restrict__ zrec,
-                                                 float* __restrict__ heavy_acc) {
+                                                 float* __restrict__ heavy_acc, int n_heavy, int n_occ, int B, int64_t T,
+                                                 int32_t* __restrict__ status) {
   constexpr int GPB = BLOCK / LPE;
   const int lig = threadIdx.x % LPE;
   const int C = (d + VEC - 1) / VEC;
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
+  // (a corrupted index is clamped, never followed: vfm_index_t.status counts the clamps)
+  int nclamp = 0;
   for (int it = blockIdx.x * GPB + threadIdx.x / LPE; it < n_items; it += gridDim.x * GPB) {
-    const int slot = items[4 * it], beg = items[4 * it + 1], end = items[4 * it + 2];
+    int slot = items[4 * it], beg = items[4 * it + 1], end = items[4 * it + 2];
+    if (slot < 0 || slot >= n_heavy || beg < 0 || end < beg || end > n_occ) { slot = 0; beg = end = 0; ++nclamp; }
     Chunk<VEC> A[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i)
@@ -41,9 +45,12 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
         const bool ok = o + u < end;
         const int oo = ok ? o + u : beg;
         r[u] = occ_rows[oo];
+        if ((unsigned)r[u] >= (unsigned)B) { r[u] = 0; ++nclamp; }
         g[u] = ok ? grow[r[u]] : 0.f;
         gs += g[u];
-        src[u] = zrec ? zrec + (size_t)occ_other[oo] * xs + 4 : sumz + (size_t)r[u] * d;
+        int64_t oe = zrec ? (int64_t)occ_other[oo] : 0;
+        if (oe < 0 || oe >= T) { oe = 0; ++nclamp; }
+        src[u] = zrec ? zrec + (size_t)oe * xs + 4 : sumz + (size_t)r[u] * d;
       }
 #pragma unroll
       for (int i = 0; i < CPL; ++i) {
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(BLOCK) void k_heavy(const int32_t* __restrict__ ite
     }
     if (lig == 0) *reinterpret_cast<float4*>(rec) = make_float4(gs, (float)(end - beg), 0.f, 0.f);
   }
+  if (nclamp != 0 && status) atomicAdd(status, nclamp);
 }
 
 // heavy entity `slot`: sum of its work items' records (the items of a slot are consecutive and in list order).
@@ -81,7 +89,7 @@ template <int LPE, int CPL, int VEC>
 __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__ items, int n_items, int n_heavy,
                                                      const float* __restrict__ item_acc,
                                                      float* __restrict__ heavy_acc, int d) {
-  (void)items; (void)n_items;
+  (void)items;
   constexpr int GPB = BLOCK / LPE;
   __shared__ float sh[BLOCK * CPL * VEC + 2 * GPB];
   const int lig = threadIdx.x % LPE, grp = threadIdx.x / LPE;
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(BLOCK) void k_heavy_sum(const int32_t* __restrict__
   const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
   for (int slot = blockIdx.x; slot < n_heavy; slot += gridDim.x) {
     const int* hdr = reinterpret_cast<const int*>(heavy_acc + (size_t)slot * xs);
-    const int lo = hdr[2], end = hdr[3];      // the slot's work items (written by k_heavy)
+    int lo = hdr[2], end = hdr[3];            // the slot's work items (written by k_heavy)
+    if (lo < 0 || end < lo || end > n_items) lo = end = 0;      // (never follow a corrupted range: k_heavy / k_bwd report it)
     if (end - lo <= VFM_HEAVY_DIRECT) continue;      // (uniform) few items: the main kernel adds them itself
     Chunk<VEC> A[CPL];
 #pragma unroll

@@ -2,24 +2,28 @@
 //
 // Replaces what the reference does with torch.unique(x, return_inverse, return_counts) three times per
 // step (vfm-torch.py:190-192): the kernels never need `unique`, only, per entity, the list of the batch
-// rows that contain it (the backward walks it).  The loader does not shuffle (vfm-torch.py:121-122), so
-// an index is built once per batch and reused every epoch.
+// rows that contain it (the backward walks it) -- plus the batch normalisers of :305-306, which read the same ids.
 //
-// Method: a STABLE least-significant-digit radix sort of the B*F (entity id, position) pairs by entity id,
-// 8 bits per pass, ceil(log2(T) / 8) passes; stable means an entity's rows come out in row order, so the
-// backward's sums have a fixed order and the whole step stays bitwise reproducible.  No atomics between
-// workgroups:
-//   k_index_keys     ids -> uint32 keys (range-checked; out-of-range ids are counted and clamped to 0
-//                    like the forward does), values = positions r*F + f
-//   per pass:  k_radix_hist     per-tile digit histograms                  hist[digit][tile]
-//              k_radix_scan     per digit: exclusive scan of its row over the tiles + the digit's total (one
-//                               workgroup per digit); only with more than RS_FUSE_NB tiles -- below, every
-//                               scatter workgroup adds up the counts it needs itself
-//              k_radix_scatter  stable rank inside the tile (per-wave digit matching with ballots + a
-//                               scan over the tile's 32 sub-tiles in LDS) + base -> scatter
-//   k_index_finish   occ_rows[i] = position / F;  occ_ptr[e] = lower bound of e in the sorted keys
-//   k_heavy_count / k_heavy_scan / k_heavy_write   entities with more than `heavy_list` occurrences and
-//                    their work items (vfm_index_t), compacted in id order
+// Method: a STABLE least-significant-digit radix sort of the B*F (entity id, position) pairs by entity id, up to 9 bits
+// per pass, ceil(log2(T) / 9) passes (two at the ML-20M shape); stable means an entity's rows come out in row order, so
+// the backward's sums have a fixed order and the whole step stays bitwise reproducible.  The whole build is latency-bound
+// (200 K keys: 3 MB per pass), so it is organised around the NUMBER of dependent launches (six; sixteen before round 4):
+//   memset           the digit-count tables of the passes after the first
+//   k_index_keys     ids -> uint32 keys (range-checked; out-of-range ids are counted and clamped to 0 like the forward
+//                    does), values = positions r*F + f; the first pass's per-tile digit counts; the workgroup's share of
+//                    the batch normalisers W_f = sum_r inv_occ[x_rf] (fp64, fixed order)
+//   k_radix_scatter  one per pass: stable rank inside the tile (per-wave digit matching with ballots + a scan over the
+//                    tile's 32 sub-tiles in LDS) + the tile's base, formed by the workgroup itself from TWO levels of
+//                    digit counts (per tile, per group of G tiles: <= NB/G + G - 1 rows to add, not NB); while scattering,
+//                    the keys count themselves into the NEXT pass's tables at their new positions (integer atomics, one per
+//                    group of lanes with equal digits: a popular id does not serialise on one address); the LAST pass
+//                    writes occ_rows / occ_other directly and leaves the first position of every leading digit
+//   k_index_count    per chunk of 1024 entities: occ_ptr (lower bound of e among the sorted keys, searched inside the
+//                    range of e's leading digit: ~9 probes instead of 18) and the chunk's counts of heavy entities, work
+//                    items, entities present, longest item list
+//   k_index_write    every chunk adds up the chunks before it itself, then the heavy lists and the touched list; the last
+//                    chunk leaves the totals in `counts` and finishes W
+// Integer atomics only, and only where the total is what matters: two builds of one batch give identical buffers.
 // gfx950 only, wave = 64.
 #include <string.h>
 
@@ -32,93 +36,186 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;       // keys per workgroup per pass
 constexpr int RS_SUB = RS_ITEMS * (RS_THREADS / 64); // 64-key sub-tiles of a tile, in key order
-constexpr int HV_CHUNK = 1024;                       // entities per workgroup of the heavy-list compaction
+constexpr int RS_MAXBITS = 9;
+constexpr int RS_MAXD = 1 << RS_MAXBITS;             // digits per pass, at most
+constexpr int RS_MAXPASS = 4;                        // ceil(32 / 9)
+constexpr int HV_CHUNK = 1024;                       // entities per workgroup of the compaction launches
+constexpr int HV_SELF = 4096;                        // chunks up to which a compaction workgroup adds up its predecessors itself
+constexpr int NW_MAXF = 4;                           // fields up to which W is formed inside k_index_keys
 
-__global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restrict__ x, int id64, int n, uint32_t T32,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                           unsigned int* __restrict__ counters) {
-  unsigned int bad = 0;
-  for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += gridDim.x * RS_THREADS) {
-    uint32_t lo, hi;
-    if (id64) {
-      const uint2 t = reinterpret_cast<const uint2*>(x)[i];
-      lo = t.x; hi = t.y;
-    } else {
-      lo = reinterpret_cast<const uint32_t*>(x)[i];
-      hi = (lo >> 31) ? 0xFFFFFFFFu : 0u;
-    }
-    const bool ok = hi == 0u && lo < T32;
-    bad += ok ? 0u : 1u;
-    keys[i] = ok ? lo : 0u;
-    vals[i] = (uint32_t)i;
-  }
-  if (bad) atomicAdd(&counters[0], bad);      // integer: the total does not depend on the order
+// ---- geometry of one build: shared by vfm_index_workspace_bytes and vfm_build_index ----
+struct Geo {
+  int64_t n, n4, NB, G, NS, NBH;
+  int passes, rb[RS_MAXPASS], shift[RS_MAXPASS];
+  // offsets into the workspace, in 4-byte words
+  int64_t k0, v0, k1, v1, zero_lo, L1[RS_MAXPASS], L2[RS_MAXPASS], zero_hi, excl, blk, bad, wpart, total;
+};
+
+int key_bits(int64_t T) {
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < T) ++bits;
+  return bits;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int n, int shift,
-                                                           uint32_t* __restrict__ hist, int NB) {
-  __shared__ unsigned int sh[256];
-  sh[threadIdx.x] = 0;
+Geo geometry(int64_t n, int64_t T) {
+  Geo g;
+  memset(&g, 0, sizeof(g));
+  g.n = n; g.n4 = (n + 3) & ~(int64_t)3;
+  g.NB = (n + RS_TILE - 1) / RS_TILE;
+  g.G = 32;
+  while (g.G * g.G < g.NB) g.G *= 2;                 // rows a scatter workgroup adds up: NB/G + G - 1 <= ~2 sqrt(NB)
+  g.NS = (g.NB + g.G - 1) / g.G;
+  g.NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
+  const int bits = key_bits(T);
+  g.passes = (bits + RS_MAXBITS - 1) / RS_MAXBITS;
+  int sh = 0;
+  for (int p = 0; p < g.passes; ++p) {
+    g.rb[p] = bits / g.passes + (p < bits % g.passes ? 1 : 0);
+    if (g.rb[p] < 2) g.rb[p] = 2;                     // (T <= 2: the extra bit is zero in every key)
+    g.shift[p] = sh;
+    sh += g.rb[p];
+  }
+  int64_t o = 0;
+  g.k0 = o; o += g.n4; g.v0 = o; o += g.n4; g.k1 = o; o += g.n4; g.v1 = o; o += g.n4;
+  g.zero_lo = o;
+  for (int p = 0; p < g.passes; ++p) { g.L1[p] = o; o += g.NB * ((int64_t)1 << g.rb[p]); }
+  for (int p = 0; p < g.passes; ++p) { g.L2[p] = o; o += g.NS * ((int64_t)1 << g.rb[p]); }
+  g.zero_hi = o;
+  g.excl = o; o += RS_MAXD + 4;
+  g.blk = o; o += 5 * g.NBH + 8;
+  g.bad = o; o += (g.NB + 4) & ~(int64_t)3;
+  o = (o + 1) & ~(int64_t)1;                          // (doubles: 8-byte aligned)
+  g.wpart = o; o += 2 * NW_MAXF * (g.NB + 1);
+  g.total = o + 16;
+  return g;
+}
+
+__device__ __forceinline__ void load_id(const void* __restrict__ x, int id64, int64_t i, uint32_t& lo, uint32_t& hi) {
+  if (id64) {
+    const uint2 t = reinterpret_cast<const uint2*>(x)[i];
+    lo = t.x; hi = t.y;
+  } else {
+    lo = reinterpret_cast<const uint32_t*>(x)[i];
+    hi = (lo >> 31) ? 0xFFFFFFFFu : 0u;
+  }
+}
+
+// ids -> keys / positions, the first pass's digit counts of the tile, the tile's share of W and of the bad-id count
+__global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restrict__ x, int id64, int n, uint32_t T32, int F,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                           int rb0, uint32_t* __restrict__ L1, uint32_t* __restrict__ L2, int G,
+                                                           const float* __restrict__ inv_occ, double* __restrict__ wpart,
+                                                           uint32_t* __restrict__ badpart) {
+  __shared__ unsigned int sh_hist[RS_MAXD];
+  __shared__ double sh_w[NW_MAXF][RS_THREADS / 64];
+  __shared__ unsigned int sh_bad[RS_THREADS / 64];
+  const int tid = threadIdx.x, ND = 1 << rb0;
+  for (int i = tid; i < ND; i += RS_THREADS) sh_hist[i] = 0;
   __syncthreads();
   const int base = blockIdx.x * RS_TILE;
+  unsigned int bad = 0;
+  double w[NW_MAXF] = {0.0, 0.0, 0.0, 0.0};
+  const bool want_w = inv_occ != nullptr;
+  uint32_t kd[RS_ITEMS];
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
-    const int i = base + k * RS_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&sh[(keys[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  hist[(size_t)threadIdx.x * NB + blockIdx.x] = sh[threadIdx.x];
-}
-
-// Many tiles (NB > RS_FUSE_NB): one workgroup PER DIGIT scans its row hist[digit][0..NB) in place (exclusive) and
-// leaves the digit's total in tot[digit]; the scatter workgroups add the totals of the smaller digits themselves.
-// (A single workgroup scanning all 256 * NB counts took 383 us per pass at B = 1,048,576: 1.15 of the 1.3 ms build.)
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scan(uint32_t* __restrict__ hist, int NB, uint32_t* __restrict__ tot) {
-  __shared__ uint32_t sh_w[RS_THREADS / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* row = hist + (size_t)blockIdx.x * NB;
-  uint32_t carry = 0;
-  for (int c0 = 0; c0 < NB; c0 += RS_THREADS * 4) {          // 4 consecutive tiles per thread and round
-    const int i0 = c0 + tid * 4;
-    uint32_t v[4], s = 0;
+    const int i = base + k * RS_THREADS + tid;
+    kd[k] = 0u;
+    if (i < n) {
+      uint32_t lo, hi;
+      load_id(x, id64, i, lo, hi);
+      const bool ok = hi == 0u && lo < T32;
+      bad += ok ? 0u : 1u;
+      const uint32_t key = ok ? lo : 0u;
+      keys[i] = key;
+      vals[i] = (uint32_t)i;
+      kd[k] = key & (uint32_t)(ND - 1);
+      if (want_w) {
+        const double v = ok ? (double)inv_occ[lo] : 0.0;        // (ids out of range add nothing, as in vfm_batch_norms)
+        const int f = i % F;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[i] = (i0 + i < NB) ? row[i0 + i] : 0u; s += v[i]; }
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
+        for (int q = 0; q < NW_MAXF; ++q) w[q] += (q == f) ? v : 0.0;
+      }
     }
-    if (lane == 63) sh_w[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < RS_THREADS / 64; ++w) { const uint32_t t = sh_w[w]; if (w < wave) wbase += t; all += t; }
-    uint32_t run = carry + wbase + inc - s;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { if (i0 + i < NB) row[i0 + i] = run; run += v[i]; }
-    carry += all;
-    __syncthreads();
   }
-  if (tid == 0) tot[blockIdx.x] = carry;
+  // digit counts of the tile: one LDS add per group of lanes with the same digit (a run of one popular id is one add)
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const bool valid = base + k * RS_THREADS + tid < n;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RS_MAXBITS; ++b) {
+      if (b < rb0) {
+        const bool bit = (kd[k] >> b) & 1u;
+        const unsigned long long bb = __ballot(bit);
+        m &= bit ? bb : ~bb;
+      }
+    }
+    if (valid && (m & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicAdd(&sh_hist[kd[k]], (unsigned int)__popcll(m));
+  }
+  // bad ids + W: wave sums in a fixed tree, then the waves in order
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) bad += __shfl_xor(bad, m, 64);
+  if ((tid & 63) == 0) sh_bad[tid >> 6] = bad;
+  if (want_w) {
+#pragma unroll
+    for (int q = 0; q < NW_MAXF; ++q) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) w[q] += __shfl_xor(w[q], m, 64);
+      if ((tid & 63) == 0) sh_w[q][tid >> 6] = w[q];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int t = 0;
+    for (int v = 0; v < RS_THREADS / 64; ++v) t += sh_bad[v];
+    badpart[blockIdx.x] = t;
+  }
+  if (want_w && tid < NW_MAXF) {
+    double t = 0.0;
+    for (int v = 0; v < RS_THREADS / 64; ++v) t += sh_w[tid][v];
+    wpart[(size_t)blockIdx.x * NW_MAXF + tid] = t;
+  }
+  // the tile's digit counts: its own row of L1 (plain stores), its group's row of L2 (integer atomics)
+  uint32_t* row1 = L1 + (size_t)blockIdx.x * ND;
+  uint32_t* row2 = L2 + (size_t)(blockIdx.x / G) * ND;
+  for (int i = tid; i < ND; i += RS_THREADS) {
+    const unsigned int c = sh_hist[i];
+    row1[i] = c;
+    if (c) atomicAdd(&row2[i], c);
+  }
 }
 
-// FUSED (few tiles: NB <= RS_FUSE_NB): `base` holds the RAW per-tile digit counts of k_radix_hist and every
-// workgroup forms its own offsets -- digit `tid`: the counts of the tiles before this one plus the totals of the
-// smaller digits -- instead of waiting for a one-workgroup scan kernel (26 us per pass at cfg3, most of it latency).
-constexpr int RS_FUSE_NB = 256;
-template <bool FUSED>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ kin,
-                                                              const uint32_t* __restrict__ vin, int n, int shift,
-                                                              const uint32_t* __restrict__ base, int NB,
-                                                              uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
-  __shared__ uint32_t sub[RS_SUB][256];          // [sub-tile][digit]: count, then start position
+// One radix pass.  L1 [NB][ND] / L2 [NS][ND]: this pass's digit counts per tile / per group of G tiles.
+// L1n / L2n (NULL on the last pass): the next pass's tables, counted here at the keys' new positions.
+// LAST: the sorted positions go out as occ_rows / occ_other (+ the sorted keys, for the lower-bound searches of
+// k_index_count) and workgroup 0 leaves excl[dg] = first position of leading digit dg (excl[ND] = n).
+template <bool LAST>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                              int n, int shift, int rb, const uint32_t* __restrict__ L1,
+                                                              const uint32_t* __restrict__ L2, int G, int NS,
+                                                              uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                              uint32_t* __restrict__ L1n, uint32_t* __restrict__ L2n,
+                                                              int shift_n, int rb_n, uint32_t* __restrict__ excl,
+                                                              int32_t* __restrict__ occ_rows, int32_t* __restrict__ occ_other,
+                                                              const void* __restrict__ x, int id64, int F, int64_t T) {
+  __shared__ uint16_t sub[RS_SUB][RS_MAXD];          // [sub-tile][digit]: count, then start inside the tile
+  __shared__ uint32_t sh_bef[RS_MAXD];               // digit: keys of it in the tiles before this one
+  __shared__ uint32_t sh_tot[RS_MAXD];               // digit: keys of it anywhere, then (scanned) keys of smaller digits
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < RS_SUB * 256; i += RS_THREADS) (&sub[0][0])[i] = 0;
+  const int ND = 1 << rb;
+  const uint32_t dmask = (uint32_t)(ND - 1);
+  {
+    uint4* z = reinterpret_cast<uint4*>(&sub[0][0]);
+    for (int i = tid; i < RS_SUB * RS_MAXD * 2 / 16; i += RS_THREADS) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < RS_MAXD; i += RS_THREADS) { sh_bef[i] = 0u; sh_tot[i] = 0u; }
+  }
   __syncthreads();
-  const int tbase = blockIdx.x * RS_TILE;
+  const int me = blockIdx.x;
+  const int tbase = me * RS_TILE;
   uint32_t key[RS_ITEMS], val[RS_ITEMS];
   int lower[RS_ITEMS];
+  unsigned long long same[RS_ITEMS];                 // lanes of this wave holding the same digit in round k
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
@@ -126,153 +223,228 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
     const bool valid = i < n;
     key[k] = valid ? kin[i] : 0u;
     val[k] = valid ? vin[i] : 0u;
-    const uint32_t dg = (key[k] >> shift) & 255u;
-    // lanes of this wave holding the same digit
-    unsigned long long m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (dg >> b) & 1u;
-      const unsigned long long bb = __ballot(bit);
-      m &= bit ? bb : ~bb;
-    }
-    m = valid ? m : 0ull;
-    lower[k] = __popcll(m & lt);
-    if (valid && lower[k] == 0) sub[k * (RS_THREADS / 64) + wave][dg] = (uint32_t)__popcll(m);
   }
-  __syncthreads();
-  uint32_t tile_base;
-  if constexpr (FUSED) {
-    __shared__ uint32_t sh_tot[256];
-    const uint32_t* row = base + (size_t)tid * NB;
-    uint32_t before = 0, total = 0;
-    const int me = blockIdx.x;
-    int t0 = 0;
-    for (; t0 + 8 <= NB; t0 += 8) {
-      uint32_t c[8];
+  // ---- this tile's base per digit: the keys of smaller digits anywhere + the keys of the digit in the tiles before.
+  // Rows to add: every group row of L2 (total; the groups before mine also count as `before`) and the L1 rows of the
+  // tiles of my own group before me -- NB/G + G - 1 rows at most.  Four digits per load, rows dealt over the row groups
+  // of the workgroup, eight loads in flight per thread; the row groups meet in LDS (integer adds: order-free).
+  {
+    const int ms = me / G;                            // my group
+    const int nrow = NS + (me - ms * G);
+    const int lanes = ND >> 2;                        // threads covering one row (4 digits each): 1 .. 128
+    const int RG = RS_THREADS / lanes;                // row groups: >= 2
+    const int q = tid % lanes, rg = tid / lanes;
+    uint4 bef = make_uint4(0u, 0u, 0u, 0u), tot = make_uint4(0u, 0u, 0u, 0u);
+    for (int r0 = rg; r0 < nrow; r0 += RG * 8) {
+      uint4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) c[u] = row[t0 + u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { total += c[u]; before += (t0 + u < me) ? c[u] : 0u; }
-    }
-    for (; t0 < NB; ++t0) { const uint32_t c = row[t0]; total += c; before += (t0 < me) ? c : 0u; }
-    sh_tot[tid] = total;
-    __syncthreads();
-    if (tid < 64) {                              // exclusive scan of the 256 digit totals: 4 per lane + wave scan
-      uint32_t v[4], tot = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = sh_tot[4 * tid + i]; tot += v[i]; }
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += t;
+      for (int u = 0; u < 8; ++u) {                   // (no load under a branch: a dead slot re-reads row 0 and is masked)
+        const int r = r0 + u * RG;
+        const bool live = r < nrow, grp = r < NS;
+        const uint32_t* row = !live ? L2 : (grp ? L2 + (size_t)r * ND : L1 + (size_t)(ms * G + (r - NS)) * ND);
+        v[u] = reinterpret_cast<const uint4*>(row)[q];
       }
-      uint32_t run = inc - tot;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { sh_tot[4 * tid + i] = run; run += v[i]; }
-    }
-    __syncthreads();
-    tile_base = sh_tot[tid] + before;
-  } else {       // rows scanned by k_radix_scan, digit totals behind the histogram
-    __shared__ uint32_t sh_tot[256];
-    sh_tot[tid] = base[(size_t)256 * NB + tid];
-    __syncthreads();
-    if (tid < 64) {
-      uint32_t v[4], tot = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = sh_tot[4 * tid + i]; tot += v[i]; }
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += t;
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u * RG;
+        const bool live = r < nrow, grp = r < NS;
+        const uint32_t mt = (live && grp) ? 0xFFFFFFFFu : 0u, mb = (live && (!grp || r < ms)) ? 0xFFFFFFFFu : 0u;
+        tot.x += v[u].x & mt; tot.y += v[u].y & mt; tot.z += v[u].z & mt; tot.w += v[u].w & mt;
+        bef.x += v[u].x & mb; bef.y += v[u].y & mb; bef.z += v[u].z & mb; bef.w += v[u].w & mb;
       }
-      uint32_t run = inc - tot;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { sh_tot[4 * tid + i] = run; run += v[i]; }
     }
-    __syncthreads();
-    tile_base = sh_tot[tid] + base[(size_t)tid * NB + blockIdx.x];
+    atomicAdd(&sh_bef[4 * q + 0], bef.x); atomicAdd(&sh_bef[4 * q + 1], bef.y);
+    atomicAdd(&sh_bef[4 * q + 2], bef.z); atomicAdd(&sh_bef[4 * q + 3], bef.w);
+    atomicAdd(&sh_tot[4 * q + 0], tot.x); atomicAdd(&sh_tot[4 * q + 1], tot.y);
+    atomicAdd(&sh_tot[4 * q + 2], tot.z); atomicAdd(&sh_tot[4 * q + 3], tot.w);
   }
-  {   // digit `tid`: global base of this tile, then the sub-tiles in order
-    uint32_t run = tile_base;
-#pragma unroll 4
-    for (int s = 0; s < RS_SUB; ++s) { const uint32_t c = sub[s][tid]; sub[s][tid] = run; run += c; }
-  }
-  __syncthreads();
+  // ---- rank inside the tile: lanes of a wave holding the same digit (ballots), counted per 64-key sub-tile ----
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
     const int i = tbase + k * RS_THREADS + tid;
-    if (i < n) {
-      const uint32_t dg = (key[k] >> shift) & 255u;
-      const uint32_t pos = sub[k * (RS_THREADS / 64) + wave][dg] + (uint32_t)lower[k];
-      kout[pos] = key[k];
-      vout[pos] = val[k];
-    }
-  }
-}
-
-__global__ __launch_bounds__(RS_THREADS) void k_index_finish(const uint32_t* __restrict__ keys,
-                                                             const uint32_t* __restrict__ vals, int n, int F, int64_t T,
-                                                             int32_t* __restrict__ occ_ptr, int32_t* __restrict__ occ_rows,
-                                                             const void* __restrict__ x, int id64,
-                                                             int32_t* __restrict__ occ_other) {
-  const int64_t total = (int64_t)n > T + 1 ? (int64_t)n : T + 1;
-  for (int64_t i = blockIdx.x * (int64_t)RS_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * RS_THREADS) {
-    if (i < n) occ_rows[i] = (int32_t)(vals[i] / (uint32_t)F);
-    if (occ_other && i < n) {      // two fields: the entity in the OTHER column of the occurrence's row (clamped like the keys)
-      const uint32_t op = vals[i] ^ 1u;
-      uint32_t lo, hi;
-      if (id64) { const uint2 t = reinterpret_cast<const uint2*>(x)[op]; lo = t.x; hi = t.y; }
-      else { lo = reinterpret_cast<const uint32_t*>(x)[op]; hi = (lo >> 31) ? 0xFFFFFFFFu : 0u; }
-      occ_other[i] = (hi == 0u && (int64_t)lo < T) ? (int32_t)lo : 0;
-    }
-    if (i <= T) {            // first sorted position whose key is >= i
-      int lo = 0, hi = n;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((int64_t)keys[mid] < i) lo = mid + 1; else hi = mid;
-      }
-      occ_ptr[i] = lo;
-    }
-  }
-}
-
-// ---- compaction passes over the entities, in id order: (a) entities with more than L occurrences and their work
-// items, (b) the entities the batch contains at all (`touched`: the row list of the lazy Adam step) ----
-__device__ __forceinline__ void heavy_of(const int32_t* occ_ptr, int64_t e, int64_t T, int THR, int& cnt, int& beg, bool& any) {
-  cnt = 0; beg = 0;
-  if (e < T) { beg = occ_ptr[e]; cnt = occ_ptr[e + 1] - beg; }
-  any = cnt > 0;
-  if (cnt <= THR) cnt = 0;
-}
-
-__global__ __launch_bounds__(HV_CHUNK) void k_heavy_count(const int32_t* __restrict__ occ_ptr, int64_t T, int L, int THR,
-                                                          uint32_t* __restrict__ blk /*[3][NBH]*/, int NBH) {
-  __shared__ uint32_t sh[3][HV_CHUNK / 64];
-  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + threadIdx.x;
-  int cnt, beg; bool any;
-  heavy_of(occ_ptr, e, T, THR, cnt, beg, any);
-  uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
+    const bool valid = i < n;
+    const uint32_t dg = (key[k] >> shift) & dmask;
+    unsigned long long m = __ballot(valid);
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); c += __shfl_xor(c, m, 64); }
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; sh[2][threadIdx.x >> 6] = c; }
+    for (int b = 0; b < RS_MAXBITS; ++b) {
+      if (b < rb) {                                  // (uniform)
+        const bool bit = (dg >> b) & 1u;
+        const unsigned long long bb = __ballot(bit);
+        m &= bit ? bb : ~bb;
+      }
+    }
+    m = valid ? m : 0ull;
+    same[k] = m;
+    lower[k] = __popcll(m & lt);
+    if (valid && lower[k] == 0) sub[k * (RS_THREADS / 64) + wave][dg] = (uint16_t)__popcll(m);
+  }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    uint32_t t = 0;
-    for (int w = 0; w < HV_CHUNK / 64; ++w) t += sh[threadIdx.x][w];
-    blk[(size_t)threadIdx.x * NBH + blockIdx.x] = t;
+  if (tid < 64) {                                     // exclusive scan of the ND digit totals: 8 per lane + wave scan
+    uint32_t v8[8], t8 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int dg = 8 * tid + i; v8[i] = dg < ND ? sh_tot[dg] : 0u; t8 += v8[i]; }
+    uint32_t inc = t8;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += t;
+    }
+    uint32_t run = inc - t8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int dg = 8 * tid + i;
+      if (dg < ND) {
+        sh_tot[dg] = run;
+        if (LAST && me == 0) excl[dg] = run;
+      }
+      run += v8[i];
+    }
+    if (LAST && me == 0 && tid == 63) excl[ND] = (uint32_t)n;
+  }
+  __syncthreads();
+  // digit dg (two per thread): global base of this tile, then the sub-tiles' starts inside the tile
+  for (int dg = tid; dg < ND; dg += RS_THREADS) {
+    sh_bef[dg] += sh_tot[dg];
+    uint32_t run = 0;
+#pragma unroll 8
+    for (int s = 0; s < RS_SUB; ++s) { const uint32_t c = sub[s][dg]; sub[s][dg] = (uint16_t)run; run += c; }
+  }
+  __syncthreads();
+  const uint32_t dmask_n = rb_n > 0 ? (uint32_t)((1 << rb_n) - 1) : 0u;
+  const int ND_n = 1 << (rb_n > 0 ? rb_n : 0);
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const int i = tbase + k * RS_THREADS + tid;
+    const bool valid = i < n;
+    const uint32_t dg = (key[k] >> shift) & dmask;
+    const uint32_t pos = valid ? sh_bef[dg] + (uint32_t)sub[k * (RS_THREADS / 64) + wave][dg] + (uint32_t)lower[k] : 0u;
+    if constexpr (LAST) {
+      if (valid) {
+        kout[pos] = key[k];
+        occ_rows[pos] = (int32_t)(val[k] / (uint32_t)F);
+        if (occ_other) {       // two fields: the entity in the OTHER column of the occurrence's row (clamped like the keys)
+          uint32_t lo, hi;
+          load_id(x, id64, (int64_t)(val[k] ^ 1u), lo, hi);
+          occ_other[pos] = (hi == 0u && (int64_t)lo < T) ? (int32_t)lo : 0;
+        }
+      }
+    } else {
+      if (valid) { kout[pos] = key[k]; vout[pos] = val[k]; }
+      // the next pass's digit counts at the new position: ONE add per group of lanes that share this digit, the next
+      // digit and the destination tile of the group's first lane (they sit within 64 positions of each other; a lane
+      // that fell into the following tile adds for itself) -- a popular id is one add per wave, not one per key
+      const uint32_t dn = (key[k] >> shift_n) & dmask_n;
+      unsigned long long m = same[k];
+#pragma unroll
+      for (int b = 0; b < RS_MAXBITS; ++b) {
+        if (b < rb_n) {
+          const bool bit = (dn >> b) & 1u;
+          const unsigned long long bb = __ballot(bit);
+          m &= bit ? bb : ~bb;
+        }
+      }
+      const uint32_t tn = pos / (uint32_t)RS_TILE;
+      const int lead = m ? __builtin_ctzll(m) : lane;
+      const uint32_t tn_lead = (uint32_t)__shfl((int)tn, lead, 64);
+      const bool with_lead = valid && tn == tn_lead;
+      const unsigned long long grp = m & __ballot(with_lead);
+      if (valid) {
+        if (with_lead) {
+          if (lane == lead) {
+            const uint32_t c = (uint32_t)__popcll(grp);
+            atomicAdd(&L1n[(size_t)tn * ND_n + dn], c);
+            atomicAdd(&L2n[(size_t)(tn / (uint32_t)G) * ND_n + dn], c);
+          }
+        } else {
+          atomicAdd(&L1n[(size_t)tn * ND_n + dn], 1u);
+          atomicAdd(&L2n[(size_t)(tn / (uint32_t)G) * ND_n + dn], 1u);
+        }
+      }
+    }
   }
 }
 
-// exclusive scans of the three block-count rows (one wave each); totals -> counters[1..3]
-__global__ __launch_bounds__(192) void k_heavy_scan(uint32_t* __restrict__ blk, int NBH, unsigned int* __restrict__ counters) {
+// ---- compaction over the entities, in id order: occ_ptr, the heavy lists with their work items, the touched list ----
+// blk rows: 0 occurrences, 1 heavy entities, 2 work items, 3 entities present, 4 most work items of one entity (a max)
+__device__ __forceinline__ void ent_counts(uint32_t c, int L, int THR, uint32_t& hv, uint32_t& it, uint32_t& any) {
+  any = c > 0 ? 1u : 0u;
+  hv = c > (uint32_t)THR ? 1u : 0u;
+  it = hv ? (c + (uint32_t)L - 1) / (uint32_t)L : 0u;
+}
+
+// first position in keys[lo, hi) whose key is >= e
+__device__ __forceinline__ int lower_bound(const uint32_t* __restrict__ keys, int lo, int hi, uint32_t e) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < e) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// SEARCH: occ_ptr[e] = lower bound of e among the sorted keys, looked for between the first positions of e's leading
+// digit and of the next one (excl, from the last scatter), and written here; else occ_ptr is given (vfm_rebuild_heavy)
+template <bool SEARCH>
+__global__ __launch_bounds__(HV_CHUNK) void k_index_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ excl,
+                                                          int n, int shift_top, int ND_top, int32_t* __restrict__ occ_ptr,
+                                                          int64_t T, int L, int THR, uint32_t* __restrict__ blk, int NBH) {
+  __shared__ uint32_t sh[5][HV_CHUNK / 64];
+  __shared__ int sh_lo[HV_CHUNK + 1];
+  const int tid = threadIdx.x;
+  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
+  uint32_t c = 0;
+  if constexpr (SEARCH) {
+    auto find = [&](int64_t ee) -> int {
+      if (ee >= T || n == 0) return ee > 0 ? n : 0;
+      const int b = (int)((uint64_t)ee >> shift_top);
+      if (b >= ND_top) return n;
+      return lower_bound(keys, (int)excl[b], (int)excl[b + 1], (uint32_t)ee);
+    };
+    sh_lo[tid] = find(e);
+    if (tid == 0) sh_lo[HV_CHUNK] = find(e + HV_CHUNK);
+    __syncthreads();
+    if (e <= T) occ_ptr[e] = sh_lo[tid];
+    if (tid == 0 && e + HV_CHUNK == T) occ_ptr[T] = sh_lo[HV_CHUNK];      // (T a multiple of the chunk: no thread has e == T)
+    if (e < T) c = (uint32_t)(sh_lo[tid + 1] - sh_lo[tid]);
+  } else {
+    if (e < T) c = (uint32_t)(occ_ptr[e + 1] - occ_ptr[e]);
+  }
+  uint32_t v[5];
+  v[0] = c;
+  ent_counts(c, L, THR, v[1], v[2], v[3]);
+  v[4] = v[2];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], m, 64);
+    const uint32_t o = __shfl_xor(v[4], m, 64);
+    v[4] = o > v[4] ? o : v[4];
+  }
+  if ((tid & 63) == 0)
+    for (int r = 0; r < 5; ++r) sh[r][tid >> 6] = v[r];
+  __syncthreads();
+  if (tid < 5) {
+    uint32_t t = 0;
+    for (int w = 0; w < HV_CHUNK / 64; ++w) t = tid == 4 ? (sh[4][w] > t ? sh[4][w] : t) : t + sh[tid][w];
+    blk[(size_t)tid * NBH + blockIdx.x] = t;
+  }
+}
+
+// many chunks (NBH > HV_SELF): exclusive scans of the four count rows in place (one wave each), their totals and the
+// maximum of row 4 behind the table (blk[5 * NBH + 0..4])
+__global__ __launch_bounds__(320) void k_index_scan(uint32_t* __restrict__ blk, int NBH) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* row = blk + (size_t)w * NBH;
   uint32_t carry = 0;
   for (int i0 = 0; i0 < NBH; i0 += 64) {
     const int i = i0 + lane;
     const uint32_t v = i < NBH ? row[i] : 0u;
+    if (w == 4) {
+      uint32_t mx = v;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = __shfl_xor(mx, m, 64); mx = o > mx ? o : mx; }
+      carry = mx > carry ? mx : carry;
+      continue;
+    }
     uint32_t inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -282,47 +454,116 @@ __global__ __launch_bounds__(192) void k_heavy_scan(uint32_t* __restrict__ blk, 
     if (i < NBH) row[i] = carry + inc - v;
     carry += __shfl(inc, 63, 64);
   }
-  if (lane == 0) counters[1 + w] = carry;
+  if (lane == 0) blk[(size_t)5 * NBH + w] = carry;
 }
 
-__global__ __launch_bounds__(HV_CHUNK) void k_heavy_write(const int32_t* __restrict__ occ_ptr, int64_t T, int L, int THR,
+template <bool SCANNED>      // SCANNED: k_index_scan ran; else every workgroup adds up the chunks before it itself
+__global__ __launch_bounds__(HV_CHUNK) void k_index_write(const int32_t* __restrict__ occ_ptr, int64_t T, int L, int THR,
                                                           const uint32_t* __restrict__ blk, int NBH,
                                                           int32_t* __restrict__ heavy_ids, int32_t* __restrict__ items,
-                                                          int cap_h, int cap_i, int32_t* __restrict__ touched_ids) {
+                                                          int cap_h, int cap_i, int32_t* __restrict__ touched_ids,
+                                                          int32_t* __restrict__ counts, const uint32_t* __restrict__ badpart,
+                                                          int NB, const double* __restrict__ wpart, double* __restrict__ W,
+                                                          int F) {
   __shared__ uint32_t sh[3][HV_CHUNK / 64];
-  const int tid = threadIdx.x;
-  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
-  int cnt, beg; bool any;
-  heavy_of(occ_ptr, e, T, THR, cnt, beg, any);
-  const uint32_t a = cnt > 0 ? 1u : 0u, b = cnt > 0 ? (uint32_t)((cnt + L - 1) / L) : 0u, c = any ? 1u : 0u;
-  uint32_t ia = a, ib = b, ic = c;                // inclusive scans inside the wave
+  __shared__ uint32_t sh_bt[7][HV_CHUNK / 64];
+  __shared__ uint32_t sh_base[7];                    // 0..2: heavy / items / present in the chunks before me; 3..5: totals; 6: max items
+  const int tid = threadIdx.x, me = blockIdx.x;
+  const bool last = me == (int)gridDim.x - 1;
+  if constexpr (SCANNED) {
+    if (tid < 3) { sh_base[tid] = blk[(size_t)(1 + tid) * NBH + me]; sh_base[3 + tid] = blk[(size_t)5 * NBH + 1 + tid]; }
+    if (tid == 3) sh_base[6] = blk[(size_t)5 * NBH + 4];
+  } else {
+    uint32_t b[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (int j = tid; j < NBH; j += HV_CHUNK) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint32_t v = blk[(size_t)(1 + r) * NBH + j];
+        b[r] += j < me ? v : 0u;
+        b[3 + r] += v;
+      }
+      const uint32_t v4 = blk[(size_t)4 * NBH + j];
+      b[6] = v4 > b[6] ? v4 : b[6];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) b[r] += __shfl_xor(b[r], m, 64);
+      const uint32_t o = __shfl_xor(b[6], m, 64);
+      b[6] = o > b[6] ? o : b[6];
+    }
+    if ((tid & 63) == 0)
+      for (int r = 0; r < 7; ++r) sh_bt[r][tid >> 6] = b[r];
+    __syncthreads();
+    if (tid < 7) {
+      uint32_t t = 0;
+      for (int w = 0; w < HV_CHUNK / 64; ++w) t = tid == 6 ? (sh_bt[6][w] > t ? sh_bt[6][w] : t) : t + sh_bt[tid][w];
+      sh_base[tid] = t;
+    }
+  }
+  const int64_t e = me * (int64_t)HV_CHUNK + tid;
+  int beg = 0;
+  uint32_t c = 0;
+  if (e < T) { beg = occ_ptr[e]; c = (uint32_t)(occ_ptr[e + 1] - beg); }
+  uint32_t v[3];
+  ent_counts(c, L, THR, v[0], v[1], v[2]);
+  uint32_t inc[3] = {v[0], v[1], v[2]};              // inclusive scans inside the wave
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64), tc = __shfl_up(ic, o, 64);
-    if ((tid & 63) >= o) { ia += ta; ib += tb; ic += tc; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const uint32_t t = __shfl_up(inc[r], o, 64);
+      if ((tid & 63) >= o) inc[r] += t;
+    }
   }
-  if ((tid & 63) == 63) { sh[0][tid >> 6] = ia; sh[1][tid >> 6] = ib; sh[2][tid >> 6] = ic; }
+  if ((tid & 63) == 63)
+    for (int r = 0; r < 3; ++r) sh[r][tid >> 6] = inc[r];
   __syncthreads();
   if (tid < 3) {
     uint32_t r = 0;
     for (int w = 0; w < HV_CHUNK / 64; ++w) { const uint32_t t = sh[tid][w]; sh[tid][w] = r; r += t; }
   }
   __syncthreads();
-  if (any && touched_ids) touched_ids[blk[2 * (size_t)NBH + blockIdx.x] + sh[2][tid >> 6] + ic - c] = (int32_t)e;
-  if (cnt > 0) {
-    const uint32_t slot = blk[blockIdx.x] + sh[0][tid >> 6] + ia - a;
-    uint32_t it = blk[NBH + blockIdx.x] + sh[1][tid >> 6] + ib - b;
+  uint32_t ex[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) ex[r] = sh_base[r] + sh[r][tid >> 6] + inc[r] - v[r];
+  if (v[2] && touched_ids) touched_ids[ex[2]] = (int32_t)e;
+  if (v[0]) {
+    const uint32_t slot = ex[0];
+    uint32_t it = ex[1];
     if (slot < (uint32_t)cap_h) heavy_ids[slot] = (int32_t)e;
-    for (int o = beg; o < beg + cnt; o += L, ++it) {
+    const int end = beg + (int)c;
+    for (int o = beg; o < end; o += L, ++it) {
       if (it < (uint32_t)cap_i) {
-        const int oe = (o + L < beg + cnt) ? o + L : beg + cnt;
+        const int oe = (o + L < end) ? o + L : end;
         *reinterpret_cast<int4*>(items + 4 * (size_t)it) = make_int4((int)slot, o, oe, 0);
       }
     }
   }
+  if (last) {
+    // the build's one readback: (bad ids, heavy entities, work items, entities present, most items of one entity, 0, 0, 0)
+    if (tid >= 1 && tid < 4) counts[tid] = (int32_t)sh_base[2 + tid];
+    if (tid == 4) counts[4] = (int32_t)sh_base[6];
+    if (tid >= 5 && tid < 8) counts[tid] = 0;
+    if (tid < 64) {             // ids out of range, summed over the key tiles
+      uint32_t b = 0;
+      if (badpart)
+        for (int j = tid; j < NB; j += 64) b += badpart[j];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
+      if (tid == 0) counts[0] = (int32_t)b;
+    }
+    if (W && tid >= 64 && tid < 64 + F) {       // W_f: the tiles' shares, added in tile order (fixed: reproducible)
+      const int f = tid - 64;
+      double t = 0.0;
+      if (wpart)
+        for (int j = 0; j < NB; ++j) t += wpart[(size_t)j * NW_MAXF + f];
+      W[f] = t;
+    }
+  }
 }
 
-// ---- rows of the look-ahead step: the entities of batch A or of batch B, in id order (same three-kernel compaction) ----
+// ---- rows of the look-ahead step: the entities of batch A or of batch B, in id order ----
 __device__ __forceinline__ bool in_either(const int32_t* a, const int32_t* b, int64_t e, int64_t T) {
   return e < T && (a[e + 1] != a[e] || b[e + 1] != b[e]);
 }
@@ -356,11 +597,31 @@ __global__ __launch_bounds__(64) void k_union_scan(uint32_t* __restrict__ blk, i
   }
   if (lane == 0) count[0] = (int32_t)carry;
 }
+template <bool SCANNED>      // SCANNED: k_union_scan ran; else every workgroup adds up the chunks before it itself
 __global__ __launch_bounds__(HV_CHUNK) void k_union_write(const int32_t* __restrict__ occ_a, const int32_t* __restrict__ occ_b,
-                                                          int64_t T, const uint32_t* __restrict__ blk, int32_t* __restrict__ rows) {
+                                                          int64_t T, const uint32_t* __restrict__ blk, int NBH,
+                                                          int32_t* __restrict__ rows, int32_t* __restrict__ count) {
   __shared__ uint32_t sh[HV_CHUNK / 64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
+  __shared__ uint32_t sh_bt[2][HV_CHUNK / 64];
+  __shared__ uint32_t sh_base[2];
+  const int tid = threadIdx.x, lane = tid & 63, me = blockIdx.x;
+  if constexpr (SCANNED) {
+    if (tid == 0) sh_base[0] = blk[me];
+  } else {
+    uint32_t b0 = 0, b1 = 0;
+    for (int j = tid; j < NBH; j += HV_CHUNK) { const uint32_t v = blk[j]; b0 += j < me ? v : 0u; b1 += v; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { b0 += __shfl_xor(b0, m, 64); b1 += __shfl_xor(b1, m, 64); }
+    if (lane == 0) { sh_bt[0][tid >> 6] = b0; sh_bt[1][tid >> 6] = b1; }
+    __syncthreads();
+    if (tid < 2) {
+      uint32_t t = 0;
+      for (int w = 0; w < HV_CHUNK / 64; ++w) t += sh_bt[tid][w];
+      sh_base[tid] = t;
+      if (tid == 1 && me == 0) count[0] = (int32_t)t;
+    }
+  }
+  const int64_t e = me * (int64_t)HV_CHUNK + tid;
   const bool in = in_either(occ_a, occ_b, e, T);
   const unsigned long long m = __ballot(in);
   if (lane == 0) sh[tid >> 6] = (uint32_t)__popcll(m);
@@ -368,13 +629,24 @@ __global__ __launch_bounds__(HV_CHUNK) void k_union_write(const int32_t* __restr
   uint32_t wbase = 0;
   for (int w = 0; w < (tid >> 6); ++w) wbase += sh[w];
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  if (in) rows[blk[blockIdx.x] + wbase + (uint32_t)__popcll(m & lt)] = (int32_t)e;
+  if (in) rows[sh_base[0] + wbase + (uint32_t)__popcll(m & lt)] = (int32_t)e;
 }
 
-int key_bits(int64_t T) {
-  int bits = 1;
-  while (bits < 32 && ((int64_t)1 << bits) < T) ++bits;
-  return bits;
+// the two compaction launches over an occ_ptr that is already there (the second half of a build; vfm_rebuild_heavy)
+int compaction_write(int64_t NBH64, const int32_t* occ_ptr, int64_t T, int L, int THR, uint32_t* blk, int32_t* heavy_ids,
+                     int32_t* items, int64_t cap_heavy, int64_t cap_items, int32_t* touched_ids, int32_t* counts,
+                     const uint32_t* badpart, int NB, const double* wpart, double* W, int F, hipStream_t st) {
+  const int NBH = (int)NBH64;
+  const int ch = (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy), ci = (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items);
+  if (NBH > HV_SELF) {
+    hipLaunchKernelGGL(k_index_scan, dim3(1), dim3(320), 0, st, blk, NBH);
+    hipLaunchKernelGGL(k_index_write<true>, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, L, THR, blk, NBH, heavy_ids, items,
+                       ch, ci, touched_ids, counts, badpart, NB, wpart, W, F);
+  } else {
+    hipLaunchKernelGGL(k_index_write<false>, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, L, THR, blk, NBH, heavy_ids, items,
+                       ch, ci, touched_ids, counts, badpart, NB, wpart, W, F);
+  }
+  return 0;
 }
 
 }  // namespace
@@ -400,12 +672,8 @@ int32_t vfm_heavy_threshold(int32_t heavy_list) {
 }
 
 int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
-  if (B < 0 || F < 1 || T < 1 || B * (int64_t)F > 0x7FFFFFFFLL) return -1;
-  const int64_t n = B * F;
-  const int64_t NB = (n + RS_TILE - 1) / RS_TILE;
-  const int64_t NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
-  // 4 key / value buffers, the radix histogram, the heavy block counts, a few counters
-  return 4 * ((n + 3) & ~(int64_t)3) * 4 + (256 * NB + 256) * 4 + (3 * NBH + 4) * 4 + 64;
+  if (B < 0 || F < 1 || T < 1 || T > 0xFFFFFFFELL || B * (int64_t)F > 0x7FFFFFFFLL) return -1;
+  return geometry(B * F, T).total * 4;
 }
 
 int64_t vfm_union_workspace_bytes(int64_t T) { return T < 1 ? -1 : 4 * ((T + HV_CHUNK - 1) / HV_CHUNK + 4); }
@@ -418,16 +686,20 @@ int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b
   const int NBH = (int)((T + HV_CHUNK - 1) / HV_CHUNK);
   uint32_t* blk = reinterpret_cast<uint32_t*>(ws);
   hipLaunchKernelGGL(k_union_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk);
-  hipLaunchKernelGGL(k_union_scan, dim3(1), dim3(64), 0, st, blk, NBH, count);
-  hipLaunchKernelGGL(k_union_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk, rows);
+  if (NBH > HV_SELF) {
+    hipLaunchKernelGGL(k_union_scan, dim3(1), dim3(64), 0, st, blk, NBH, count);
+    hipLaunchKernelGGL(k_union_write<true>, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk, NBH, rows, count);
+  } else {
+    hipLaunchKernelGGL(k_union_write<false>, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk, NBH, rows, count);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "vfm_union_rows");
 }
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
-                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other, int32_t* counts,
-                    void* stream) {
+                    int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other,
+                    const float* inv_occ, double* W, int32_t* counts, void* stream) {
   if (B < 0 || F < 1 || F > VFM_MAX_FIELDS || T < 1 || T > 0xFFFFFFFELL || B * (int64_t)F > 0x7FFFFFFFLL ||
       (id_bits != 32 && id_bits != 64) || heavy_list < VFM_HEAVY_MIN)
     return fail(VFM_E_INVALID, "vfm_build_index: bad B, F, T, id_bits or heavy_list");
@@ -435,53 +707,51 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
   if (!ws || !occ_ptr || !counts || (B > 0 && (!x || !occ_rows)) || cap_heavy < 0 || cap_items < 0 ||
       (cap_heavy > 0 && !heavy_ids) || (cap_items > 0 && !heavy_items))
     return fail(VFM_E_INVALID, "vfm_build_index: NULL pointer");
+  if ((inv_occ == nullptr) != (W == nullptr)) return fail(VFM_E_INVALID, "vfm_build_index: give inv_occ and W together, or neither");
+  if ((((uintptr_t)ws) & 15) != 0) return fail(VFM_E_INVALID, "vfm_build_index: ws must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int n = (int)(B * F);
-  const int NB = (n + RS_TILE - 1) / RS_TILE;
-  const int NBH = (int)((T + HV_CHUNK - 1) / HV_CHUNK);
-  const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
-  uint32_t* k0 = reinterpret_cast<uint32_t*>(ws);
-  uint32_t* v0 = k0 + n4;
-  uint32_t* k1 = v0 + n4;
-  uint32_t* v1 = k1 + n4;
-  uint32_t* hist = v1 + n4;
-  uint32_t* blk = hist + (size_t)256 * NB + 256;       // (256 digit totals behind the histogram)
-  unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)3 * NBH + 4);
-  hipError_t e = hipMemsetAsync(counters, 0, 16, st);
+  const Geo g = geometry(B * F, T);
+  const int n = (int)g.n, NB = (int)g.NB;
+  uint32_t* w32 = reinterpret_cast<uint32_t*>(ws);
+  const bool fused_w = W != nullptr && F <= NW_MAXF;
+  if (W != nullptr && !fused_w)                       // many fields: the stand-alone normaliser kernels (vfm_batch_norms)
+    if (int rc = launch_norms(B, F, T, id_bits, x, inv_occ, W, st)) return rc;
+  hipError_t e = hipSuccess;
+  if (B > 0) e = hipMemsetAsync(w32 + g.zero_lo, 0, (size_t)(g.zero_hi - g.zero_lo) * 4, st);
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index: memset");
+  double* wpart = reinterpret_cast<double*>(w32 + g.wpart);
   if (n > 0) {
-    int g = (n + RS_THREADS - 1) / RS_THREADS;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_index_keys, dim3(g), dim3(RS_THREADS), 0, st, x, (int)(id_bits == 64), n, (uint32_t)T, k0, v0,
-                       counters);
-    const int passes = (key_bits(T) + 7) / 8;
-    for (int p = 0; p < passes; ++p) {
-      hipLaunchKernelGGL(k_radix_hist, dim3(NB), dim3(RS_THREADS), 0, st, k0, n, 8 * p, hist, NB);
-      if (NB <= RS_FUSE_NB) {
-        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
+    hipLaunchKernelGGL(k_index_keys, dim3(NB), dim3(RS_THREADS), 0, st, x, (int)(id_bits == 64), n, (uint32_t)T, (int)F,
+                       w32 + g.k0, w32 + g.v0, g.rb[0], w32 + g.L1[0], w32 + g.L2[0], (int)g.G,
+                       fused_w ? inv_occ : (const float*)nullptr, wpart, w32 + g.bad);
+    uint32_t *kin = w32 + g.k0, *vin = w32 + g.v0, *kout = w32 + g.k1, *vout = w32 + g.v1;
+    for (int p = 0; p < g.passes; ++p) {
+      if (p + 1 == g.passes) {
+        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(NB), dim3(RS_THREADS), 0, st, kin, vin, n, g.shift[p], g.rb[p],
+                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, 0, 0, w32 + g.excl, occ_rows, occ_other, x, (int)(id_bits == 64), (int)F, T);
       } else {
-        hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(RS_THREADS), 0, st, hist, NB, hist + (size_t)256 * NB);
-        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(NB), dim3(RS_THREADS), 0, st, k0, v0, n, 8 * p, hist, NB, k1, v1);
+        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(NB), dim3(RS_THREADS), 0, st, kin, vin, n, g.shift[p], g.rb[p],
+                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, w32 + g.L1[p + 1],
+                           w32 + g.L2[p + 1], g.shift[p + 1], g.rb[p + 1], (uint32_t*)nullptr, occ_rows, occ_other, x,
+                           (int)(id_bits == 64), (int)F, T);
       }
-      uint32_t* t = k0; k0 = k1; k1 = t;
-      t = v0; v0 = v1; v1 = t;
+      uint32_t* t = kin; kin = kout; kout = t;
+      t = vin; vin = vout; vout = t;
     }
+    // (kin now names the sorted keys)
+    hipLaunchKernelGGL(k_index_count<true>, dim3((unsigned)g.NBH), dim3(HV_CHUNK), 0, st, kin, w32 + g.excl, n,
+                       g.shift[g.passes - 1], 1 << g.rb[g.passes - 1], occ_ptr, T, (int)heavy_list, (int)heavy_list, w32 + g.blk,
+                       (int)g.NBH);
+  } else {                                            // empty shard: every list is empty
+    e = hipMemsetAsync(occ_ptr, 0, sizeof(int32_t) * (size_t)(T + 1), st);
+    if (e != hipSuccess) return fail_hip(e, "vfm_build_index: memset of occ_ptr");
+    hipLaunchKernelGGL(k_index_count<false>, dim3((unsigned)g.NBH), dim3(HV_CHUNK), 0, st, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, 0, 0, 1, occ_ptr, T, (int)heavy_list, (int)heavy_list, w32 + g.blk, (int)g.NBH);
   }
-  {
-    const int64_t total = (int64_t)n > T + 1 ? (int64_t)n : T + 1;
-    int64_t g = (total + RS_THREADS - 1) / RS_THREADS;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_index_finish, dim3((unsigned)g), dim3(RS_THREADS), 0, st, k0, v0, n, (int)F, T, occ_ptr, occ_rows,
-                       x, (int)(id_bits == 64), occ_other);
-  }
-  const int thr = (int)heavy_list;
-  hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, thr, blk, NBH);
-  hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);
-  hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, thr, blk, NBH, heavy_ids,
-                     heavy_items, (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy),
-                     (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items), touched_ids);
-  e = hipMemcpyAsync(counts, counters, 16, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return fail_hip(e, "vfm_build_index: copy of the counters");
+  compaction_write(g.NBH, occ_ptr, T, (int)heavy_list, (int)heavy_list, w32 + g.blk, heavy_ids, heavy_items, cap_heavy, cap_items,
+                   touched_ids, counts, n > 0 ? w32 + g.bad : (const uint32_t*)nullptr, NB, fused_w && n > 0 ? wpart : nullptr,
+                   fused_w ? W : nullptr, (int)F, st);
   e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index");
   return 0;
@@ -493,19 +763,14 @@ int vfm_rebuild_heavy(int64_t T, const int32_t* occ_ptr, void* ws, int32_t heavy
       threshold > heavy_list || cap_heavy < 0 || cap_items < 0 || (cap_heavy > 0 && !heavy_ids) || (cap_items > 0 && !heavy_items))
     return fail(VFM_E_INVALID, "vfm_rebuild_heavy: bad argument (VFM_HEAVY_MIN <= threshold <= heavy_list)");
   hipStream_t st = (hipStream_t)stream;
-  const int NBH = (int)((T + HV_CHUNK - 1) / HV_CHUNK);
-  uint32_t* blk = reinterpret_cast<uint32_t*>(ws);
-  unsigned int* counters = reinterpret_cast<unsigned int*>(blk + (size_t)3 * NBH + 4);
-  hipError_t e = hipMemsetAsync(counters, 0, 16, st);
-  if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy: memset");
-  hipLaunchKernelGGL(k_heavy_count, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, (int)threshold, blk, NBH);
-  hipLaunchKernelGGL(k_heavy_scan, dim3(1), dim3(192), 0, st, blk, NBH, counters);
-  hipLaunchKernelGGL(k_heavy_write, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr, T, (int)heavy_list, (int)threshold, blk, NBH, heavy_ids,
-                     heavy_items, (int)(cap_heavy > 0x7FFFFFFF ? 0x7FFFFFFF : cap_heavy),
-                     (int)(cap_items > 0x7FFFFFFF ? 0x7FFFFFFF : cap_items), (int32_t*)nullptr);
-  e = hipMemcpyAsync(counts, counters, 16, hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy: copy of the counters");
-  e = hipGetLastError();
+  const int64_t NBH = (T + HV_CHUNK - 1) / HV_CHUNK;
+  uint32_t* blk = reinterpret_cast<uint32_t*>(ws);       // (5 * NBH + 8 words: inside any workspace of vfm_index_workspace_bytes)
+  hipLaunchKernelGGL(k_index_count<false>, dim3((unsigned)NBH), dim3(HV_CHUNK), 0, st, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, 0, 0, 1, const_cast<int32_t*>(occ_ptr), T, (int)heavy_list, (int)threshold, blk,
+                     (int)NBH);
+  compaction_write(NBH, occ_ptr, T, (int)heavy_list, (int)threshold, blk, heavy_ids, heavy_items, cap_heavy, cap_items, nullptr,
+                   counts, nullptr, 0, nullptr, nullptr, 0, st);
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "vfm_rebuild_heavy");
   return 0;
 }

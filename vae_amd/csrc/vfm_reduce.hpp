@@ -7,17 +7,17 @@
 // all BLOCK threads of ONE workgroup; the totals are valid in thread 0 (and in memory) afterwards.
 __device__ __forceinline__ void reduce_slots_and_loss(double* __restrict__ partials,
                                                       const float* __restrict__ scalars, double ll_scale,
-                                                      int flags, float* __restrict__ loss, double (*sh)[BLOCK / 64],
+                                                      int flags, float* __restrict__ loss, double (*sh)[BLOCK / 64] /* [7] */,
                                                       double (&tot)[6]) {
   const int nblk = (int)partials[7];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};                // [6]: Normal-likelihood terms behind the slots' alpha sums
   for (int b = threadIdx.x; b < nblk; b += BLOCK) {
     const double* slot = partials + VFM_N_PARTIALS * (1 + (size_t)b);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] += slot[i];
+    for (int i = 0; i < 7; ++i) acc[i] += slot[i];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 7; ++i) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
     if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = acc[i];
@@ -27,6 +27,13 @@ __device__ __forceinline__ void reduce_slots_and_loss(double* __restrict__ parti
   for (int i = 0; i < 6; ++i) {
     tot[i] = 0;
     for (int w = 0; w < BLOCK / 64; ++w) tot[i] += sh[i][w];
+  }
+  {   // dloss/d|alpha| (up to nb_train / B): sum (y - pred)^2 / 2 - n / (2 |alpha|), the difference formed once, in fp64
+    double nterms = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) nterms += sh[VFM_SLOT_NTERMS][w];
+    const double al = scalars[0];
+    const double aabs = (flags & VFM_FLAG_LINK_SOFTPLUS) ? fmax(al, 0.0) + log1p(exp(-fabs(al))) : fabs(al);
+    if (nterms > 0.0) tot[VFM_P_ALPHA] -= 0.5 * nterms / aabs;
   }
   if (threadIdx.x != 0) return;
 #pragma unroll

@@ -1,51 +1,6 @@
-// vfm_sample.hpp -- k_sample: owner-side sampling of the entity-sharded multi-rank mode.
+// vfm_sample.hpp -- k_sample_rec: the sample records of the software-pipelined step, made from the tables.
 // Included inside `namespace vfm { namespace {` of vfm_bwd.hip (one object per link function).
 #pragma once
-
-// Owner side, before the forward: sample the requested entities once.  ids[i] is a global entity id
-// owned by this rank; record i of `out` becomes (w, 0, 0, 0 | z[0..d-1]) with z = mu + link(s) eps,
-// w = mu_w + link(s_w) eps_w -- what the requesting ranks' forward (EPS_ZPRE) consumes.  A lane group per
-// record, same chunking as the other kernels.
-template <int LPE, int CPL, int VEC, int EPS, int LINK>
-__global__ __launch_bounds__(BLOCK) void k_sample(const KArgs a, const int32_t* __restrict__ ids, int n,
-                                                  float* __restrict__ out) {
-  constexpr int GPB = BLOCK / LPE;
-  const int lig = threadIdx.x % LPE;
-  const int d = a.d;
-  const int C = (d + VEC - 1) / VEC;
-  const int64_t xs = 4 + (((int64_t)d + 3) & ~(int64_t)3);
-  for (int i = blockIdx.x * GPB + threadIdx.x / LPE; i < n; i += gridDim.x * GPB) {
-    const uint32_t e = (uint32_t)ids[i];
-    const float* row = a.entity + (size_t)e * (2 * (size_t)d);
-    float* rec = out + (size_t)i * xs;
-    float epw = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const int j = lig + c * LPE;
-      if (j < C) {
-        const Chunk<VEC> mu = ld_chunk<VEC>(row + (size_t)j * VEC);
-        const Chunk<VEC> s = ld_chunk<VEC>(row + d + (size_t)j * VEC);
-        Chunk<VEC> ep, z;
-        if constexpr (EPS == EPS_TABLE) {
-          ep = ld_chunk<VEC>(a.eps_entity + (size_t)e * d + (size_t)j * VEC);
-        } else {
-          float nb;
-          eps_of_chunk<VEC>(a.key, e, j, ep.v, nb);
-          if (c == 0) epw = nb;
-        }
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) z.v[t] = fmaf(link_f<LINK>(s.v[t]), ep.v[t], mu.v[t]);
-        st_chunk<VEC>(rec + 4 + (size_t)j * VEC, z);
-      }
-    }
-    if (lig == 0) {
-      if constexpr (EPS == EPS_TABLE) epw = a.eps_bias[e];
-      const float2 th = *reinterpret_cast<const float2*>(a.bias + 2 * (size_t)e);
-      *reinterpret_cast<float4*>(rec) = make_float4(fmaf(link_f<LINK>(th.y), epw, th.x), 0.f, 0.f, 0.f);
-    }
-  }
-}
-
 
 // Software-pipelined step (VFM_FLAG_ZREC): the records of a batch's entities, indexed BY ENTITY ID --
 // zrec[e] = (w, weighted KL of e, 0, 0 | z[0..d-1]), weighted KL = KL(q_e || N(0,1)) / occ(e) * n_g / W_g (what every

@@ -53,82 +53,9 @@ __global__ void k_norms_fix(double* __restrict__ W, int F) {
 __global__ __launch_bounds__(BLOCK) void k_finalize(double* __restrict__ partials,
                                                     const float* __restrict__ scalars, double ll_scale,
                                                     int flags, float* __restrict__ loss) {
-  __shared__ double sh[6][BLOCK / 64];
+  __shared__ double sh[7][BLOCK / 64];
   double tot[6];
   reduce_slots_and_loss(partials, scalars, ll_scale, flags, loss, sh, tot);
-}
-
-// Dimension-sharded mode, after the all-reduce of the row values: pred[r] <- w0 + pred[r], the likelihood
-// terms and grow[r] = dloss/dpred_r, per-workgroup sums into `partials` slots laid out like the forward's
-// (the KL slot of workgroup 0 = the sum of pred[B .. B + VFM_MAX_FWD_BLOCKS), the forward workgroups' KL shares
-// summed over ranks; NaN there -- ids out of range on some rank -- makes the loss NaN).  Same arithmetic per row as finish_row in vfm_fwd.hpp.
-__global__ __launch_bounds__(BLOCK) void k_lik(const KArgs a, const FwdOut out) {
-  __shared__ float sh_red[6 * 4];
-  __shared__ double sh_kl[BLOCK / 64];
-  const bool softplus = (a.flags & VFM_FLAG_LINK_SOFTPLUS) != 0;
-  const float alpha = a.scalars[0], m0 = a.scalars[1], s0 = a.scalars[2];
-  const float aabs = softplus ? link_f<LINK_SOFTPLUS>(alpha) : link_f<LINK_ABS>(alpha);
-  float e0;
-  if (a.eps_global) {
-    e0 = a.eps_global[0];
-  } else {
-    float n[8], nb;
-    normal8b(a.key, 0xFFFFFFFFu, 0u, n, nb);
-    e0 = n[0];
-  }
-  const float w0 = fmaf(softplus ? link_f<LINK_SOFTPLUS>(s0) : link_f<LINK_ABS>(s0), e0, m0);
-  const float half_log_a = 0.5f * LN2 * __builtin_amdgcn_logf(aabs);
-  float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = blockIdx.x * (int64_t)BLOCK + threadIdx.x; r < a.B; r += (int64_t)gridDim.x * BLOCK) {
-    const float pred = w0 + out.pred[r];
-    const float y = a.y[r];
-    float ll, dll, at;
-    lik_terms(a.lik, y, pred, aabs, half_log_a, ll, dll, at);
-    const float g = -a.ll_scale * dll;
-    out.pred[r] = pred;
-    out.grow[r] = g;
-    tot[0] += ll; tot[2] += g; tot[3] += at;
-  }
-  block_sum<6>(tot, sh_red);
-  if (threadIdx.x == 0) {
-    double* slot = out.partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
-    if (blockIdx.x == 0) {
-      out.partials[7] = (double)gridDim.x;
-      out.partials[VFM_P_REDUCED] = 0.0;
-    }
-  }
-  if (blockIdx.x == 0) {     // the KL term: the forward workgroups' shares, summed over ranks by the all-reduce
-    double kl = 0.0;         // (fixed order: reproducible)
-    for (int b = threadIdx.x; b < VFM_MAX_FWD_BLOCKS; b += BLOCK) kl += (double)out.pred[a.B + b];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) kl += __shfl_xor(kl, m, 64);
-    if ((threadIdx.x & 63) == 0) sh_kl[threadIdx.x >> 6] = kl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t = 0.0;
-      for (int w = 0; w < BLOCK / 64; ++w) t += sh_kl[w];
-      out.partials[VFM_N_PARTIALS * 1 + VFM_P_KL] = t;
-    }
-  }
-}
-
-// ws[0] <- sum of ws[1 .. (int)ws[0]]  (per-block partial sums written by a preceding kernel)
-__global__ __launch_bounds__(BLOCK) void k_sum_slots(double* __restrict__ ws) {
-  __shared__ double sh[BLOCK / 64];
-  const int n = (int)ws[0];
-  double acc = 0;
-  for (int i = threadIdx.x; i < n; i += BLOCK) acc += ws[1 + i];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-    for (int w = 0; w < BLOCK / 64; ++w) t += sh[w];
-    ws[0] = t;
-  }
 }
 
 // replayable step: set the device-resident counters (vfm_dev_step_set)

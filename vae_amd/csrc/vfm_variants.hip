@@ -52,7 +52,18 @@ struct VarArgs {
   const float* eps_global;
   int64_t group_hi[VFM_MAX_FIELDS];
   double group_n[VFM_MAX_FIELDS];
+  int32_t* status;        // vfm_index_t.status: the backward kernels count the index entries they had to clamp (may be NULL)
+  int32_t n_occ;          // B * F: the bound of every list offset
 };
+
+// a corrupted index is clamped, never followed (list offsets to [0, n_occ], row numbers to [0, B)); `nclamp` counts
+__device__ __forceinline__ void span_ok(const VarArgs& a, int& beg, int& end, int& nclamp) {
+  if (beg < 0 || end < beg || end > a.n_occ) { beg = end = 0; ++nclamp; }
+}
+__device__ __forceinline__ int row_ok(const VarArgs& a, int r, int& nclamp) {
+  if ((unsigned)r >= (unsigned)a.B) { r = 0; ++nclamp; }
+  return r;
+}
 
 // prior of the global bias / a group's first-order weights / a group's embedding coordinate: (mean, sigma)
 __device__ __forceinline__ float2 prior0(const VarArgs& a) {
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_fwd(const VarArgs a, float* __res
           const float diff = yv - p;
           ll = half_log_a - 0.5f * aabs * (diff * diff + Tn);
           dll = aabs * diff;
-          at = 0.5f * (diff * diff + Tn) - 0.5f / aabs;
+          at = 0.5f * (diff * diff + Tn);       // (positive half: the constant -n / (2 |alpha|) is taken off in fp64, k_var_finalize)
         } else {
           lik_terms(a.lik, yv, p, aabs, 0.5f * LN2 * __builtin_amdgcn_logf(aabs), ll, dll, at);
         }
@@ -192,22 +203,23 @@ __global__ __launch_bounds__(BLOCK) void k_var_fwd(const VarArgs a, float* __res
     double* slot = partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    slot[VFM_SLOT_NTERMS] = (blockIdx.x == 0 && train && (a.lik == VFM_LIK_NORMAL || a.objective == VFM_OBJ_CLOSED_FORM)) ? (double)a.B : 0.0;
     if (blockIdx.x == 0) { partials[7] = (double)gridDim.x; partials[VFM_P_REDUCED] = 0.0; }
   }
 }
 
 // loss triple with the prior-aware KL of the global bias
 __global__ __launch_bounds__(BLOCK) void k_var_finalize(const VarArgs a, double* __restrict__ partials, float* __restrict__ loss) {
-  __shared__ double sh[6][BLOCK / 64];
+  __shared__ double sh[7][BLOCK / 64];
   const int nblk = (int)partials[7];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int b = threadIdx.x; b < nblk; b += BLOCK) {
     const double* slot = partials + VFM_N_PARTIALS * (1 + (size_t)b);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] += slot[i];
+    for (int i = 0; i < 7; ++i) acc[i] += slot[i];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 7; ++i) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
     if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = acc[i];
@@ -219,8 +231,14 @@ __global__ __launch_bounds__(BLOCK) void k_var_finalize(const VarArgs a, double*
   for (int i = 0; i < 6; ++i) {
     tot[i] = 0;
     for (int w = 0; w < BLOCK / 64; ++w) tot[i] += sh[i][w];
-    partials[i] = tot[i];
   }
+  {   // dloss/d|alpha|: sum of the rows' positive halves - n / (2 |alpha|), formed once in fp64 (VFM_P_ALPHA)
+    double nterms = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) nterms += sh[VFM_SLOT_NTERMS][w];
+    if (nterms > 0.0) tot[VFM_P_ALPHA] -= 0.5 * nterms / fabs((double)a.scalars[0]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) partials[i] = tot[i];
   partials[VFM_P_REDUCED] = 1.0;
   const float kl0 = kl_normal(a.scalars[1], fabsf(a.scalars[2]), prior0(a));
   const double nll = -(double)a.ll_scale * tot[VFM_P_LL];
@@ -284,8 +302,10 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd(const VarArgs a, const int32_
     acc_mw = 0.f; acc_sw = 0.f;
   };
   const int64_t nw = (int64_t)gridDim.x * (BLOCK / 64);
+  int nclamp = 0;
   for (int64_t e = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); e < a.T; e += nw) {
-    const int beg = occ_ptr[e], end = occ_ptr[e + 1];
+    int beg = occ_ptr[e], end = occ_ptr[e + 1];
+    span_ok(a, beg, end, nclamp);
     float* ge = g_entity + (size_t)e * (2 * (size_t)a.d);
     if (beg == end) {                                         // not in the batch: dense zero row
       for (int k = lane; k < 2 * a.d; k += 64) ge[k] = 0.f;
@@ -359,17 +379,22 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd(const VarArgs a, const int32_
     }
   }
   flush();
+  if (nclamp != 0 && a.status) atomicAdd(a.status, nclamp);
 }
 
 // the inverted index stores ROW numbers; the variants need the position r*F + f of every occurrence (its value)
 __global__ void k_positions(const int32_t* __restrict__ occ_ptr, const int32_t* __restrict__ occ_rows, const void* x,
-                            int id64, int F, int64_t T, int32_t* __restrict__ occ_pos) {
+                            int id64, int F, int64_t T, int32_t* __restrict__ occ_pos, int64_t B, int32_t* __restrict__ status) {
   // entity e's occurrences in row r: the fields f of r with x[r,f] == e, in field order (the index is stable)
+  const int n_occ = (int)(B * F);
+  int nclamp = 0;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < T; e += (int64_t)gridDim.x * blockDim.x) {
-    const int beg = occ_ptr[e], end = occ_ptr[e + 1];
+    int beg = occ_ptr[e], end = occ_ptr[e + 1];
+    if (beg < 0 || end < beg || end > n_occ) { beg = end = 0; ++nclamp; }      // (a corrupted index is clamped, never followed)
     int last_r = -1, f = 0;
     for (int o = beg; o < end; ++o) {
-      const int r = occ_rows[o];
+      int r = occ_rows[o];
+      if ((unsigned)r >= (unsigned)B) { r = 0; ++nclamp; }
       if (r != last_r) { last_r = r; f = 0; }
       for (; f < F; ++f) {
         const int64_t id = id64 ? ((const int64_t*)x)[(int64_t)r * F + f] : (int64_t)((const int32_t*)x)[(int64_t)r * F + f];
@@ -379,6 +404,7 @@ __global__ void k_positions(const int32_t* __restrict__ occ_ptr, const int32_t* 
       ++f;
     }
   }
+  if (nclamp != 0 && status) atomicAdd(status, nclamp);
 }
 
 #include "vfm_variants8.hpp"
@@ -435,6 +461,8 @@ bool use_var8(const vfm_problem_t* p, const float* eps_entity) {
 
 int check_var(const vfm_problem_t* p, int objective) {
   if (!p) return fail(VFM_E_INVALID, "problem is NULL");
+  if (p->struct_size != (uint32_t)sizeof(vfm_problem_t) || p->abi_version != (uint32_t)VFM_ABI_VERSION)
+    return fail(VFM_E_INVALID, "vfm_problem_t: struct_size / abi_version differ from this library's (VFM_STRUCT_INIT)");
   if (p->B < 0 || p->T <= 0 || p->T > 0xFFFFFFFELL || p->F < 1 || p->F > VFM_MAX_FIELDS || p->d < 1 ||
       (p->id_bits != 32 && p->id_bits != 64) || p->B * (int64_t)p->F > 0x7FFFFFFFLL)
     return fail(VFM_E_INVALID, "variant: bad problem");
@@ -454,6 +482,7 @@ VarArgs make_var(const vfm_problem_t* p, int objective, const void* x, const flo
   VarArgs a;
   memset(&a, 0, sizeof(a));
   a.B = p->B; a.T = p->T; a.F = p->F; a.d = p->d; a.G = p->F; a.id64 = p->id_bits == 64; a.lik = p->likelihood;
+  a.n_occ = (int32_t)(p->B * (int64_t)p->F);
   a.objective = objective; a.eps_mode = ee ? EPS_TABLE : EPS_PHILOX;
   a.ll_scale = (float)((double)p->nb_train / (double)(p->B_global > 0 ? p->B_global : 1));
   a.key.seed_lo = (uint32_t)p->seed; a.key.seed_hi = (uint32_t)(p->seed >> 32);
@@ -521,12 +550,15 @@ int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_ind
                         const float* grow, const double* partials, const float* grad_out, float* g_entity,
                         float* g_bias, float* g_scalars, float* g_priors, void* stream) {
   if (int rc = check_var(p, objective)) return rc;
+  if (idx && (idx->struct_size != (uint32_t)sizeof(vfm_index_t) || idx->abi_version != (uint32_t)VFM_ABI_VERSION))
+    return fail(VFM_E_INVALID, "vfm_index_t: struct_size / abi_version differ from this library's (VFM_STRUCT_INIT)");
   if (!idx || !idx->occ_ptr || (p->B > 0 && !idx->occ_rows) || !occ_pos_ws || !x || !entity_params || !bias_params ||
       !inv_occ || !scalars || !W || !partials || !grad_out || !g_entity || !g_bias || !g_scalars ||
       (p->B > 0 && (!state || !grow)) || ((priors != nullptr) != (g_priors != nullptr)))
     return fail(VFM_E_INVALID, "vfm_variant_bwd_f32: NULL pointer (g_priors goes with priors)");
   VarArgs a = make_var(p, objective, x, values, nullptr, entity_params, bias_params, inv_occ, scalars, W, priors,
                        eps_entity, eps_bias, eps_global);
+  a.status = idx->status;
   hipStream_t st = (hipStream_t)stream;
   if (use_var8(p, eps_entity)) {
     // ws = [B*F positions (only used with values) | (VAR_BWD_BLOCKS + F) partial rows of the prior gradients | F * VAR_PSUM_CH chunk sums]
@@ -539,7 +571,7 @@ int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_ind
       int64_t nbp = (p->T + 255) / 256;
       if (nbp > 4096) nbp = 4096;
       hipLaunchKernelGGL(k_positions, dim3((unsigned)nbp), dim3(256), 0, st, idx->occ_ptr, idx->occ_rows, x,
-                         (int)(p->id_bits == 64), (int)p->F, p->T, occ_pos_ws);
+                         (int)(p->id_bits == 64), (int)p->F, p->T, occ_pos_ws, p->B, idx->status);
     }
     int lpe, cpl;
     var_shape(p->d, &lpe, &cpl);
@@ -563,7 +595,7 @@ int vfm_variant_bwd_f32(const vfm_problem_t* p, int32_t objective, const vfm_ind
   int64_t nbp = (p->T + 255) / 256;
   if (nbp > 4096) nbp = 4096;
   hipLaunchKernelGGL(k_positions, dim3((unsigned)nbp), dim3(256), 0, st, idx->occ_ptr, idx->occ_rows, x,
-                     (int)(p->id_bits == 64), (int)p->F, p->T, occ_pos_ws);
+                     (int)(p->id_bits == 64), (int)p->F, p->T, occ_pos_ws, p->B, idx->status);
   int64_t nb = (p->T + BLOCK / 64 - 1) / (BLOCK / 64);
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(k_var_bwd, dim3((unsigned)nb), dim3(BLOCK), 0, st, a, idx->occ_ptr, occ_pos_ws, state, grow, partials,

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_fwd8(const VarArgs a, float* __re
               const float diff = yv - p;
               ll = half_log_a - 0.5f * aabs * (diff * diff + Tn);
               dll = aabs * diff;
-              at = 0.5f * (diff * diff + Tn) - 0.5f / aabs;
+              at = 0.5f * (diff * diff + Tn);       // (positive half: the constant -n / (2 |alpha|) is taken off in fp64, k_var_finalize)
             } else {
               lik_terms(a.lik, yv, p, aabs, half_log_a, ll, dll, at);
             }
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_fwd8(const VarArgs a, float* __re
     double* slot = partials + VFM_N_PARTIALS * (1 + (size_t)blockIdx.x);
 #pragma unroll
     for (int i = 0; i < 6; ++i) slot[i] = (double)tot[i];
+    slot[VFM_SLOT_NTERMS] = (blockIdx.x == 0 && train && (a.lik == VFM_LIK_NORMAL || a.objective == VFM_OBJ_CLOSED_FORM)) ? (double)a.B : 0.0;
     if (blockIdx.x == 0) { partials[7] = (double)gridDim.x; partials[VFM_P_REDUCED] = 0.0; }
   }
 }
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
   }
   const float* pri_m = PRI ? a.priors + 2 + 2 * a.G : nullptr;
   const float* pri_s = PRI ? pri_m + (size_t)a.G * d : nullptr;
+  int nclamp = 0;                                            // index entries clamped (vfm_index_t.status)
   // this workgroup's contiguous entity range, walked one id group at a time (uniform loop)
   int64_t epb = (a.T + gridDim.x - 1) / gridDim.x;
   epb = (epb + GPB - 1) / GPB * GPB;
@@ -307,7 +309,8 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
     float pwm = 0.f, pws = 1.f, pws_raw = 1.f;
     if constexpr (PRI) { pwm = a.priors[2 + g]; pws_raw = a.priors[2 + a.G + g]; pws = fmaxf(fabsf(pws_raw), SIGMA_MIN); }
     for (int64_t e = e_lo + grp; e < seg_hi; e += GPB) {
-      const int beg = occ_ptr[e], end = occ_ptr[e + 1];
+      int beg = occ_ptr[e], end = occ_ptr[e + 1];
+      span_ok(a, beg, end, nclamp);
       float* ge = g_entity + (size_t)e * (2 * (size_t)d);
       if (beg == end) {                                       // not in the batch: dense zero row
         const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
       };
       int o = beg;
       for (; o + 1 < end; o += 2) {                           // two occurrences in flight
-        const int ra = occ_rows[o], rb = occ_rows[o + 1];
+        const int ra = row_ok(a, occ_rows[o], nclamp), rb = row_ok(a, occ_rows[o + 1], nclamp);
         float va = 1.f, vb = 1.f;
         if constexpr (HASV) { va = a.xv[occ_pos[o]]; vb = a.xv[occ_pos[o + 1]]; }
         const float ga = grow[ra], gb = grow[rb];
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
         one(rb, vb, gb);
       }
       if (o < end) {
-        const int ra = occ_rows[o];
+        const int ra = row_ok(a, occ_rows[o], nclamp);
         float va = 1.f;
         if constexpr (HASV) va = a.xv[occ_pos[o]];
         one(ra, va, grow[ra]);
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(BLOCK) void k_var_bwd8(const VarArgs a, const int32
     ++g;
     if (g >= a.G) g = a.G - 1;
   }
+  if (nclamp != 0 && a.status) atomicAdd(a.status, nclamp);
 }
 
 // g_priors[2 ..] = sum over the partial rows of each group, in a fixed order.  The workgroups whose entity range

@@ -151,29 +151,15 @@ class VFM(nn.Module):
         # catch-up kernel refresh the rows they update, anything else that writes bias_params drops it (_wrec_ok).
         self.use_wrec = True
         self._wrec, self._wrec_ok = None, False
-        # Replayable step (OPT-IN, `replay = True`): with the step-dependent constants in device memory (ops.StepState), the
-        # launches of a fused step are captured ONCE per (batch, next batch, step form) in a HIP graph and replayed; bitwise
-        # the eager trajectory (tests/test_gpu_replay.py).  Off by default because on this stack (ROCm 7.2) it measures
-        # SLOWER than the eager launches at every shape tried: a graph launch costs 22-46 us of host time (two direct
-        # launches: ~10) and ~6 us on the GPU (cfg3 0.1966 vs 0.1902 ms per step, ML-100K shape 50.9 vs 44.9 us, B = 5,000
-        # 63.2 vs 57.0, Criteo shape 0.3651 vs 0.3585: profiles/r03_points.jsonl, keys `sustained` / `replayed`).
-        self.replay = False
-        self._graphs = {}
-        self._step_state = None
         self._la_tab = None                # device table of the period's per-step constants (written by the kernels)
         self._la_ready_for = None          # (plan, adam step): rows of that plan are current through that step
         # what the ranks exchange per step when a process group is given: "stats" = sufficient
         # statistics of the gradient ([T,d+2] floats), "grads" = the dense gradient ([T,2d+2] floats),
         # "rows" = every row's dloss/dpred and the six ELBO sums (B_global + 8 doubles; two fields, one sample): each rank
         # samples all the batch's entities from its replica and runs the whole batch's backward itself (dist.step_rows);
-        # "sharded" = entity-sharded tables (vae_amd/sharded.py): two all-to-alls of the touched rows'
-        # records per step -- every GPU pair talks over its own xGMI link -- and Adam on owned rows only.
-        # "dims" = the embedding dimension cut over the ranks (vae_amd/dims.py): every rank sees all rows, holds
-        # d / N coordinates, ONE all-reduce of B + 4096 floats per step and Adam traffic / N.
         # "auto" = the row-sharded batch + one all-reduce the north star names: "stats" (the all-reduce
         # carries the gradient's sufficient statistics, half the bytes of the gradient), "grads" with
-        # n_samples > 1.  "sharded" and "dims" are opt-in (bench.py --exchange auto times all of them):
-        # neither has been measured on a multi-GPU node yet.
+        # n_samples > 1.
         self.exchange = "auto"
         self.exchange_chunks = 4
         # "stats": exchange only the records of entities some rank's shard contains (vae_amd/dist.py: the ranks agree on
@@ -183,9 +169,6 @@ class VFM(nn.Module):
         # multi-rank form of the row-list lazy exact Adam (vae_amd/dist.py::step_stats)
         self.exchange_lazy = True
         self._xcompact, self._exchanged_floats = None, 0
-        self.shard_gather = True           # sharded mode: the apply kernel gathers the sources' records itself
-        self.shard_deterministic = False   # (shard_gather=False) add the sources one launch per rank, no atomics
-        self._stale_group = None
         self._xflat = None
 
         # ---- parameters: same names / shapes / RNG order as CF.__init__ (vfm-torch.py:136-153)
@@ -257,10 +240,6 @@ class VFM(nn.Module):
         # keep the parameters tied to the flat buffer across .to()/.cuda(); the kernels are fp32 only
         if fn(torch.zeros(1, dtype=torch.float32, device=self._flat.device)).dtype != torch.float32:
             raise TypeError("VFM computes in fp32 only (like the reference); dtype conversions are not supported")
-        if getattr(self, "_stale_group", None) is not None:
-            raise RuntimeError("sync_params() first: a sharded training mode holds slices / owned rows of the tables "
-                               "on this device")
-        self._dims = None            # (rebuilt from the full tables by the next dimension-sharded step)
         if getattr(self, "_lazy_dirty", False):
             self.sync_lazy()
         with torch.no_grad():
@@ -285,9 +264,7 @@ class VFM(nn.Module):
         self._la_tab = self._la_ready_for = None          # (look-ahead step table: no row lags after sync_lazy above)
         self._wrec, self._wrec_ok = None, False
         self._xcompact = None
-        self._graphs, self._step_state = {}, None         # (captured steps hold pointers of the old device's buffers)
         self._zrec = self._zrec_for = None                # (sample records of the pipelined step: re-made on demand)
-        self._shard_acc = self._shard_small = self._shard_klws = None
         if getattr(self, "_state_bufs", None) is not None:
             self._state_bufs = {}
         return out
@@ -314,17 +291,10 @@ class VFM(nn.Module):
         self._forget_derived_state()
 
     # ------------------------------------------------------------------ checkpoint / resume
-    def training_state_dict(self, sync: bool = True):
+    def training_state_dict(self):
         """Everything needed to resume training bit-for-bit: parameters (state_dict), Adam moments and
-        step count, the Philox step counter, the epoch-averaged posterior means of save_weights().
-        After steps of a sharded multi-rank mode ("sharded", "dims") the full tables of a rank are stale and this
-        call is COLLECTIVE (it gathers them: every rank must call it).  For a rank-0-only checkpoint call
-        `sync_params(group)` on every rank first; `sync=False` raises instead of starting a hidden collective."""
-        if getattr(self, "_stale_group", None) is not None:
-            if not sync:
-                raise RuntimeError("the tables of this rank are stale (sharded training mode): call sync_params(group) on "
-                                   "every rank before a checkpoint taken by one rank alone")
-            self.sync_params(self._stale_group)       # (collective: every rank calls this together)
+        step count, the Philox step counter, the epoch-averaged posterior means of save_weights().  (Every rank of a
+        multi-rank run holds the full replicated state: a checkpoint taken by one rank alone is complete.)"""
         self.sync_lazy()
         opt = None
         if self._adam_m is not None:
@@ -347,11 +317,8 @@ class VFM(nn.Module):
             self._adam_v.copy_(state["adam"]["v"].to(self.device))
             self._adam_t = int(state["adam"]["t"])
             self._moments_scaled = bool(state["adam"].get("scaled_form", False))
-            self._lazy_lr = {}             # (_lazy_last keeps its buffer -- captured graphs point at it; no row lags, so
-                                           #  the next lazy step stamps every entry before anything reads one)
+            self._lazy_lr = {}             # (no row lags: the next lazy step stamps every entry of _lazy_last before reading one)
         self._forget_derived_state()          # (with or without optimiser state: the restored rows are current)
-        if getattr(self, "_dims", None) is not None:
-            self._dims.scatter(self)
         if state.get("snapshots") is not None:
             self._n_saved = int(state["snapshots"]["n"])
             self._mean_flat = state["snapshots"]["mean"].to(self.device).clone()
@@ -379,7 +346,6 @@ class VFM(nn.Module):
             raise ValueError("nb_occ must have one entry per entity")
         self.inv_occ = ops.inv_occ_from_counts(self.nb_occ)
         self._wrec_ok = False
-        self._graphs = {}                  # (captured steps hold the old inv_occ pointer)
 
     def plan(self, x, y=None, B_global=None, build_index=True, process_group=None, defer_readback=False) -> ops.BatchPlan:
         x = torch.as_tensor(x).to(self.device)
@@ -392,14 +358,6 @@ class VFM(nn.Module):
                 raise RuntimeError("call set_training_data() before building training plans")
         if process_group is not None and y is not None:
             self._resolve_exchange(process_group)
-        if process_group is not None and self.exchange == "dims" and y is not None:
-            # embedding-dimension-sharded: every rank plans ALL rows of the batch (vae_amd/dims.py)
-            return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=x.shape[0], build_index=build_index)
-        if process_group is not None and self.exchange == "sharded" and y is not None:
-            from .sharded import ShardedPlan
-            return ShardedPlan(self.spec(), x, y, self.inv_occ, B_global if B_global is not None else x.shape[0],
-                               process_group, torch.distributed.get_rank(process_group),
-                               torch.distributed.get_world_size(process_group))
         return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
                              build_index=build_index and y is not None, process_group=process_group,
                              defer_readback=defer_readback)
@@ -407,7 +365,7 @@ class VFM(nn.Module):
     def _resolve_exchange(self, process_group):
         """exchange == "auto" -> the pattern for this model / world size (see __init__)."""
         if self.n_samples > 1:
-            self.exchange = "grads"      # the statistics / sharded / dims exchanges carry one sample
+            self.exchange = "grads"      # the statistics / rows exchanges carry one sample
         if self.exchange == "auto":
             self.exchange = "stats"          # row-sharded batch, ONE (chunk-overlapped) all-reduce per step
         return self.exchange
@@ -419,7 +377,7 @@ class VFM(nn.Module):
     def elbo(self, x=None, y=None, plan: Optional[ops.BatchPlan] = None, eps=None):
         """Differentiable ELBO loss of one batch: `-log_prob(y).mean()*nb_train + kl`
         (vfm-torch.py:353-359).  Returns (loss[1], pred[B], detail[3] = loss, nll, kl)."""
-        self._fresh_params()      # sharded training modes: collective, every rank calls it
+        self._fresh_params()
         self._wrec_ok = False     # (the caller's optimiser writes the parameters: the packed records go stale)
         if plan is None:
             plan = self.plan(x, y)
@@ -436,7 +394,7 @@ class VFM(nn.Module):
         a fresh posterior sample; last/mean logits are the deterministic predictions from the last /
         epoch-averaged posterior means once `save_weights()` has run (None before).  The KL branch
         is not evaluated on inference inputs (kl_term is None)."""
-        self._fresh_params()      # sharded training modes: collective, every rank calls it
+        self._fresh_params()
         plan = self.plan(x, None) if not isinstance(x, ops.BatchPlan) else x
         ent, bia, scal = self._views(self._flat)
         step = self.global_step
@@ -455,40 +413,8 @@ class VFM(nn.Module):
         st = ops.elbo_forward(_single_sample(plan), ent, bia, scal, None, train=False, flags=ops.FLAG_EPS_ZERO)
         return st.pred
 
-    def _dims_state(self, group):
-        from .dims import DimsState
-        if getattr(self, "_dims", None) is None:
-            self._ensure_opt_state()
-            self._dims = DimsState(self, group)
-        return self._dims
-
-    def sync_params(self, process_group, moments: bool = True):
-        """Entity-sharded mode: refresh the rows owned by the other ranks (all-gather).  Dimension-sharded mode:
-        assemble the full tables from the ranks' slices.  `moments=False` gathers the parameters only (enough for
-        predict / save_weights; the tables then still count as stale for checkpoints and mode switches)."""
-        kind = getattr(self, "_stale_kind", None) or self.exchange      # what made the full tables stale
-        if kind == "dims":
-            if getattr(self, "_dims", None) is not None:
-                self._dims.gather(self, moments=moments)
-        else:
-            from .sharded import sync_params
-            sync_params(self, process_group, torch.distributed.get_rank(process_group),
-                        torch.distributed.get_world_size(process_group), moments=moments)
-        self._stale_params = False
-        if moments:
-            self._stale_moments = False
-            self._stale_group = self._stale_kind = None
-
-    def _mark_stale(self, group, kind):
-        """A multi-rank step that trains slices / owned rows leaves the full buffers of this rank stale."""
-        self._stale_group, self._stale_kind = group, kind
-        self._stale_params = self._stale_moments = True
-
     def _fresh_params(self):
-        """Collective (every rank together): gather the parameters if a sharded mode left them stale; bring the rows
-        the lazy Adam mode skipped up to date."""
-        if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_params", True):
-            self.sync_params(self._stale_group, moments=False)
+        """Bring the rows the lazy Adam forms skipped up to date (called before anything reads the parameters)."""
         self.sync_lazy()
 
     def sync_lazy(self, upto=None):
@@ -583,16 +509,6 @@ class VFM(nn.Module):
         bounds = [self.T * i // k for i in range(k + 1)]
         return f[:n], f[n: n + 2], f[n + 4: n + 7], bounds
 
-    def _ensure_shard_state(self, world, rank):
-        """Buffers of the entity-sharded step: dense local statistics records, small exchange vector,
-        KL workspace."""
-        if getattr(self, "_shard_acc", None) is None:
-            from .sharded import owned_rows
-            rl = ops.exchange_record_len(self.d)
-            self._shard_acc = torch.zeros(owned_rows(self.T, rank, world) * rl, dtype=torch.float32, device=self.device)
-            self._shard_small = torch.zeros(16, dtype=torch.float32, device=self.device)
-            self._shard_klws = torch.zeros(4097, dtype=torch.float64, device=self.device)
-
     def _step_buffers(self, B):
         """Persistent per-step training state (sumz [S*B,d], grow [B], pred [B] or [S,B]) -- no allocator
         traffic inside the step."""
@@ -607,13 +523,30 @@ class VFM(nn.Module):
             self._state_bufs[B] = b
         return b
 
+    def plan_async(self, x, y, pair_with: Optional[ops.BatchPlan] = None) -> ops.BatchPlan:
+        """The plan of a batch, built on the model's side stream while whatever is already enqueued on the current stream
+        runs (`ops.PlanStream`): returns at once; the first `train_step` that uses the plan makes its stream wait for the
+        build.  pair_with: the plan of the batch BEFORE this one -- the look-ahead step's row list of the pair is made on
+        the side stream too.  Single rank (a multi-rank plan sums W over the ranks: a collective, built in line)."""
+        if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != self.device:
+            self._plan_stream = ops.PlanStream(self.device)
+        pair = pair_with if (pair_with is not None and self.lookahead and self.lookahead_list and self.n_samples == 1) else None
+        return self._plan_stream.build(lambda: self.plan(x, y, defer_readback=True), pair_with=pair)
+
     def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
                    process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None,
-                   next_plan: Optional[ops.BatchPlan] = None):
+                   next_plan: Optional[ops.BatchPlan] = None, prefetch=None):
         """One iteration of vfm-torch.py:351-370 without autograd: forward, loss, backward, dense
         Adam (betas (0.9, 0.999), eps 1e-8).  Everything is enqueued on the current stream; nothing
-        synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B])."""
+        synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B]).
+        prefetch = (x, y) of the batch AFTER `next_plan` (after `plan` when no next batch is named): its plan is built on
+        the side stream while this step runs (`plan_async`) and waits in `self.prefetched` for the caller to take."""
         self._ensure_opt_state()
+        if prefetch is not None:
+            self.prefetched = self.plan_async(prefetch[0], prefetch[1], pair_with=next_plan if next_plan is not None else plan)
+        plan.use_on_current()
+        if next_plan is not None:
+            next_plan.use_on_current()
         lr = self.lr if lr is None else lr
         if lr is None:
             raise RuntimeError("learning rate not set (fit() uses 1/(1+nb_train//batch_size))")
@@ -621,25 +554,11 @@ class VFM(nn.Module):
         rows_step = process_group is not None and adam and self.exchange == "rows"
         if process_group is not None and not (stats_step or rows_step):
             self.sync_lazy()          # these multi-rank steps update every row they own (the statistics / rows steps keep their own lazy state)
-        # a step in another mode than the one that left the full tables stale: bring them up to date first
-        if getattr(self, "_stale_group", None) is not None and getattr(self, "_stale_kind", None) not in (
-                None, self.exchange if process_group is not None else "single"):
-            self.sync_params(self._stale_group)
-            self._dims = None
-        if process_group is not None and self.exchange == "dims":
-            from .dims import train_step_dims
-            if not adam or out_pred is not None:
-                raise ValueError("the dimension-sharded step always applies Adam and owns its prediction buffer")
-            return train_step_dims(self, plan, lr, process_group, eps=eps, mark=mark)
-        if process_group is not None and self.exchange == "sharded" and self.n_samples == 1:
-            from .sharded import train_step_sharded
-            if not adam:
-                raise ValueError("the entity-sharded step always applies Adam")
-            self._set_moment_form(self.scaled_moments)
-            return train_step_sharded(self, plan, lr, eps=eps, out_pred=out_pred, mark=mark)
+        if process_group is not None and self.exchange not in ("stats", "grads", "rows"):
+            raise ValueError(f"exchange = {self.exchange!r}: the multi-rank step forms are 'stats', 'grads', 'rows' ('auto' is "
+                             "resolved when the plan is built with the process group)")
         step = self.global_step
         self.global_step += 1
-        marking = mark is not None
         mark = mark or (lambda name: None)      # bench.py records HIP events at these points
         mark("start")
         if fused is None:
@@ -649,7 +568,7 @@ class VFM(nn.Module):
         # (every other step form drops them)
         wrec = self._wrec_for_step((fused or stats_step) and eps is None and self.n_samples == 1 and not self.sparse_adam)
         if fused:
-            return self._step_fused(plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec)
+            return self._step_fused(plan, next_plan, lr, step, eps, out_pred, mark, wrec)
         if process_group is not None and adam and self.exchange == "stats" and self.n_samples == 1:
             from .dist import step_stats
             return step_stats(self, plan, lr, step, process_group, eps, out_pred, mark, wrec)
@@ -690,11 +609,11 @@ class VFM(nn.Module):
             mark("adam")
         return loss3, st.pred
 
-    def _step_fused(self, plan, next_plan, lr, step, eps, out_pred, mark, marking, wrec):
+    def _step_fused(self, plan, next_plan, lr, step, eps, out_pred, mark, wrec):
         """The single-rank step with loss + backward + dense Adam in ONE kernel, in the form the state allows: look-ahead
-        (rows of this batch and of the next), row-list lazy (+ catch-up pass), software-pipelined, or plain dense -- each
-        either launched eagerly or replayed as a captured graph (`replay`).  All forms are the same dense Adam trajectory
-        (the lazy ones bit for bit: tests/test_gpu_lazy_adam.py, test_gpu_state_machine.py)."""
+        (rows of this batch and of the next), row-list lazy (+ catch-up pass), software-pipelined, or plain dense.  All
+        forms are the same dense Adam trajectory (the lazy ones bit for bit: tests/test_gpu_lazy_adam.py,
+        test_gpu_state_machine.py)."""
         ent, bia, scal = self._views(self._flat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
         sumz, grow, pred = self._step_buffers(plan.B)
@@ -712,9 +631,6 @@ class VFM(nn.Module):
               and next_plan is not None and next_plan.y is not None and next_plan.spec.T == self.T
               and self._lookahead_pays(plan, next_plan))
         lazy = scaled and not la and self.n_samples >= 1 and self._use_lazy(plan)
-        # may this step be a replayed graph?  (no per-kernel events, no caller-owned buffers, Philox eps)
-        may_replay = (self.replay is True and not marking and eps is None and out_pred is None and self.n_samples == 1
-                      and not self.sparse_adam)
         if k == 1:
             self._lazy_lr = {}
         self._lazy_lr[k] = float(lr)
@@ -735,10 +651,9 @@ class VFM(nn.Module):
                 if self._lazy_dirty and not pipe_la:      # (the last step of a moment period, or no next batch named: the
                     self.sync_lazy(self._adam_t - 1)      #  every-row form -- all rows up to date first; the records stay valid)
                     mark("catchup")
-                return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec, may_replay,
+                return self._train_step_pipelined(plan, nxt, lr, step, scaled, mark, wrec,
                                                   la_next=next_plan if pipe_la else None)
         kind = "list" if lazy else ("la" if la else None)
-        caught_up = False                # a catch-up pass ran in front of this step: not a replayable launch sequence
         if self._lazy_dirty and kind != self._lazy_kind:
             self.sync_lazy(self._adam_t - 1)      # another step form than the one that let rows lag: all rows current first
         if kind is not None:
@@ -752,7 +667,6 @@ class VFM(nn.Module):
                 ops.adam_catchup(ent, bia, mv, vv, self._lazy_last, plan.touched_ids(), self._lazy_lrs(k - 1),
                                  upto=self._adam_t - 1, mark=self._adam_t, wrec=wrec)
                 rows, self._lazy_dirty, self._lazy_kind = "touched", True, "list"
-                caught_up = True
                 mark("catchup")
             elif la:
                 if self._la_tab is None:
@@ -773,43 +687,25 @@ class VFM(nn.Module):
         elif self._lazy_dirty:
             self.sync_lazy(self._adam_t - 1)
 
-        def launch(dev):
-            """The launches of the fused step (forward, then loss + backward + dense Adam in ONE kernel: the gradient
-            rows never reach HBM).  dev: None = step-dependent values as host arguments; else the device step state."""
-            st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
-                                  train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
-                                  out_sumz=sumz, out_grow=grow, out_partials=self._partials, wrec=wrec, dev_step=dev)
-            mark("fwd")
-            if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
-                ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
-                                                 self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
-                                                 loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list,
-                                                 wrec=wrec, dev_step=dev)
-            else:
-                ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
-                                       self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
-                                       sparse=self.sparse_adam, scaled_moments=scaled, rows=rows, wrec=wrec, dev_step=dev)
-            mark("bwd_adam")
-            return st.pred
-
-        if may_replay and not caught_up and not lazy:
-            plan.index_tensors()                  # (deferred index readbacks: not inside a capture)
-            if la:
-                next_plan.index_tensors()
-                if self.lookahead_list:
-                    plan.lookahead_rows(next_plan)
-            # (everything a captured launch points at is part of the key or allocated once per model and device)
-            key = ("la" if la else "dense", id(plan), id(next_plan) if la else 0, bool(scaled),
-                   wrec.data_ptr() if wrec is not None else 0, self.lookahead_list if la else None,
-                   self._lazy_last.data_ptr() if la else 0)
-            out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, sumz, grow, pred))
+        # the launches of the fused step: forward, then loss + backward + dense Adam in ONE kernel (the gradient rows
+        # never reach HBM)
+        st = ops.elbo_forward(plan, ent, bia, scal, self.inv_occ, eps=eps, seed=self.rng_seed, step=step,
+                              train=True, flags=flags, out_pred=out_pred if out_pred is not None else pred,
+                              out_sumz=sumz, out_grow=grow, out_partials=self._partials, wrec=wrec)
+        mark("fwd")
+        if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
+            ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
+                                             self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
+                                             loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list, wrec=wrec)
         else:
-            self._eager_step_ran()
-            out = launch(None)
+            ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
+                                   self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
+                                   sparse=self.sparse_adam, scaled_moments=scaled, rows=rows, wrec=wrec)
+        mark("bwd_adam")
         if la:
             self._lazy_dirty, self._lazy_kind = True, "la"
             self._la_ready_for = (next_plan, self._adam_t)
-        return loss3, out
+        return loss3, st.pred
 
     def _wrec_for_step(self, keep: bool):
         """The packed first-order records for a step that keeps them coherent (None: this step form does not -- they are
@@ -828,41 +724,11 @@ class VFM(nn.Module):
             assert torch.equal(self._wrec[:, :2], bia) and torch.equal(self._wrec[:, 2], self.inv_occ), "stale packed records"
         return self._wrec
 
-    def _eager_step_ran(self):
-        """A step with host-side constants ran: the device-resident counters (if any) no longer match."""
-        if self._step_state is not None:
-            self._step_state.counters = None
-
-    def _replay(self, key, launch, step, lr, scaled, keep=()):
-        """Run `launch(dev_step)` as a captured HIP graph: captured the first time `key` is seen (the launches then read
-        the Philox step and the Adam constants from device memory), replayed afterwards.  The device counters are set to
-        this step's (Philox step, Adam step) whenever something else ran in between."""
-        st8 = self._step_state
-        if st8 is None:
-            st8 = self._step_state = ops.StepState(self.device)
-        st8.cover(self._adam_t, lr, 0.9, 0.999, 1e-8, scaled)
-        hit = self._graphs.get(key, 0)
-        if hit == 0:                # first sight of this launch sequence: run it eagerly (warm-up: lazily made buffers,
-            if len(self._graphs) >= 4096:                                  # streams, the allocator), capture it next time
-                self._graphs.clear()
-            self._graphs[key] = None
-            self._eager_step_ran()
-            return launch(None)
-        if hit is None:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = launch(st8.dev)
-            hit = self._graphs[key] = (g, out, keep)          # (keep: whatever the captured pointers belong to)
-        st8.set(step, self._adam_t)
-        hit[0].replay()
-        st8.advanced()
-        return hit[1]
-
     def _records_ready(self, plan, step) -> bool:
         f = self._zrec_for
         return f is not None and f[0] is plan and f[1] == step and f[2] == self._flat._version
 
-    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark, wrec=None, may_replay=False, la_next=None):
+    def _train_step_pipelined(self, plan, next_plan, lr, step, scaled, mark, wrec=None, la_next=None):
         """The fused step with the sampling of the NEXT batch moved into this step's backward (see __init__).
         la_next (the next batch's plan): the look-ahead form -- the backward visits only the rows of this batch and of that
         one, replaying the zero-gradient updates a visited row skipped (exactly the bookkeeping of the look-ahead form in
@@ -892,7 +758,6 @@ class VFM(nn.Module):
                                  wrec=wrec)
                 mark("catchup")
                 fresh = True             # (records written for this batch before its rows were caught up would be stale)
-            may_replay = False           # (the look-ahead bookkeeping of this form is not part of a captured graph)
         if fresh:                                     # first step of a run (or the tables changed since): from the tables
             ops.sample_records(plan, ent, bia, self.inv_occ, cur, self.rng_seed, step)
             mark("sample_rec")
@@ -900,27 +765,15 @@ class VFM(nn.Module):
         if next_plan is not None and (next_plan.spec.T != self.T or next_plan.y is None):
             next_plan = None
 
-        def launch(dev):
-            st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials, dev_step=dev)
-            mark("fwd")
-            ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
-                                        self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
-                                        scaled_moments=scaled, wrec=wrec, dev_step=dev,
-                                        last_step=self._lazy_last if la else None, step_tab=self._la_tab if la else None,
-                                        listed=self.lookahead_list, la_next=la_next)
-            mark("bwd_adam")
-            return st.pred
-
-        if may_replay and not fresh:
-            plan.index_tensors()                      # (deferred index readbacks: not inside a capture)
-            if next_plan is not None:
-                next_plan.index_tensors()
-            key = ("pipe", id(plan), id(next_plan) if next_plan is not None else 0, cur.data_ptr(), bool(scaled),
-                   wrec.data_ptr() if wrec is not None else 0)
-            out = self._replay(key, launch, step, lr, scaled, keep=(plan, next_plan, cur, nxt, grow, pred))
-        else:
-            self._eager_step_ran()
-            out = launch(None)
+        st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials)
+        mark("fwd")
+        ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
+                                    self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
+                                    scaled_moments=scaled, wrec=wrec,
+                                    last_step=self._lazy_last if la else None, step_tab=self._la_tab if la else None,
+                                    listed=self.lookahead_list, la_next=la_next)
+        mark("bwd_adam")
+        out = st.pred
         if next_plan is not None:
             self._zrec = [nxt, cur]
             self._zrec_for = (next_plan, step + 1, self._flat._version)
@@ -933,7 +786,7 @@ class VFM(nn.Module):
 
     def fit(self, X_train, y_train, n_epochs: int = 50, batch_size: int = 100000, X_test=None,
             y_test=None, display_every: int = 1, lr: Optional[float] = None, verbose: bool = True,
-            process_group=None, sort_within_batch: bool = True):
+            process_group=None, sort_within_batch: bool = True, stream_plans: bool = False):
         """The training loop of vfm-torch.py:337-422: sequential batches without shuffling
         (:121-122), lr = 1/(1 + nb_train // batch_size) (:92), dense Adam, per-epoch train metrics,
         `save_weights()` each epoch for 'reg' (:380), test metrics every `display_every` epochs.
@@ -942,6 +795,9 @@ class VFM(nn.Module):
         once, before training -- the batch composition, the loss and the gradients are unchanged
         (they are sums over the batch's rows), but rows sharing an item become neighbours, so the
         forward gather re-reads item rows from L2 instead of HBM.
+        `stream_plans` (single rank): keep NO plan across steps -- every batch's plan (inverted index, normalisers, look-ahead
+        row list) is built again each time the batch comes up, two steps ahead on a side stream (`plan_async`), as a caller
+        that streams or shuffles its batches has to; same trajectory, bit for bit (tests/test_gpu_model.py).
         Returns a history dict (lists per evaluated epoch)."""
         X_train = torch.as_tensor(X_train)
         y_train = torch.as_tensor(y_train, dtype=torch.float32)
@@ -955,33 +811,27 @@ class VFM(nn.Module):
         if sort_within_batch:
             Xd, yd = sort_rows_within_batches(Xd, yd, batch_size)
         plans, spans = [], []
-        dims = world > 1 and self._resolve_exchange(process_group) == "dims"
+        stream_plans = bool(stream_plans) and world == 1
         for lo in range(0, nb_train, batch_size):
             hi = min(lo + batch_size, nb_train)
-            if dims:
-                a, b = lo, hi                 # every rank handles all rows, d / N coordinates (vae_amd/dims.py)
-            else:
-                a, b = shard_rows(lo, hi, rank, world)
-            plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group,
-                                   defer_readback=True))      # (the index builds are enqueued back to back)
+            a, b = shard_rows(lo, hi, rank, world)
             spans.append((a, b))
+            if not stream_plans:
+                plans.append(self.plan(Xd[a:b], yd[a:b], B_global=hi - lo, process_group=process_group,
+                                       defer_readback=True))      # (the index builds are enqueued back to back)
+        if stream_plans:
+            return self._fit_streamed(Xd, yd, spans, n_epochs, X_test, y_test, display_every, verbose)
         if world == 1 and self.lookahead and self.lookahead_list and len(plans) > 1 and self.n_samples == 1:
             for i, plan in enumerate(plans):              # row lists of the look-ahead step, once per pair of batches --
                 nxt = plans[(i + 1) % len(plans)]         # only where that step form will run (U: one deferred readback)
                 if self._lookahead_pays(plan, nxt) and (not self._will_pipeline(plan, nxt) or self.pipeline_lookahead):
                     plan.prepare_lookahead(nxt)       # (the pipelined step has a look-ahead form too)
         train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
-        replay_before = self.replay
-        if world > 1:
-            self.replay = False               # (the multi-rank steps interleave collectives with their launches)
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
         losses = torch.zeros(len(plans), dtype=torch.float32, device=self.device)
         for epoch in range(n_epochs):
             for i, (plan, (a, b)) in enumerate(zip(plans, spans)):
-                if world > 1 and self.exchange == "dims":
-                    loss3, pr = self.train_step(plan, process_group=process_group)
-                    train_pred[a:b] = pr
-                elif self.n_samples == 1:
+                if self.n_samples == 1:
                     # (the pipelined / look-ahead forms, and the multi-rank rows exchange, are told which batch follows)
                     nxt = plans[(i + 1) % len(plans)] if (world == 1 or self.exchange == "rows") else None
                     loss3, pr = self.train_step(plan, process_group=process_group, next_plan=nxt)
@@ -991,12 +841,15 @@ class VFM(nn.Module):
                     train_pred[a:b] = pr.mean(0)
                 losses[i] = loss3[0]
             # ---- end of epoch (vfm-torch.py:378-384)
+            if epoch == 0 or epoch == n_epochs - 1:
+                for plan in plans:            # (did a kernel have to clamp an entry of a plan's index?  vfm_index_t.status)
+                    plan.check_status()
             if self.output == "reg":
-                self.save_weights()          # (sharded modes: gathers the parameters first)
+                self.save_weights()
             if epoch % display_every == 0:
                 rec = {"epoch": epoch, "elbo": float(losses.mean())}
                 tp = train_pred
-                if world > 1 and self.exchange != "dims":       # each rank only wrote its own row blocks (the rest stays 0)
+                if world > 1:                  # each rank only wrote its own row blocks (the rest stays 0)
                     tp = train_pred.clone()
                     torch.distributed.all_reduce(tp, group=process_group)
                 if self.output == "reg":
@@ -1016,10 +869,47 @@ class VFM(nn.Module):
                           (f"Minibatch train RMSE {rec['train_rmse']:.4f}" if self.output == "reg" else
                            f"Minibatch train AUC {rec['train_auc']:.4f} Minibatch train MAP {rec['train_map']:.4f}"),
                           rec.get("test", ""))
-        self.replay = replay_before
-        if self._step_state is not None and self._step_state.error():
-            raise RuntimeError("a replayed training step found no entry for its Adam step in the device table")
         self.sync_lazy()          # (lazy Adam mode: every row up to date before the caller looks at the tables)
+        return hist
+
+    def _fit_streamed(self, Xd, yd, spans, n_epochs, X_test, y_test, display_every, verbose):
+        """fit() with every plan built when its batch comes up (two steps ahead, on the side stream): the loop of
+        vfm-torch.py:347-422 as a caller that cannot reuse plans runs it."""
+        nb, nb_train = len(spans), Xd.shape[0]
+        train_pred = torch.zeros(nb_train, dtype=torch.float32, device=self.device)
+        hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
+        losses = torch.zeros(nb, dtype=torch.float32, device=self.device)
+        total = n_epochs * nb
+        batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]])
+        cur = self.plan(*batch(0), defer_readback=True)
+        nxt = self.plan_async(*batch(1), pair_with=cur) if total > 1 else None
+        for t in range(total):
+            epoch, i = divmod(t, nb)
+            a, b = spans[i]
+            loss3, pr = self.train_step(cur, next_plan=nxt if self.n_samples == 1 else None,
+                                        prefetch=batch(t + 2) if t + 2 < total else None)
+            train_pred[a:b] = pr if self.n_samples == 1 else pr.mean(0)
+            losses[i] = loss3[0]
+            cur, nxt = nxt, (self.prefetched if t + 2 < total else None)
+            if i == nb - 1:
+                if self.output == "reg":
+                    self.save_weights()
+                if epoch % display_every == 0:
+                    rec = {"epoch": epoch, "elbo": float(losses.mean())}
+                    if self.output == "reg":
+                        rec["train_rmse"] = float(torch.sqrt(torch.mean((train_pred.clamp(1, 5) - yd) ** 2)))
+                    else:
+                        rec["train_auc"], rec["train_map"] = _auc_map(yd, torch.sigmoid(train_pred))
+                    if X_test is not None:
+                        rec["test"] = self.evaluate(X_test, y_test)
+                    for k in ("epoch", "elbo"):
+                        hist[k].append(rec[k])
+                    hist["train_rmse"].append(rec.get("train_rmse"))
+                    hist["train_auc"].append(rec.get("train_auc"))
+                    hist["test"].append(rec.get("test"))
+                    if verbose:
+                        print(f"Epoch {epoch}: Elbo {rec['elbo']:.4f}", rec.get("train_rmse", rec.get("train_auc")), rec.get("test", ""))
+        self.sync_lazy()
         return hist
 
     @torch.no_grad()
@@ -1051,8 +941,7 @@ class VFM(nn.Module):
         """Posterior-predictive mean and variance of the prediction over `n_samples` fresh posterior
         samples (the quantity the paper's preference-elicitation use case consumes: mean + logit
         variance, cf. vfm.py:1024-1057).  Each sample is one forward launch with its own Philox step.
-        Returns dict(mean, var, logits_mean, logits_var); 'reg': mean == logits_mean.
-        Collective after a step of a sharded training mode (the parameters are gathered first)."""
+        Returns dict(mean, var, logits_mean, logits_var); 'reg': mean == logits_mean."""
         self._fresh_params()
         plan = self.plan(X, None)
         ent, bia, scal = self._views(self._flat)

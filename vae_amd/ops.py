@@ -27,13 +27,9 @@ from ._lib import Problem, check, ptr, current_stream_ptr
 FLAG_NO_PRIOR_TERMS = 1
 FLAG_EPS_ZERO = 2
 FLAG_SPARSE_ADAM = 4
-FLAG_ZPRE = 8
 FLAG_LINK_SOFTPLUS = 16
 FLAG_SCALED_MOMENTS = 32
-FLAG_ROWS_UNTOUCHED = 64
 FLAG_ROWS_TOUCHED = 128
-FLAG_PARTIAL_PRED = 256
-FLAG_NO_BIAS = 512
 MOMENT_PERIOD = 128
 MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
@@ -51,7 +47,6 @@ class Spec:
     likelihood: int      # _lib.LIK_NORMAL / LIK_BERNOULLI
     nb_train: int = 1
     n_samples: int = 1   # N_VARIATIONAL_SAMPLES (vfm-torch.py:19)
-    coord_off: int = 0   # dimension-sharded mode: the tables hold coordinates [coord_off, coord_off + d)
     link: str = "abs"    # LINK (vfm-torch.py:125-126): "abs" (the one in effect) or "softplus"
 
     def __post_init__(self):
@@ -79,7 +74,6 @@ def _problem(spec: Spec, B: int, B_global: int, id_bits: int, seed: int = 0, ste
         p.group_hi[g] = int(spec.group_hi[g])
         p.group_n[g] = float(spec.group_n[g])
     p.seed, p.step = seed & (2 ** 64 - 1), step & (2 ** 62 - 1)
-    p.coord_off = int(spec.coord_off)
     return p
 
 
@@ -168,32 +162,40 @@ class BatchPlan:
                 raise ValueError("y must be [B]")
         self.W = None
         self.occ_ptr = self.occ_rows = None
+        self._ready = None               # (event, stream) of a build enqueued on another stream (PlanStream): see use_on_current
+        self._arena = None
         self._heavy = self._pend = None
         self._U = 0
         self._touched = None
         self._checked = False
         dev = x.device
         lib = _lib.load()
-        if inv_occ is not None and y is not None:
+        want_w = inv_occ is not None and y is not None
+        if want_w:
             self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
+        if build_index and y is not None:
+            # the batch normalisers W (vfm-torch.py:305-306) come out of the index build's own launches (the ids are read once)
+            self.build_index(validate=validate, defer=defer_readback, inv_occ=inv_occ if want_w else None)
+        elif want_w:
             p = _problem(spec, self.B, self.B_global, self.id_bits)
             check(lib.vfm_batch_norms(C.byref(p), ptr(x), ptr(inv_occ), ptr(self.W),
                                       current_stream_ptr(dev)), "vfm_batch_norms")
-            if process_group is not None:
-                from .dist import sum_normalisers
-                sum_normalisers(self.W, process_group)
+        if want_w and process_group is not None:
+            from .dist import sum_normalisers
+            sum_normalisers(self.W, process_group)
         if build_index and y is not None:
-            self.build_index(validate=validate, defer=defer_readback)     # (its one readback carries the id check too)
+            pass                                                          # (the build's one readback carries the id check too)
         elif validate and self.B > 0:
             # nn.Embedding would raise IndexError (vfm-torch.py:207): one readback
             if bool(((x < 0) | (x >= spec.T)).any()):
                 raise IndexError(f"entity id out of range [0,{spec.T}): min {int(x.min())}, max {int(x.max())}")
             self._checked = True
 
-    def build_index(self, validate: bool = False, defer: bool = False):
+    def build_index(self, validate: bool = False, defer: bool = False, inv_occ=None):
         """Inverted index entity -> batch rows: `vfm_build_index` (a stable radix sort in HIP, csrc/vfm_index.hip;
         what the reference gets from torch.unique, vfm-torch.py:190-192).  Launch-only except for ONE small
-        readback at the end: (ids out of range, number of heavy lists, number of their work items)."""
+        readback at the end: (ids out of range, number of heavy lists, number of their work items, entities in the
+        batch, most work items of one entity).  inv_occ: also fill self.W in the same launches."""
         spec, dev = self.spec, self.x.device
         lib = _lib.load()
         n = self.B * spec.F
@@ -202,28 +204,31 @@ class BatchPlan:
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
         with _ENQUEUE_LOCK:
-            self._build_index_locked(lib, n, L, nbytes, validate)
+            self._build_index_locked(lib, n, L, nbytes, validate, inv_occ)
         if not defer:
             self._finish()
 
-    def _build_index_locked(self, lib, n, L, nbytes, validate):
+    def _build_index_locked(self, lib, n, L, nbytes, validate, inv_occ=None):
         spec, dev = self.spec, self.x.device
         ws = _index_workspace(nbytes // 4 + 4, dev)       # scratch of the build only: shared by all plans of a device
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
         # ONE device allocation per plan, carved into the index's arrays (seven allocations per plan made the first
         # build of a training set's plans twice as long as the kernels themselves)
-        sizes = [spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 4, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0]
-        arena = torch.empty(sum((v + 3) & ~3 for v in sizes), dtype=torch.int32, device=dev)
+        sizes = [spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 8, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0]
+        arena = self._arena = torch.empty(sum((v + 3) & ~3 for v in sizes), dtype=torch.int32, device=dev)
         occ_ptr, occ_rows, hid, items, counts, touched, other = _carve(arena, sizes)
         items = items.view(cap_i, 4)
         # two fields: also the entity in the other column of every occurrence (the pipelined step gathers its sample)
         self.occ_other = other if spec.F == 2 else None
         check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
                                   ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched),
-                                  ptr(self.occ_other), ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
+                                  ptr(self.occ_other), ptr(inv_occ), ptr(self.W) if inv_occ is not None else None,
+                                  ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
         self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
-        # the plan build's one readback: 16 bytes into pinned host memory, asynchronously
-        host = _pinned_ints(4)
+        # counts[5]: the word the kernels that walk this index report clamped entries in (vfm_index_t.status); zeroed by the build
+        self.status = counts[5:6]
+        # the plan build's one readback: 32 bytes into pinned host memory, asynchronously
+        host = _pinned_ints(8)
         host.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
@@ -233,10 +238,11 @@ class BatchPlan:
         """Complete a deferred index build: read (bad ids, heavy lists, work items, entities) and size the lists."""
         if self._pend is None:
             return
+        self.use_on_current()            # (a build enqueued on a side stream: whatever is launched from here on comes after it)
         host, done, hid, items, touched, validate, _keep = self._pend
         self._pend = None
         done.synchronize()
-        n_bad, n_heavy, n_items, n_touched = (int(v) for v in host.tolist())
+        n_bad, n_heavy, n_items, n_touched, max_items = (int(v) for v in host.tolist()[:5])
         spec, dev = self.spec, self.x.device
         self._U = n_touched                              # entities in the batch
         self._touched = touched[:n_touched]
@@ -253,13 +259,13 @@ class BatchPlan:
             n, L = self.B * spec.F, self.heavy_list
             cap_h, cap_i = n // thr + 1, n // L + n // thr + 2
             arena = torch.empty(((cap_h + 3) & ~3) + 4 * cap_i + 8, dtype=torch.int32, device=dev)
-            hid, items, counts2 = arena[:cap_h], arena[(cap_h + 3) & ~3:((cap_h + 3) & ~3) + 4 * cap_i].view(cap_i, 4), arena[-4:]
+            hid, items, counts2 = arena[:cap_h], arena[(cap_h + 3) & ~3:((cap_h + 3) & ~3) + 4 * cap_i].view(cap_i, 4), arena[-8:]
             lib = _lib.load()
             with _ENQUEUE_LOCK:
                 ws = _index_workspace(int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T)) // 4 + 4, dev)
                 check(lib.vfm_rebuild_heavy(spec.T, ptr(self.occ_ptr), ptr(ws), L, thr, ptr(hid), cap_h, ptr(items), cap_i,
                                             ptr(counts2), current_stream_ptr(dev)), "vfm_rebuild_heavy")
-                _, n_heavy, n_items, _ = (int(v) for v in counts2.tolist())          # (a second small readback, these plans only)
+                _, n_heavy, n_items, _, max_items = (int(v) for v in counts2.tolist()[:5])      # (a second small readback, these plans only)
             self.heavy_threshold = thr
         if validate and n_bad and not self._checked:
             # nn.Embedding would raise IndexError (vfm-torch.py:207)
@@ -270,9 +276,9 @@ class BatchPlan:
         self._heavy = None
         self.heavy_max_items = 0
         if n_heavy > 0:
-            # the most work items one entity has (one small reduction + readback, plans with long lists only): at most
-            # VFM_HEAVY_DIRECT and the backward leaves its k_heavy_sum launch out (vfm_index_t.max_items)
-            self.heavy_max_items = int(torch.bincount(items[:n_items, 0].long(), minlength=1).max())
+            # the most work items one entity has (from the build's own readback): at most VFM_HEAVY_DIRECT and the
+            # backward leaves its k_heavy_sum launch out (vfm_index_t.max_items)
+            self.heavy_max_items = max_items
             self._heavy_meta = torch.tensor([self.heavy_max_items], dtype=torch.int32)
             rec = 4 + (spec.d + 3) // 4 * 4
             self._heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
@@ -306,8 +312,12 @@ class BatchPlan:
         hit = pairs.get(id(next_plan))
         if hit is not None and hit[0]() is next_plan:
             if hit[2] is not None:               # deferred count: first use
-                host, done = hit[2]
+                host, done, src = hit[2]
                 done.synchronize()
+                cur = torch.cuda.current_stream(self.x.device)
+                if cur != src:                   # (made on a side stream: PlanStream)
+                    cur.wait_event(done)
+                    hit[1].record_stream(cur)
                 pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())].clone(), None)      # (frees the upper-bound buffer)
             return pairs[id(next_plan)][1]
         self.prepare_lookahead(next_plan)
@@ -335,9 +345,31 @@ class BatchPlan:
             host.copy_(count, non_blocking=True)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
-        pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done))
+        pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done, torch.cuda.current_stream(dev)))
         if len(pairs) > 4:
             pairs.pop(next(iter(pairs)))
+
+    def use_on_current(self):
+        """A plan built on a side stream (PlanStream) is about to be used on the current one: that stream waits for the
+        build (an event, no host sync) and the caching allocator is told the buffers are in use there."""
+        if self._ready is None:
+            return
+        ev, src = self._ready
+        cur = torch.cuda.current_stream(self.x.device)
+        if cur != src:
+            cur.wait_event(ev)
+            for t in (self._arena, self.W, self.y):
+                if t is not None:
+                    t.record_stream(cur)
+        self._ready = None
+
+    def check_status(self):
+        """Raise if a kernel that walked this plan's index had to clamp an entry (a row number, a list offset or an entity
+        outside its range: a corrupted or stale index -- the kernels never follow such an entry, they count it in
+        `vfm_index_t.status`).  One 4-byte readback: `fit()` calls it once per epoch."""
+        if self.occ_ptr is not None and int(self.status.item()) != 0:
+            raise _lib.VfmLibraryError("corrupted inverted index: a backward kernel clamped entries of this plan's index "
+                                       "(vfm_index_t.status != 0); the step's results are not to be trusted")
 
     def index_tensors(self, with_touched: bool = False):
         """What the backward-family ops take as `index` (with_touched: + the batch's entities as a list, for the
@@ -345,12 +377,56 @@ class BatchPlan:
         if self.occ_ptr is None:
             self.build_index()
         self._finish()
-        base = [self.occ_ptr, self.occ_rows]
+        base = [self.occ_ptr, self.occ_rows, self.status]
         if self.heavy is not None:
             base = base + list(self.heavy)
         if with_touched:
             base = base + [self._touched]
         return base + [self._heavy_meta] if self.heavy is not None else base       # (host tensor: vfm_index_t.max_items)
+
+
+def _index_struct(plan: BatchPlan) -> "_lib.Index":
+    """`vfm_index_t` of a plan (the ctypes callers; the torch.ops shim builds its own from `index_tensors()`)."""
+    if plan.occ_ptr is None:
+        plan.build_index()
+    plan._finish()
+    ix = _lib.Index()
+    ix.occ_ptr, ix.occ_rows, ix.status = plan.occ_ptr.data_ptr(), plan.occ_rows.data_ptr(), plan.status.data_ptr()
+    if plan.heavy is not None:
+        hid, items, acc = plan.heavy
+        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = hid.data_ptr(), items.data_ptr(), acc.data_ptr()
+        ix.n_heavy, ix.n_items = hid.numel(), items.numel() // 4
+        ix.max_items = plan.heavy_max_items
+    return ix
+
+
+class PlanStream:
+    """A side stream for plan builds: the index of batch t+1 (and the look-ahead row list of the pair) is built WHILE step t
+    runs -- what a caller that streams or shuffles its batches needs, since nothing of a plan can then be reused (the
+    reference itself pays torch.unique x3 inside every step, vfm-torch.py:190-192).  Fork / join by events only: the side
+    stream waits for the caller's stream at the point of the call (the ids may have just been produced there), and the plan
+    carries the event its first user waits for (`BatchPlan.use_on_current`).  The builds are small latency-bound launches
+    (~40 us of GPU time per batch at the ML-20M shape) that fit beside the bandwidth-bound step kernels."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def build(self, make, pair_with: Optional[BatchPlan] = None) -> BatchPlan:
+        """`make()` -> BatchPlan, called with the side stream current (build it with defer_readback=True); `pair_with`: also
+        enqueue the look-ahead row list of (pair_with, new plan) there."""
+        main = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        self.stream.wait_event(fork)
+        with torch.cuda.stream(self.stream):
+            plan = make()
+            if pair_with is not None:
+                pair_with.prepare_lookahead(plan)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        plan._ready = (ev, self.stream)
+        return plan
 
 
 @dataclass
@@ -391,7 +467,7 @@ def elbo_forward(plan: BatchPlan, entity_params, bias_params, scalars, inv_occ, 
     _lib.ops().elbo_fwd(plan.x, plan.y, entity_params, bias_params, inv_occ if have_y else None, scalars,
                         plan.W if have_y else None, e[0], e[1], e[2], pred, partials, sumz, grow,
                         list(spec.group_hi), list(spec.group_n), spec.nb_train, plan.B_global,
-                        spec.likelihood, p.flags, p.seed & _I63, p.step, S, spec.coord_off,
+                        spec.likelihood, p.flags, p.seed & _I63, p.step, S,
                         wrec if (train and eps is None) else None, dev_step)
     return FwdState(pred, partials, sumz, grow, p, eps)
 
@@ -421,7 +497,7 @@ def elbo_backward(plan: BatchPlan, st: FwdState, entity_params, bias_params, sca
     _lib.ops().elbo_bwd(plan.index_tensors(), entity_params, bias_params, inv_occ, scalars, plan.W,
                         e[0], e[1], e[2], st.sumz, st.grow, st.partials, grad_out, g_entity, g_bias, g_scalars,
                         spec.F, list(spec.group_hi), list(spec.group_n), p.nb_train, p.B_global, p.likelihood,
-                        p.flags, p.seed & _I63, p.step, p.n_samples, p.coord_off)
+                        p.flags, p.seed & _I63, p.step, p.n_samples)
     return g_entity, g_bias, g_scalars
 
 
@@ -432,10 +508,8 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
     m_views / v_views = (entity, bias, scalars) moment tensors.  `loss_out` (3 floats): also do the
     work of elbo_finalize in the same launch.  `scaled_moments`: the buffers are in the scaled form of
     VFM_FLAG_SCALED_MOMENTS (see include/vfm_hip.h; `moments_rescale` converts).  `rows`: None = all
-    table rows; "untouched" = only the rows the batch does not contain (pure Adam decay -- may run
-    concurrently with the forward on another stream, `st` then only carries the problem and placeholder
-    buffers); "touched" = the complement (+ scalars, loss)."""
-    rows_flag = {None: 0, "untouched": FLAG_ROWS_UNTOUCHED, "touched": FLAG_ROWS_TOUCHED}[rows]
+    table rows; "touched" = only the rows of the batch (+ scalars, loss): the row-list step of the lazy exact Adam."""
+    rows_flag = {None: 0, "touched": FLAG_ROWS_TOUCHED}[rows]
     if plan.occ_ptr is None:
         plan.build_index()
     e = st.eps if st.eps is not None else (None, None, None)
@@ -448,7 +522,7 @@ def elbo_backward_adam(plan: BatchPlan, st: FwdState, entity_params, bias_params
                              p.flags | (FLAG_SPARSE_ADAM if sparse else 0) |
                              (FLAG_SCALED_MOMENTS if scaled_moments else 0) | rows_flag,
                              p.seed & _I63, p.step, lr, beta1, beta2, eps_adam, int(step), loss_out, p.n_samples,
-                             p.coord_off, wrec, dev_step)
+                             wrec, dev_step)
 
 
 FLAG_ZREC = 1024
@@ -461,7 +535,7 @@ def record_len(d: int) -> int:
 
 def pipeline_supported(spec: Spec) -> bool:
     """The software-pipelined step covers the reference's own shape: two fields, one sample, d % 4 == 0, d <= 512."""
-    return spec.F == 2 and int(spec.n_samples) == 1 and spec.d % 4 == 0 and spec.d <= 512 and spec.coord_off == 0
+    return spec.F == 2 and int(spec.n_samples) == 1 and spec.d % 4 == 0 and spec.d <= 512 and spec.link == "abs"
 
 
 def sample_records(plan: BatchPlan, entity_params, bias_params, inv_occ, zrec, seed, step):
@@ -490,13 +564,7 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
                             listed=True, la_next=None):
     """vfm_elbo_bwd_adam_pipe_f32: loss + backward + dense Adam, gathering samples from `zrec`, and (next_plan given)
     writing the records of `next_plan`'s entities for Philox step `next_step` into `zrec_next`."""
-    t = plan.index_tensors()
-    ix = _lib.Index()
-    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
-    if len(t) >= 5:
-        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
-        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
-        ix.max_items = plan.heavy_max_items
+    ix = _index_struct(plan)
     ix.occ_other = plan.occ_other.data_ptr()
     pipe = _lib.Pipe()
     pipe.zrec = zrec.data_ptr()
@@ -532,17 +600,11 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
                                  beta1=0.9, beta2=0.999, eps_adam=1e-8, listed=True, wrec=None, dev_step=None):
     """vfm_elbo_bwd_adam_lookahead_f32: the fused dense step visiting only the rows of this batch and of the next
     (listed: as a list made once per pair of plans; else the kernel classifies all T rows itself)."""
-    t = plan.index_tensors()
-    ix = _lib.Index()
-    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
+    ix = _index_struct(plan)
     if listed:
         rows = plan.lookahead_rows(next_plan)
         if rows.numel() > 0:
             ix.touched_ids, ix.n_touched = rows.data_ptr(), rows.numel()
-    if len(t) >= 5:
-        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
-        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
-        ix.max_items = plan.heavy_max_items
     if next_plan.occ_ptr is None:
         next_plan.build_index()
     p = st.problem
@@ -583,7 +645,8 @@ class StepState:
     """Device-resident step state (`vfm_dev_step_t` + its table of per-step Adam constants): what lets a captured HIP
     graph of a training step be REPLAYED -- the kernels read the Philox step and the Adam constants from here and
     advance the counters themselves (include/vfm_hip.h).  The table is filled on the host by `vfm_step_consts` (the
-    arithmetic of the host-argument path, so a replayed trajectory is bitwise the eager one)."""
+    arithmetic of the host-argument path, so a replayed trajectory is bitwise the eager one).  For callers that capture
+    their own graphs (`VFM.fit` launches eagerly: tests/test_gpu_replay.py is the worked example)."""
     WINDOW = 4096          # Adam steps per table fill
 
     def __init__(self, device):
@@ -606,6 +669,7 @@ class StepState:
         self.tab.copy_(raw)               # (synchronous copy from pageable memory: the host buffer may go right after)
         hdr = _lib.DevStep()
         hdr.tab_first, hdr.tab_len, hdr.tab = adam_step, self.WINDOW, self.tab.data_ptr()
+        hdr.error = int(self.dev[7].item())       # (sticky: a table miss of earlier replays survives the refill)
         self.dev.copy_(torch.frombuffer(bytearray(bytes(hdr)), dtype=torch.int64))
         self.first, self.length, self.key, self.counters = adam_step, self.WINDOW, key, None
 
@@ -641,7 +705,7 @@ def elbo_backward_acc(plan: BatchPlan, st: FwdState, acc, sums, e_lo=0, e_hi=0):
 
 def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bias_params, scalars,
                     inv_occ, m_views, v_views, lr, step, beta1=0.9, beta2=0.999, eps_adam=1e-8, e_lo=0, e_hi=0,
-                    own_mod=1, own_rank=0, kl_ws=None, rec_index=None, scaled_moments=False):
+                    scaled_moments=False):
     """Multi-rank backward, stage 2: gradient epilogue + dense Adam from the rank-summed statistics of
     the entities [e_lo, e_hi) (the chunk that ends at T also updates the three scalars)."""
     e = st.eps if st.eps is not None else (None, None, None)
@@ -652,20 +716,13 @@ def elbo_apply_adam(plan: BatchPlan, st: FwdState, acc, sums, entity_params, bia
                                p.B_global, p.likelihood,
                                (p.flags & ~FLAG_NO_PRIOR_TERMS) | (FLAG_SCALED_MOMENTS if scaled_moments else 0),
                                p.seed & _I63, p.step,
-                               lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi, own_mod, own_rank, kl_ws,
-                               rec_index[0] if rec_index else None, rec_index[1] if rec_index else None)
+                               lr, beta1, beta2, eps_adam, int(step), e_lo, e_hi)
 
 
 def elbo_backward_acc_rows(plan: BatchPlan, st: FwdState, row_ids, acc, sums):
     """vfm_elbo_bwd_acc_rows_f32: this shard's gradient statistics of the listed rows (sorted int32 ids), written
     COMPACTLY: record i of `acc` belongs to row_ids[i] (zeros for listed rows this shard does not contain)."""
-    t = plan.index_tensors()
-    ix = _lib.Index()
-    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
-    if len(t) >= 5:
-        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
-        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
-        ix.max_items = plan.heavy_max_items
+    ix = _index_struct(plan)
     spec = plan.spec
     p = _problem(spec, plan.B, plan.B, 64)
     check(_lib.load().vfm_elbo_bwd_acc_rows_f32(C.byref(p), C.byref(ix), ptr(row_ids), row_ids.numel(), ptr(st.sumz),
@@ -688,15 +745,6 @@ def elbo_apply_adam_rows(plan: BatchPlan, st: FwdState, acc, sums, row_ids, enti
         ptr(inv_occ), ptr(plan.W), ptr(m_views[0]), ptr(v_views[0]), ptr(m_views[1]), ptr(v_views[1]), ptr(m_views[2]),
         ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), current_stream_ptr(entity_params.device)),
         "vfm_elbo_apply_adam_rows_f32")
-
-
-def elbo_lik(st: FwdState, y, scalars, flags=0):
-    """Dimension-sharded mode, after the all-reduce of st.pred[0..B] (row values + KL term): predictions,
-    grow and a `partials` workspace as a full forward would have left it (in place on st)."""
-    p = st.problem
-    e = st.eps if st.eps is not None else (None, None, None)
-    _lib.ops().elbo_lik(y, scalars, e[2], st.pred, st.grow, st.partials, p.nb_train, p.B_global, p.likelihood,
-                        flags | (p.flags & FLAG_LINK_SOFTPLUS), p.seed & _I63, p.step)
 
 
 def moments_rescale(m, v, step, to_scaled, beta1=0.9, beta2=0.999):

@@ -29,15 +29,7 @@ def priors_len(G: int, d: int) -> int:
     return 2 + 2 * G + 2 * G * d
 
 
-def _index_struct(plan: ops.BatchPlan) -> _lib.Index:
-    t = plan.index_tensors()
-    ix = _lib.Index()
-    ix.occ_ptr, ix.occ_rows = t[0].data_ptr(), t[1].data_ptr()
-    if len(t) >= 5:
-        ix.heavy_ids, ix.heavy_items, ix.heavy_acc = t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr()
-        ix.n_heavy, ix.n_items = t[2].numel(), t[3].numel() // 4
-        ix.max_items = plan.heavy_max_items
-    return ix
+_index_struct = ops._index_struct
 
 
 def variant_forward(plan: ops.BatchPlan, objective: str, entity_params, bias_params, scalars, inv_occ, *,
