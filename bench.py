@@ -312,11 +312,12 @@ def main():
         t0 = step_no[0]
         cur = model.plan(*bt[t0 % nbt], defer_readback=True)
         nxt = model.plan_async(*bt[(t0 + 1) % nbt], pair_with=cur)
-        for _ in range(n):
+        nx2 = model.plan_async(*bt[(t0 + 2) % nbt], pair_with=nxt)
+        for _ in range(n):       # three plans in hand: this batch's, the next one's (named to the step), the one after (being built)
             s = step_no[0]
             step_no[0] += 1
-            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 2) % nbt])
-            cur, nxt = nxt, model.prefetched
+            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 3) % nbt] + (False, nx2))   # (resident data: no fork)
+            cur, nxt, nx2 = nxt, nx2, model.prefetched
 
     def run(plans, n, events, streamed=None):
         if streamed is not None:

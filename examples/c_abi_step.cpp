@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
   VFM_OK(vfm_inv_occ_f32(d_occ, d_inv, T, st));                       // once per training set
   // once per batch: the index AND the batch normalisers W (vfm-torch.py:305-306), in the same launches
   VFM_OK(vfm_build_index(B, (int32_t)F, T, 64, d_x, d_ws, d_ptr, d_rows, L, d_hid, cap_h, d_items, cap_i, nullptr, nullptr,
-                         d_inv, d_W, d_counts, st));
+                         d_inv, d_W, d_counts, nullptr, st));
   int32_t counts[8];
   HIP_OK(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));

@@ -80,6 +80,11 @@ extern "C" {
                                      x holds entity ids as usual.  Nothing is sampled and no sumz is written (the
                                      pipelined backward gathers the samples themselves): bias_params, inv_occ, W, sumz
                                      may be NULL.  Half the gather bytes of the (mu | s) rows, no RNG.  |.| link only. */
+#define VFM_FLAG_SHARE_GPU 2048   /* the caller runs other work BESIDE this step -- the next batches' index builds on a side stream
+                                     (vfm_build_index) -- so the two-field forward and the fused backward launch 7/8 of the
+                                     workgroups the chip can hold instead of filling every slot: small kernels of the other
+                                     stream then find room at once (ML-20M shape, plans built inside the loop: 0.242 -> 0.220 ms
+                                     per step; with nothing beside it the step itself is 3 % slower, hence a flag)            */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 #define VFM_FLAG_LINK_SOFTPLUS 16 /* LINK = softplus instead of |.| (vfm-torch.py:125-126; applies to alpha,
@@ -258,6 +263,8 @@ const char* vfm_last_error(void);
  *             clamps them --, n_heavy, n_items, n_touched = entities in the batch, max_items = the most work items one
  *             heavy entity has (vfm_index_t.max_items), 0 = a zeroed word for vfm_index_t.status, 0, 0): the caller reads
  *             them back once to fill vfm_index_t
+ *   counts_host  NULL, or 8 int32 of PINNED HOST memory: the library enqueues that readback itself (an asynchronous copy
+ *             behind the last kernel; the caller synchronises with the stream or an event of its own before reading)
  * Launches (B*F <= 2^31 keys, T < 2^32): one memset, key extraction (+ the first pass's digit counts, W), one stable scatter
  * per ceil(log2 T / 9) radix passes (each also counts the next pass's digits and, once, the occurrences per entity), and two
  * compaction launches -- six at the ML-20M shape (was sixteen). */
@@ -284,7 +291,7 @@ int32_t vfm_heavy_list_for(int64_t n_occ, int64_t T);
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
                     int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other,
-                    const float* inv_occ, double* W, int32_t* counts, void* stream);
+                    const float* inv_occ, double* W, int32_t* counts, int32_t* counts_host, void* stream);
 
 /* inv_occ[e] = 1 / nb_occ[e]   (nb_occ = bincount of the training ids, vfm-torch.py:89;
  * used as `nb_occ[uniq]` divisors at :298-306,315).  Done once per training set. */
@@ -490,10 +497,11 @@ int vfm_adam_catchup_f32(float* entity_params, float* bias_params, const float* 
  * arguments as vfm_elbo_bwd_adam_f32 otherwise (Philox eps). */
 /* rows [count] = the sorted ids of the entities that occur in batch A or in batch B (their inverted indexes' occ_ptr
  * arrays), count[0] (DEVICE int32) their number; ws = vfm_union_workspace_bytes(T) bytes of scratch.  Room for
- * min(T, n_occ_A + n_occ_B) ids always suffices.  Launch-only, no atomics: two calls give the same list. */
+ * min(T, n_occ_A + n_occ_B) ids always suffices.  Launch-only, no atomics: two calls give the same list.  count_host: NULL, or one int32 of
+ * PINNED HOST memory the count is copied to asynchronously (as vfm_build_index's counts_host). */
 int64_t vfm_union_workspace_bytes(int64_t T);
 int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b, void* ws, int32_t* rows, int32_t* count,
-                   void* stream);
+                   int32_t* count_host, void* stream);
 int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* idx,
                                     float* entity_params, float* bias_params, float* scalars,
                                     const float* inv_occ, const double* W,

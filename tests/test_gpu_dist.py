@@ -168,7 +168,7 @@ def test_lazy_statistics_step_is_bitwise_the_dense_one(F, d, monkeypatch):
 
 
 @pytest.mark.parametrize("world,B,d,output,n_steps,announce", [(3, 96, 32, "reg", 60, False), (3, 96, 32, "reg", 150, True),
-                                                              (5, 4, 16, "class", 60, True), (8, 300, 128, "reg", 20, True)])
+                                                              (5, 4, 16, "class", 60, True), (8, 300, 128, "reg", 16, True)])
 def test_rows_exchange_follows_the_single_rank_pipelined_step(world, B, d, output, n_steps, announce, monkeypatch):
     """`exchange = "rows"` (vae_amd/dist.py::step_rows): the ranks all-reduce every row's dloss/dpred and the six ELBO sums
     (B_global + 8 doubles), each samples the records of all the batch's entities from its replica and runs the whole

@@ -36,6 +36,9 @@ CASES = [  # (B, field sizes, zipf exponent or None, id dtype)
     (300000, [138493, 26744], 1.05, torch.int32),   # 293 sort tiles: the per-digit scan kernel (more than 256 tiles)
     (263000, [90, 26744], None, torch.int64),       # 257 tiles, one column with very long lists
     (60000, [300, 40000], 1.3, torch.int64),        # many rows per entity, a small part of a large table: the lowered heavy threshold
+    (3000, [200, 300], 1.2, torch.int64),           # 9-bit keys: ONE radix pass (the first pass is the last)
+    (5000, [1024, 1024], None, torch.int32),        # T a multiple of the compaction chunk: occ_ptr[T] has no thread of its own
+    (70000, [2, 3], None, torch.int64),             # 3-bit keys, 69 sort tiles in three tile groups, five enormous lists
 ]
 
 
@@ -67,8 +70,104 @@ def test_index_equals_stable_sort(B, sizes, zipf, dtype):
         assert plan.heavy is None
     uniq = np.unique(X.cpu().numpy())
     assert plan.U == len(uniq) and np.array_equal(plan.touched_ids().cpu().numpy(), uniq)
-    # W (vfm_batch_norms) with inv_occ = 1 is the row count of every column
+    # W (formed inside the index build for F <= 4, by vfm_batch_norms' kernels otherwise) with inv_occ = 1 is the row count of every column
     assert np.allclose(plan.W.cpu().numpy(), B)
+    # the most work items one heavy entity has (vfm_index_t.max_items), from the build's own readback
+    if len(heavy_want):
+        assert plan.heavy_max_items == int(np.bincount(items_want[:, 0]).max())
+    if F == 2:      # the entity in the other column of every occurrence
+        xn = X.cpu().numpy().astype(np.int64)
+        order = np.argsort(xn.reshape(-1), kind="stable")
+        assert np.array_equal(plan.occ_other.cpu().numpy()[: 2 * B], xn.reshape(-1)[order ^ 1].astype(np.int32))
+    assert int(plan.status.item()) == 0
+
+
+def test_normalisers_from_the_index_build_equal_the_stand_alone_kernels():
+    """W_f = sum_r 1/occ(x_rf) (vfm-torch.py:305-306) comes out of the index build's own launches (fp64, fixed order) for up
+    to four fields: == vfm_batch_norms (fp64 partial sums + fixed-point integer atomics) to 1e-9, == numpy's fp64 sum, and
+    bitwise reproducible."""
+    import ctypes as C
+    from vae_amd import ops, _lib
+    from vae_amd.data import synthetic_triples
+    dev = torch.device("cuda:0")
+    for sizes, B in (([5000, 300], 70001), ([40, 30, 20], 5000), ([10, 10, 10, 10], 333), ([9] * 5, 4000)):
+        F, T = len(sizes), int(sum(sizes))
+        X, y = synthetic_triples(sizes, B, seed=3, device=dev, zipf=1.1)
+        occ = torch.randint(1, 900, (T,), device=dev)
+        inv_occ = ops.inv_occ_from_counts(occ)
+        spec = ops.Spec(T=T, F=F, d=8, group_hi=tuple(int(v) for v in np.cumsum(sizes)), group_n=tuple(float(v) for v in sizes), likelihood=0)
+        a, b = ops.BatchPlan(spec, X, y, inv_occ), ops.BatchPlan(spec, X, y, inv_occ)
+        assert torch.equal(a.W, b.W)
+        alone = torch.empty(F, dtype=torch.float64, device=dev)
+        p = ops._problem(spec, B, B, 64)
+        _lib.check(_lib.load().vfm_batch_norms(C.byref(p), _lib.ptr(X), _lib.ptr(inv_occ), _lib.ptr(alone),
+                                               _lib.current_stream_ptr(dev)), "vfm_batch_norms")
+        want = inv_occ.double().cpu().numpy()[X.cpu().numpy()].sum(0)
+        assert np.allclose(a.W.cpu().numpy(), want, rtol=1e-12) and np.allclose(alone.cpu().numpy(), want, rtol=1e-9)
+
+
+def test_a_corrupted_index_is_clamped_and_reported_not_followed():
+    """The kernels that walk an inverted index bound what they read: an occ_ptr that is not monotone, list
+    offsets past B*F, row numbers outside [0, B) -- a freed or overwritten plan -- give a FINITE run (no hang, no fault), a
+    non-zero vfm_index_t.status, and `BatchPlan.check_status()` raises.  Every backward family: gradients, fused Adam,
+    statistics, the pipelined form with its heavy-list pre-reduction, the variants' backward."""
+    from vae_amd import ops, _lib
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    from vae_amd.variants import variant_forward, variant_backward
+    dev = torch.device("cuda:0")
+    sizes, d, B = [300, 40], 32, 4000
+    X, y = synthetic_triples(sizes, B, seed=2, device=dev, zipf=1.2)
+    torch.manual_seed(1)
+    m = VFM(field_sizes=sizes, embedding_size=d, device=dev, rng_seed=5)
+    m.set_training_data(X, nb_train=B)
+    m._ensure_opt_state()
+    m._set_moment_form(True)
+    ent, bia, scal = m._views(m._flat)
+    mv, vv = m._views(m._adam_m), m._views(m._adam_v)
+    g = torch.Generator(device="cpu").manual_seed(7)
+
+    def broken(kind):
+        plan = m.plan(X, y)
+        assert plan.heavy is not None and int(plan.status.item()) == 0
+        if kind == "ptr":          # not monotone, negative, far past the end
+            bad = torch.randint(-5, 3 * B * 2, (m.T + 1,), generator=g).to(torch.int32)
+            plan.occ_ptr.copy_(bad.to(dev))
+        elif kind == "rows":       # row numbers outside the batch
+            plan.occ_rows.copy_(torch.randint(-B, 5 * B, (2 * B,), generator=g).to(torch.int32).to(dev))
+        elif kind == "items":      # work items naming lists that do not exist
+            hid, items, acc = plan.heavy
+            items.copy_(torch.randint(-7, 4 * B, tuple(items.shape), generator=g).to(torch.int32).to(dev))
+        elif kind == "other":      # entities outside the table in the other-column array (the pipelined walk)
+            plan.occ_other.copy_(torch.randint(-9, 50 * m.T, (2 * B,), generator=g).to(torch.int32).to(dev))
+        return plan
+
+    for kind in ("ptr", "rows", "items"):
+        plan = broken(kind)
+        st = ops.elbo_forward(plan, ent, bia, scal, m.inv_occ, seed=5, step=1)
+        ops.elbo_finalize(st, scal)
+        ops.elbo_backward(plan, st, ent.clone(), bia.clone(), scal.clone(), m.inv_occ, torch.ones(1, device=dev))
+        ops.elbo_backward_adam(plan, st, ent.clone(), bia.clone(), scal.clone(), m.inv_occ, mv, vv, 0.01, 1,
+                               loss_out=torch.zeros(3, device=dev), scaled_moments=True)
+        torch.cuda.synchronize()            # (returns: nothing hung)
+        assert int(plan.status.item()) > 0, kind
+        with pytest.raises(_lib.VfmLibraryError):
+            plan.check_status()
+    for kind in ("other", "rows"):          # the pipelined step's backward: gathers the other entity's record per occurrence
+        plan = broken(kind)
+        zrec = torch.zeros(m.T, ops.record_len(d), device=dev)
+        ops.sample_records(plan, ent, bia, m.inv_occ, zrec, 5, 1)
+        st = ops.elbo_forward_records(plan, zrec, scal, 5, 1, torch.empty(B, device=dev), torch.empty(B, device=dev), m._partials)
+        ops.elbo_backward_adam_pipe(plan, st, zrec, None, None, 2, ent.clone(), bia.clone(), scal.clone(), m.inv_occ, mv, vv, 0.01, 1,
+                                    torch.zeros(3, device=dev))
+        torch.cuda.synchronize()
+        assert int(plan.status.item()) > 0, kind
+    plan = broken("ptr")                    # the sibling scripts' objective (closed form), lane-group kernels
+    spec = plan.spec
+    fw = variant_forward(plan, "closed_form", ent, bia, scal, m.inv_occ, seed=5, step=1)
+    variant_backward(plan, fw, ent, bia, scal, m.inv_occ, torch.ones(1, device=dev))
+    torch.cuda.synchronize()
+    assert int(plan.status.item()) > 0
 
 
 def test_empty_shard_and_bad_ids():

@@ -628,3 +628,29 @@ def test_step_is_capturable_in_a_hip_graph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(ba[3], bb[3])
+
+
+@pytest.mark.parametrize("shape", ["lookahead", "pipelined", "dense_small_table"])
+def test_streamed_plans_give_the_resident_plans_trajectory(shape):
+    """fit(stream_plans=True): no plan is kept -- every batch's index, normalisers and look-ahead row list are built again
+    when the batch comes up, two steps ahead on the side stream (plan_async / train_step(prefetch=)) -- and the run is the
+    resident-plans run BIT FOR BIT (plans are parameter-free: the same buffers, built on another stream).  The regime of a
+    caller that streams or shuffles batches; the reference pays torch.unique x3 inside every step (vfm-torch.py:190-192)."""
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    sizes, d, n, bs = {"lookahead": ([3000, 900], 32, 9000, 1000), "pipelined": ([300, 200], 32, 12000, 3000),
+                       "dense_small_table": ([60, 40], 20, 2400, 400)}[shape]
+    X, y = synthetic_triples(sizes, n, seed=9, device="cuda")
+    Xt, yt = synthetic_triples(sizes, 500, seed=10, device="cuda")
+    runs = []
+    for stream in (False, True):
+        torch.manual_seed(5)
+        m = VFM(sizes[0], sizes[1], d, device="cuda", rng_seed=3)
+        if shape == "pipelined":
+            m.pipeline, m.pipeline_min_T = True, 0
+        h = m.fit(X, y, n_epochs=3, batch_size=bs, X_test=Xt, y_test=yt, verbose=False, stream_plans=stream)
+        runs.append((m, h))
+    (m0, h0), (m1, h1) = runs
+    assert h0["elbo"] == h1["elbo"] and h0["train_rmse"] == h1["train_rmse"] and h0["test"] == h1["test"]
+    assert torch.equal(m0._flat, m1._flat) and torch.equal(m0._adam_m, m1._adam_m) and torch.equal(m0._mean_flat, m1._mean_flat)
+    assert m1._plan_stream is not None and getattr(m0, "_plan_stream", None) is None

@@ -66,7 +66,9 @@ def test_pipelined_trajectory_equals_plain(cfg):
         assert rel_err(la.cpu().numpy(), lb.cpu().numpy()) < (2e-5 if s < 5 else 2e-4), s      # (later: trajectory amplification)
         if s in (0, 1, 39):
             assert rel_err(pa.cpu().numpy(), pb.cpu().numpy()) < (1e-4 if s < 5 else 2e-3), s
-    assert a._zrec is not None and b._zrec is None
+    # (the record step exists for the |.| link -- the assignment in effect in the reference, vfm-torch.py:126; with the
+    #  softplus link `pipeline = True` falls back to the plain fused step: the two runs are then the same form)
+    assert (a._zrec is None if cfg.get("link") == "softplus" else a._zrec is not None) and b._zrec is None
     a.sync_lazy(); b.sync_lazy()          # (the pipelined step runs in its look-ahead form: rows outside the two batches lag)
     # Adam normalises every coordinate's step, so a last-bit difference in a tiny gradient grows over the steps; the
     # skewed case (long lists: summed in another order by the two forms) is the loosest

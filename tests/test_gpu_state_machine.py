@@ -48,13 +48,19 @@ def _same_state(a, b, exact, where):
         if exact:
             assert torch.equal(ta, tb), (where, name)
             continue
-        # per table (entity rows, first-order rows, the three scalars): 1e-4 of its largest entry -- alpha's first moment too
+        # per table (entity rows, first-order rows, the three scalars): 1e-4 of its largest entry.  The scalars' first moments
+        # against 1e-4 of the scale of what they are a DIFFERENCE of: dloss/dalpha = nb_train/B sum_r (y-pred)^2/2 - nb_train/(2|alpha|)
+        # -- the two models' predictions differ by the trajectories' 1e-5 after a hundred steps, the halves by as much, their
+        # difference by that much of a HALF (each form by itself is within 2e-6 of the halves of the fp64 truth: last test)
         for part, (pa, pb) in enumerate(zip(a._views(ta), b._views(tb))):
-            assert float((pa - pb).abs().max()) <= 1e-4 * float(pb.abs().max()) + 1e-30, (where, name, part)
+            scale = float(pb.abs().max())
+            if part == 2 and name == "_adam_m":         # (scaled form: the buffers hold m / beta1^k, k = steps into the moment period)
+                scale = max(scale, a.nb_train / (2.0 * abs(float(b.alpha))) * (0.9 ** -(a._adam_t % 128) if a._moments_scaled else 1.0))
+            assert float((pa - pb).abs().max()) <= 1e-4 * scale + 1e-30, (where, name, part)
     assert a._adam_t == b._adam_t and a.global_step == b.global_step, where
 
 
-def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None):
+def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None, with_twin=False):
     import vae_amd.model as M
     if monkeypatch is not None:
         monkeypatch.setattr(M, "_CHECK_WREC", True)
@@ -65,7 +71,7 @@ def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None):
     ref.lookahead = ref.pipeline = ref.use_wrec = False
     ref.lazy_adam = False
     twin = plans_w = None
-    if with_pipeline:       # the same sequence with every lazy form replaced by its every-row equivalent: bitwise `tst`
+    if with_twin:           # the same sequence with every lazy form replaced by its every-row equivalent: bitwise `tst`
         twin, plans_w, _ = _make(sizes, d, B, nb, output)
         twin.lookahead = twin.use_wrec = False
         twin.lazy_adam = False
@@ -100,7 +106,10 @@ def _walk(cfg, seed, with_pipeline, n_steps=140, monkeypatch=None):
         elif act == "lr":
             lr = float(g.choice([0.05, 0.02, 0.08]))
         # ---- the step form of the model under test
-        form = str(g.choice(["dense", "la_list", "la_scan", "lazy_list", "lazy_auto", "unfused"] + (["pipe", "pipe_la", "pipe_la"] if with_pipeline else [])))
+        # (twin walks: no row-list lazy form -- rows lagging in THAT form keep the next step from pipelining, so the twin,
+        #  whose rows never lag, would take another step form: a rule of the step, not a difference to test)
+        form = str(g.choice(["dense", "la_list", "la_scan"] + ([] if with_twin else ["lazy_list", "lazy_auto"]) + ["unfused"] +
+                            (["pipe", "pipe_la", "pipe_la"] if with_pipeline else [])))
         tst.lookahead = form in ("la_list", "la_scan", "pipe_la")
         tst.lookahead_list = form != "la_scan"
         tst.lazy_adam = {"lazy_list": True, "lazy_auto": "auto"}.get(form, False)
@@ -155,6 +164,16 @@ def test_random_sequences_with_the_pipelined_step(seed, monkeypatch):  #  1e-4 i
     assert {"pipe", "pipe_la"} <= {t[2] for t in trace}
 
 
+@pytest.mark.parametrize("seed", [6, 7, 8, 104])
+def test_lazy_forms_are_bitwise_their_every_row_twins_in_walks_with_the_pipelined_step(seed, monkeypatch):
+    """the pipelined look-ahead form against the every-row pipelined form INSIDE the random walk -- a twin model
+    takes the same sequence (steps, predictions, checkpoints, un-announced batches) with look-ahead off, i.e. every
+    look-ahead step as a dense one and every pipelined look-ahead step as an every-row pipelined one: loss triple and
+    predictions equal BIT FOR BIT after every step, parameters and moments at random points and at the end."""
+    trace = _walk("F2_d32", seed, with_pipeline=True, monkeypatch=monkeypatch, with_twin=True)
+    assert {"pipe", "pipe_la", "la_list"} <= {t[2] for t in trace}
+
+
 def test_alpha_gradient_of_both_forward_forms_against_the_fp64_oracle():
     """dloss/dalpha = sign(alpha) nb_train / B * sum_r [(y - pred)^2 / 2 - 1 / (2|alpha|)] is a CANCELLING sum (zero at the
     optimum of alpha), the least accurate number the step emits when the rows' differences are added in fp32.  Here alpha
@@ -179,7 +198,9 @@ def test_alpha_gradient_of_both_forward_forms_against_the_fp64_oracle():
     ee, eb, eg = (t.cpu().numpy() for t in ops.philox_eps(spec, seed=11, step=5, device=dev))
 
     def oracle():
-        P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        ent_, bia_, scal_ = (t.detach().cpu().numpy() for t in m._views(m._flat))
+        P = {"alpha": scal_[0:1], "global_bias_mean": scal_[1:2], "global_bias_scale": scal_[2:3], "bias_params": bia_,
+             "entity_params": ent_}
         return O.rowwise_elbo(P, X.cpu().numpy(), y.cpu().numpy().astype(np.float64), m.nb_occ.cpu().numpy(), np.array(m.group_hi),
                               np.array(m.group_n), m.nb_train, eg, eb, ee, "reg")
     r0 = oracle()

@@ -115,7 +115,7 @@ def load():
     lib.vfm_moments_rescale_f32.argtypes = [vp, vp, i64, C.c_float, C.c_float, i64, i32, vp]
     lib.vfm_index_workspace_bytes.argtypes = [i64, i32, i64]
     lib.vfm_heavy_list_for.argtypes = [i64, i64]
-    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.vfm_build_index.argtypes = [i64, i32, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.vfm_rebuild_heavy.argtypes = [i64, vp, vp, i32, i32, vp, i64, vp, i64, vp, vp]
     lib.vfm_adam_catchup_f32.argtypes = [vp] * 8 + [i64, i64, i32, C.POINTER(C.c_float), i64, C.c_float, C.c_float, C.c_float,
                                          i64, i64, vp, vp]
@@ -131,7 +131,7 @@ def load():
     lib.vfm_variant_bwd_f32.argtypes = [PP, i32, C.POINTER(Index)] + [vp] * 21
     lib.vfm_union_workspace_bytes.argtypes = [i64]
     lib.vfm_union_workspace_bytes.restype = i64
-    lib.vfm_union_rows.argtypes = [i64] + [vp] * 6
+    lib.vfm_union_rows.argtypes = [i64] + [vp] * 7
     lib.vfm_variant_workspace_elems.argtypes = [i64, i32, i32]
     lib.vfm_variant_workspace_elems.restype = i64
     for name in EXPORTS:
@@ -176,5 +176,12 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def raw_stream(device) -> int:
+    """The current HIP stream of `device` as an integer handle (torch.cuda.current_stream() builds a Python Stream object
+    through three layers of device-index helpers: 4.5 us; a training step asked a dozen times)."""
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
 def current_stream_ptr(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return C.c_void_p(raw_stream(device))

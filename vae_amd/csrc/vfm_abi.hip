@@ -104,7 +104,7 @@ int check_problem(const vfm_problem_t* p, bool dev_ok = false) {
   if (p->B * (int64_t)p->F > 0x7FFFFFFFLL) return fail(VFM_E_INVALID, "B*F exceeds int32 index range");
   if (p->e_lo < 0 || p->e_lo > p->T || (p->e_hi != 0 && p->e_hi < p->e_lo)) return fail(VFM_E_INVALID, "bad entity range");
   if (p->flags & ~(VFM_FLAG_NO_PRIOR_TERMS | VFM_FLAG_EPS_ZERO | VFM_FLAG_SPARSE_ADAM | VFM_FLAG_LINK_SOFTPLUS |
-                   VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_ROWS_TOUCHED | VFM_FLAG_ZREC))
+                   VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_ROWS_TOUCHED | VFM_FLAG_ZREC | VFM_FLAG_SHARE_GPU))
     return fail(VFM_E_INVALID, "unknown bit in vfm_problem_t.flags");
   Shape s;
   if (!pick_shape(p->d, &s)) return fail(VFM_E_UNSUPPORTED, "embedding size d not supported (d%4==0: d<=1024, else d<=256)");
@@ -728,7 +728,7 @@ int vfm_elbo_bwd_adam_pipe_f32(const vfm_problem_t* p, const vfm_index_t* idx, c
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_pipe_f32")) return rc;
   if (p->F != 2 || (p->d & 3) != 0 || p->d > 512)
     return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: two fields, d % 4 == 0, d <= 512");
-  if (p->flags & ~VFM_FLAG_SCALED_MOMENTS)
+  if (p->flags & ~(VFM_FLAG_SCALED_MOMENTS | VFM_FLAG_SHARE_GPU))
     return fail(VFM_E_UNSUPPORTED, "vfm_elbo_bwd_adam_pipe_f32: only VFM_FLAG_SCALED_MOMENTS (the record step exists for the |.| link)");
   if (!pipe) return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_pipe_f32: pipe is NULL");
   if (int rc = check_struct(pipe->struct_size, pipe->abi_version, sizeof(vfm_pipe_t), "vfm_pipe_t")) return rc;
@@ -781,7 +781,7 @@ int vfm_elbo_bwd_adam_lookahead_f32(const vfm_problem_t* p, const vfm_index_t* i
   if (p->dev_step) { step = 1; lr = 0.f; }      // (replayable step: the caller keeps period-ending steps out of its graphs)
   if (int rc = single_sample_only(p, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
   if (int rc = check_index(p, idx, "vfm_elbo_bwd_adam_lookahead_f32")) return rc;
-  if ((p->flags & ~VFM_FLAG_LINK_SOFTPLUS) != VFM_FLAG_SCALED_MOMENTS)
+  if ((p->flags & ~(VFM_FLAG_LINK_SOFTPLUS | VFM_FLAG_SHARE_GPU)) != VFM_FLAG_SCALED_MOMENTS)
     return fail(VFM_E_INVALID, "vfm_elbo_bwd_adam_lookahead_f32: VFM_FLAG_SCALED_MOMENTS (and optionally the link flag) only");
   if (!entity_params || !bias_params || !scalars || !m_entity || !v_entity || !m_bias || !v_bias || !m_scalars ||
       !v_scalars || step < 1 || !inv_occ || !W || !partials || (p->B > 0 && (!sumz || !grow)) || !last_step ||

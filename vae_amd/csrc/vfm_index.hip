@@ -7,20 +7,22 @@
 // Method: a STABLE least-significant-digit radix sort of the B*F (entity id, position) pairs by entity id, up to 9 bits
 // per pass, ceil(log2(T) / 9) passes (two at the ML-20M shape); stable means an entity's rows come out in row order, so
 // the backward's sums have a fixed order and the whole step stays bitwise reproducible.  The whole build is latency-bound
-// (200 K keys: 3 MB per pass), so it is organised around the NUMBER of dependent launches (six; sixteen before round 4):
-//   memset           the digit-count tables of the passes after the first
+// (200 K keys: 3 MB per pass), so it is organised around the NUMBER of dependent launches and the dependent memory round
+// trips inside each (seven launches at the ML-20M shape; sixteen before round 4):
+//   memset           the per-tile-group digit counts of every pass (16 KB)
 //   k_index_keys     ids -> uint32 keys (range-checked; out-of-range ids are counted and clamped to 0 like the forward
 //                    does), values = positions r*F + f; the first pass's per-tile digit counts; the workgroup's share of
 //                    the batch normalisers W_f = sum_r inv_occ[x_rf] (fp64, fixed order)
 //   k_radix_scatter  one per pass: stable rank inside the tile (per-wave digit matching with ballots + a scan over the
 //                    tile's 32 sub-tiles in LDS) + the tile's base, formed by the workgroup itself from TWO levels of
-//                    digit counts (per tile, per group of G tiles: <= NB/G + G - 1 rows to add, not NB); while scattering,
-//                    the keys count themselves into the NEXT pass's tables at their new positions (integer atomics, one per
-//                    group of lanes with equal digits: a popular id does not serialise on one address); the LAST pass
+//                    digit counts (per tile, per group of G tiles: <= NB/G + G - 1 rows to add, not NB); the LAST pass
 //                    writes occ_rows / occ_other directly and leaves the first position of every leading digit
-//   k_index_count    per chunk of 1024 entities: occ_ptr (lower bound of e among the sorted keys, searched inside the
-//                    range of e's leading digit: ~9 probes instead of 18) and the chunk's counts of heavy entities, work
-//                    items, entities present, longest item list
+//   k_radix_hist     between two passes: the next pass's digit counts of every tile of the scattered keys.  (Counting
+//                    them inside the scatter with one atomic per key was tried: 400 K scattered device atomics took 45 us,
+//                    each is a 64-byte request at the memory side; this kernel reads the keys coalesced: 4 us.)
+//   k_index_count    per chunk of 1024 entities: occ_ptr = lower bound of e among the sorted keys -- the chunk's key range
+//                    (between the first positions of its leading digits) is staged in LDS and searched there -- and the
+//                    chunk's counts of heavy entities, work items, entities present, longest item list
 //   k_index_write    every chunk adds up the chunks before it itself, then the heavy lists and the touched list; the last
 //                    chunk leaves the totals in `counts` and finishes W
 // Integer atomics only, and only where the total is what matters: two builds of one batch give identical buffers.
@@ -77,8 +79,8 @@ Geo geometry(int64_t n, int64_t T) {
   }
   int64_t o = 0;
   g.k0 = o; o += g.n4; g.v0 = o; o += g.n4; g.k1 = o; o += g.n4; g.v1 = o; o += g.n4;
-  g.zero_lo = o;
   for (int p = 0; p < g.passes; ++p) { g.L1[p] = o; o += g.NB * ((int64_t)1 << g.rb[p]); }
+  g.zero_lo = o;
   for (int p = 0; p < g.passes; ++p) { g.L2[p] = o; o += g.NS * ((int64_t)1 << g.rb[p]); }
   g.zero_hi = o;
   g.excl = o; o += RS_MAXD + 4;
@@ -100,6 +102,35 @@ __device__ __forceinline__ void load_id(const void* __restrict__ x, int id64, in
   }
 }
 
+// digit counts of one tile into its row of L1 (plain stores) and its group's row of L2 (integer atomics on consecutive
+// addresses).  One LDS add per group of lanes of a wave with the same digit: a run of one popular id is one add.
+__device__ __forceinline__ void tile_digit_counts(const uint32_t (&dg)[RS_ITEMS], int base, int n, int rb, unsigned int* sh_hist,
+                                                  uint32_t* __restrict__ L1, uint32_t* __restrict__ L2, int G) {
+  const int tid = threadIdx.x, ND = 1 << rb;
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const bool valid = base + k * RS_THREADS + tid < n;
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RS_MAXBITS; ++b) {
+      if (b < rb) {
+        const bool bit = (dg[k] >> b) & 1u;
+        const unsigned long long bb = __ballot(bit);
+        m &= bit ? bb : ~bb;
+      }
+    }
+    if (valid && (m & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicAdd(&sh_hist[dg[k]], (unsigned int)__popcll(m));
+  }
+  __syncthreads();
+  uint32_t* row1 = L1 + (size_t)blockIdx.x * ND;
+  uint32_t* row2 = L2 + (size_t)(blockIdx.x / G) * ND;
+  for (int i = tid; i < ND; i += RS_THREADS) {
+    const unsigned int c = sh_hist[i];
+    row1[i] = c;
+    if (c) atomicAdd(&row2[i], c);
+  }
+}
+
 // ids -> keys / positions, the first pass's digit counts of the tile, the tile's share of W and of the bad-id count
 __global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restrict__ x, int id64, int n, uint32_t T32, int F,
                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -114,44 +145,38 @@ __global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restric
   __syncthreads();
   const int base = blockIdx.x * RS_TILE;
   unsigned int bad = 0;
-  double w[NW_MAXF] = {0.0, 0.0, 0.0, 0.0};
   const bool want_w = inv_occ != nullptr;
-  uint32_t kd[RS_ITEMS];
+  uint32_t lo[RS_ITEMS], hi[RS_ITEMS], kd[RS_ITEMS];
+  float io[RS_ITEMS];
+  // all ids first, then all 1/occ gathers: two dependent round trips for the tile, not sixteen (no load under a branch:
+  // a slot past the end re-reads the last id and is masked)
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
     const int i = base + k * RS_THREADS + tid;
-    kd[k] = 0u;
-    if (i < n) {
-      uint32_t lo, hi;
-      load_id(x, id64, i, lo, hi);
-      const bool ok = hi == 0u && lo < T32;
-      bad += ok ? 0u : 1u;
-      const uint32_t key = ok ? lo : 0u;
-      keys[i] = key;
-      vals[i] = (uint32_t)i;
-      kd[k] = key & (uint32_t)(ND - 1);
-      if (want_w) {
-        const double v = ok ? (double)inv_occ[lo] : 0.0;        // (ids out of range add nothing, as in vfm_batch_norms)
-        const int f = i % F;
-#pragma unroll
-        for (int q = 0; q < NW_MAXF; ++q) w[q] += (q == f) ? v : 0.0;
-      }
-    }
+    load_id(x, id64, i < n ? i : n - 1, lo[k], hi[k]);
   }
-  // digit counts of the tile: one LDS add per group of lanes with the same digit (a run of one popular id is one add)
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
-    const bool valid = base + k * RS_THREADS + tid < n;
-    unsigned long long m = __ballot(valid);
+    const bool ok = hi[k] == 0u && lo[k] < T32;
+    io[k] = want_w ? inv_occ[ok ? lo[k] : 0u] : 0.f;
+  }
+  double w[NW_MAXF] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int b = 0; b < RS_MAXBITS; ++b) {
-      if (b < rb0) {
-        const bool bit = (kd[k] >> b) & 1u;
-        const unsigned long long bb = __ballot(bit);
-        m &= bit ? bb : ~bb;
-      }
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const int i = base + k * RS_THREADS + tid;
+    const bool valid = i < n;
+    const bool ok = hi[k] == 0u && lo[k] < T32;
+    const uint32_t key = ok ? lo[k] : 0u;
+    kd[k] = key & (uint32_t)(ND - 1);
+    if (valid) {
+      bad += ok ? 0u : 1u;
+      keys[i] = key;
+      vals[i] = (uint32_t)i;
+      const double v = ok ? (double)io[k] : 0.0;        // (ids out of range add nothing, as in vfm_batch_norms)
+      const int f = i % F;
+#pragma unroll
+      for (int q = 0; q < NW_MAXF; ++q) w[q] += (q == f) ? v : 0.0;
     }
-    if (valid && (m & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicAdd(&sh_hist[kd[k]], (unsigned int)__popcll(m));
   }
   // bad ids + W: wave sums in a fixed tree, then the waves in order
 #pragma unroll
@@ -160,12 +185,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restric
   if (want_w) {
 #pragma unroll
     for (int q = 0; q < NW_MAXF; ++q) {
+      if (q < F) {
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) w[q] += __shfl_xor(w[q], m, 64);
+        for (int m = 32; m >= 1; m >>= 1) w[q] += __shfl_xor(w[q], m, 64);
+      }
       if ((tid & 63) == 0) sh_w[q][tid >> 6] = w[q];
     }
   }
-  __syncthreads();
+  tile_digit_counts(kd, base, n, rb0, sh_hist, L1, L2, G);      // (its barrier also covers sh_bad / sh_w)
   if (tid == 0) {
     unsigned int t = 0;
     for (int v = 0; v < RS_THREADS / 64; ++v) t += sh_bad[v];
@@ -176,18 +203,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_index_keys(const void* __restric
     for (int v = 0; v < RS_THREADS / 64; ++v) t += sh_w[tid][v];
     wpart[(size_t)blockIdx.x * NW_MAXF + tid] = t;
   }
-  // the tile's digit counts: its own row of L1 (plain stores), its group's row of L2 (integer atomics)
-  uint32_t* row1 = L1 + (size_t)blockIdx.x * ND;
-  uint32_t* row2 = L2 + (size_t)(blockIdx.x / G) * ND;
-  for (int i = tid; i < ND; i += RS_THREADS) {
-    const unsigned int c = sh_hist[i];
-    row1[i] = c;
-    if (c) atomicAdd(&row2[i], c);
+}
+
+// between two passes: the digit counts of every tile of the freshly scattered keys
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int n, int shift, int rb,
+                                                           uint32_t* __restrict__ L1, uint32_t* __restrict__ L2, int G) {
+  __shared__ unsigned int sh_hist[RS_MAXD];
+  const int tid = threadIdx.x, ND = 1 << rb;
+  for (int i = tid; i < ND; i += RS_THREADS) sh_hist[i] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * RS_TILE;
+  uint32_t dg[RS_ITEMS];
+#pragma unroll
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const int i = base + k * RS_THREADS + tid;
+    dg[k] = (keys[i < n ? i : n - 1] >> shift) & (uint32_t)(ND - 1);
   }
+  tile_digit_counts(dg, base, n, rb, sh_hist, L1, L2, G);
 }
 
 // One radix pass.  L1 [NB][ND] / L2 [NS][ND]: this pass's digit counts per tile / per group of G tiles.
-// L1n / L2n (NULL on the last pass): the next pass's tables, counted here at the keys' new positions.
 // LAST: the sorted positions go out as occ_rows / occ_other (+ the sorted keys, for the lower-bound searches of
 // k_index_count) and workgroup 0 leaves excl[dg] = first position of leading digit dg (excl[ND] = n).
 template <bool LAST>
@@ -195,8 +230,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
                                                               int n, int shift, int rb, const uint32_t* __restrict__ L1,
                                                               const uint32_t* __restrict__ L2, int G, int NS,
                                                               uint32_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                              uint32_t* __restrict__ L1n, uint32_t* __restrict__ L2n,
-                                                              int shift_n, int rb_n, uint32_t* __restrict__ excl,
+                                                              uint32_t* __restrict__ excl,
                                                               int32_t* __restrict__ occ_rows, int32_t* __restrict__ occ_other,
                                                               const void* __restrict__ x, int id64, int F, int64_t T) {
   __shared__ uint16_t sub[RS_SUB][RS_MAXD];          // [sub-tile][digit]: count, then start inside the tile
@@ -215,7 +249,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
   const int tbase = me * RS_TILE;
   uint32_t key[RS_ITEMS], val[RS_ITEMS];
   int lower[RS_ITEMS];
-  unsigned long long same[RS_ITEMS];                 // lanes of this wave holding the same digit in round k
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
@@ -274,7 +307,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
       }
     }
     m = valid ? m : 0ull;
-    same[k] = m;
     lower[k] = __popcll(m & lt);
     if (valid && lower[k] == 0) sub[k * (RS_THREADS / 64) + wave][dg] = (uint16_t)__popcll(m);
   }
@@ -310,55 +342,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint32_t* __
     for (int s = 0; s < RS_SUB; ++s) { const uint32_t c = sub[s][dg]; sub[s][dg] = (uint16_t)run; run += c; }
   }
   __syncthreads();
-  const uint32_t dmask_n = rb_n > 0 ? (uint32_t)((1 << rb_n) - 1) : 0u;
-  const int ND_n = 1 << (rb_n > 0 ? rb_n : 0);
 #pragma unroll
   for (int k = 0; k < RS_ITEMS; ++k) {
     const int i = tbase + k * RS_THREADS + tid;
-    const bool valid = i < n;
-    const uint32_t dg = (key[k] >> shift) & dmask;
-    const uint32_t pos = valid ? sh_bef[dg] + (uint32_t)sub[k * (RS_THREADS / 64) + wave][dg] + (uint32_t)lower[k] : 0u;
-    if constexpr (LAST) {
-      if (valid) {
-        kout[pos] = key[k];
+    if (i < n) {
+      const uint32_t dg = (key[k] >> shift) & dmask;
+      const uint32_t pos = sh_bef[dg] + (uint32_t)sub[k * (RS_THREADS / 64) + wave][dg] + (uint32_t)lower[k];
+      kout[pos] = key[k];
+      if constexpr (LAST) {
         occ_rows[pos] = (int32_t)(val[k] / (uint32_t)F);
         if (occ_other) {       // two fields: the entity in the OTHER column of the occurrence's row (clamped like the keys)
           uint32_t lo, hi;
           load_id(x, id64, (int64_t)(val[k] ^ 1u), lo, hi);
           occ_other[pos] = (hi == 0u && (int64_t)lo < T) ? (int32_t)lo : 0;
         }
-      }
-    } else {
-      if (valid) { kout[pos] = key[k]; vout[pos] = val[k]; }
-      // the next pass's digit counts at the new position: ONE add per group of lanes that share this digit, the next
-      // digit and the destination tile of the group's first lane (they sit within 64 positions of each other; a lane
-      // that fell into the following tile adds for itself) -- a popular id is one add per wave, not one per key
-      const uint32_t dn = (key[k] >> shift_n) & dmask_n;
-      unsigned long long m = same[k];
-#pragma unroll
-      for (int b = 0; b < RS_MAXBITS; ++b) {
-        if (b < rb_n) {
-          const bool bit = (dn >> b) & 1u;
-          const unsigned long long bb = __ballot(bit);
-          m &= bit ? bb : ~bb;
-        }
-      }
-      const uint32_t tn = pos / (uint32_t)RS_TILE;
-      const int lead = m ? __builtin_ctzll(m) : lane;
-      const uint32_t tn_lead = (uint32_t)__shfl((int)tn, lead, 64);
-      const bool with_lead = valid && tn == tn_lead;
-      const unsigned long long grp = m & __ballot(with_lead);
-      if (valid) {
-        if (with_lead) {
-          if (lane == lead) {
-            const uint32_t c = (uint32_t)__popcll(grp);
-            atomicAdd(&L1n[(size_t)tn * ND_n + dn], c);
-            atomicAdd(&L2n[(size_t)(tn / (uint32_t)G) * ND_n + dn], c);
-          }
-        } else {
-          atomicAdd(&L1n[(size_t)tn * ND_n + dn], 1u);
-          atomicAdd(&L2n[(size_t)(tn / (uint32_t)G) * ND_n + dn], 1u);
-        }
+      } else {
+        vout[pos] = val[k];
       }
     }
   }
@@ -372,32 +371,54 @@ __device__ __forceinline__ void ent_counts(uint32_t c, int L, int THR, uint32_t&
   it = hv ? (c + (uint32_t)L - 1) / (uint32_t)L : 0u;
 }
 
-// first position in keys[lo, hi) whose key is >= e
-__device__ __forceinline__ int lower_bound(const uint32_t* __restrict__ keys, int lo, int hi, uint32_t e) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (keys[mid] < e) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-// SEARCH: occ_ptr[e] = lower bound of e among the sorted keys, looked for between the first positions of e's leading
-// digit and of the next one (excl, from the last scatter), and written here; else occ_ptr is given (vfm_rebuild_heavy)
+// SEARCH: occ_ptr[e] = lower bound of e among the sorted keys, written here.  The chunk's entities [e0, e0 + 1024] can
+// only be found between the first position of e0's leading digit and the first position past (e0 + 1024)'s (excl, from
+// the last scatter): that range of keys -- about 1024 n / T of them -- is staged in LDS with one coalesced round of loads
+// and every thread searches there (a global binary search is ~10 dependent memory round trips); a longer range (skewed
+// ids) is searched in global memory.  Else occ_ptr is given (vfm_rebuild_heavy).
+constexpr int IC_STAGE = 6144;                       // keys staged per chunk, at most (24 KB)
 template <bool SEARCH>
 __global__ __launch_bounds__(HV_CHUNK) void k_index_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ excl,
                                                           int n, int shift_top, int ND_top, int32_t* __restrict__ occ_ptr,
                                                           int64_t T, int L, int THR, uint32_t* __restrict__ blk, int NBH) {
   __shared__ uint32_t sh[5][HV_CHUNK / 64];
-  __shared__ int sh_lo[HV_CHUNK + 1];
+  __shared__ int sh_lo[SEARCH ? HV_CHUNK + 1 : 1];
+  __shared__ uint32_t sh_keys[SEARCH ? IC_STAGE : 1];
   const int tid = threadIdx.x;
-  const int64_t e = blockIdx.x * (int64_t)HV_CHUNK + tid;
+  const int64_t e0 = blockIdx.x * (int64_t)HV_CHUNK;
+  const int64_t e = e0 + tid;
   uint32_t c = 0;
   if constexpr (SEARCH) {
+    // key range of the chunk: [first position of digit(e0), first position of digit(e0 + 1024) + 1)
+    auto first_of = [&](int64_t ee, bool past) -> int {
+      if (n == 0) return 0;
+      const int64_t b = (int64_t)((uint64_t)ee >> shift_top) + (past ? 1 : 0);
+      return b >= ND_top ? n : (int)excl[b];
+    };
+    const int64_t e_hi = e0 + HV_CHUNK < T ? e0 + HV_CHUNK : T;
+    const int r_lo = first_of(e0, false), r_hi = first_of(e_hi, true);
+    const bool staged = r_hi - r_lo <= IC_STAGE;          // (uniform)
+    if (staged)
+      for (int i = tid; i < r_hi - r_lo; i += HV_CHUNK) sh_keys[i] = keys[r_lo + i];
+    __syncthreads();
     auto find = [&](int64_t ee) -> int {
       if (ee >= T || n == 0) return ee > 0 ? n : 0;
+      if (staged) {
+        int lo = 0, hi = r_hi - r_lo;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (sh_keys[mid] < (uint32_t)ee) lo = mid + 1; else hi = mid;
+        }
+        return r_lo + lo;
+      }
       const int b = (int)((uint64_t)ee >> shift_top);
       if (b >= ND_top) return n;
-      return lower_bound(keys, (int)excl[b], (int)excl[b + 1], (uint32_t)ee);
+      int lo = (int)excl[b], hi = (int)excl[b + 1];
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)ee) lo = mid + 1; else hi = mid;
+      }
+      return lo;
     };
     sh_lo[tid] = find(e);
     if (tid == 0) sh_lo[HV_CHUNK] = find(e + HV_CHUNK);
@@ -553,12 +574,14 @@ __global__ __launch_bounds__(HV_CHUNK) void k_index_write(const int32_t* __restr
       for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
       if (tid == 0) counts[0] = (int32_t)b;
     }
-    if (W && tid >= 64 && tid < 64 + F) {       // W_f: the tiles' shares, added in tile order (fixed: reproducible)
-      const int f = tid - 64;
+    if (W && tid >= 64 && tid < 64 * (1 + NW_MAXF)) {       // W_f: wave 1 + f adds the tiles' shares of field f -- every lane its
+      const int f = (tid >> 6) - 1, lane = tid & 63;       // tiles in order, then the lanes in a fixed tree: reproducible
       double t = 0.0;
-      if (wpart)
-        for (int j = 0; j < NB; ++j) t += wpart[(size_t)j * NW_MAXF + f];
-      W[f] = t;
+      if (wpart && f < F)
+        for (int j = lane; j < NB; j += 64) t += wpart[(size_t)j * NW_MAXF + f];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+      if (lane == 0 && f < F) W[f] = t;
     }
   }
 }
@@ -679,7 +702,7 @@ int64_t vfm_index_workspace_bytes(int64_t B, int32_t F, int64_t T) {
 int64_t vfm_union_workspace_bytes(int64_t T) { return T < 1 ? -1 : 4 * ((T + HV_CHUNK - 1) / HV_CHUNK + 4); }
 
 int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b, void* ws, int32_t* rows, int32_t* count,
-                   void* stream) {
+                   int32_t* count_host, void* stream) {
   if (T < 1 || T > 0x7FFFFFFELL || !occ_ptr_a || !occ_ptr_b || !ws || !rows || !count)
     return fail(VFM_E_INVALID, "vfm_union_rows: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -692,14 +715,16 @@ int vfm_union_rows(int64_t T, const int32_t* occ_ptr_a, const int32_t* occ_ptr_b
   } else {
     hipLaunchKernelGGL(k_union_write<false>, dim3(NBH), dim3(HV_CHUNK), 0, st, occ_ptr_a, occ_ptr_b, T, blk, NBH, rows, count);
   }
-  const hipError_t e = hipGetLastError();
+  hipError_t e = hipSuccess;
+  if (count_host) e = hipMemcpyAsync(count_host, count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipGetLastError();
   return e == hipSuccess ? 0 : fail_hip(e, "vfm_union_rows");
 }
 
 int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void* x, void* ws, int32_t* occ_ptr,
                     int32_t* occ_rows, int32_t heavy_list, int32_t* heavy_ids, int64_t cap_heavy,
                     int32_t* heavy_items, int64_t cap_items, int32_t* touched_ids, int32_t* occ_other,
-                    const float* inv_occ, double* W, int32_t* counts, void* stream) {
+                    const float* inv_occ, double* W, int32_t* counts, int32_t* counts_host, void* stream) {
   if (B < 0 || F < 1 || F > VFM_MAX_FIELDS || T < 1 || T > 0xFFFFFFFELL || B * (int64_t)F > 0x7FFFFFFFLL ||
       (id_bits != 32 && id_bits != 64) || heavy_list < VFM_HEAVY_MIN)
     return fail(VFM_E_INVALID, "vfm_build_index: bad B, F, T, id_bits or heavy_list");
@@ -726,15 +751,17 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
                        fused_w ? inv_occ : (const float*)nullptr, wpart, w32 + g.bad);
     uint32_t *kin = w32 + g.k0, *vin = w32 + g.v0, *kout = w32 + g.k1, *vout = w32 + g.v1;
     for (int p = 0; p < g.passes; ++p) {
+      if (p > 0)        // (pass 0's digit counts came with the keys)
+        hipLaunchKernelGGL(k_radix_hist, dim3(NB), dim3(RS_THREADS), 0, st, kin, n, g.shift[p], g.rb[p], w32 + g.L1[p],
+                           w32 + g.L2[p], (int)g.G);
       if (p + 1 == g.passes) {
         hipLaunchKernelGGL(k_radix_scatter<true>, dim3(NB), dim3(RS_THREADS), 0, st, kin, vin, n, g.shift[p], g.rb[p],
-                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr, 0, 0, w32 + g.excl, occ_rows, occ_other, x, (int)(id_bits == 64), (int)F, T);
+                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, w32 + g.excl, occ_rows, occ_other, x,
+                           (int)(id_bits == 64), (int)F, T);
       } else {
         hipLaunchKernelGGL(k_radix_scatter<false>, dim3(NB), dim3(RS_THREADS), 0, st, kin, vin, n, g.shift[p], g.rb[p],
-                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, w32 + g.L1[p + 1],
-                           w32 + g.L2[p + 1], g.shift[p + 1], g.rb[p + 1], (uint32_t*)nullptr, occ_rows, occ_other, x,
-                           (int)(id_bits == 64), (int)F, T);
+                           w32 + g.L1[p], w32 + g.L2[p], (int)g.G, (int)g.NS, kout, vout, (uint32_t*)nullptr, occ_rows, occ_other,
+                           x, (int)(id_bits == 64), (int)F, T);
       }
       uint32_t* t = kin; kin = kout; kout = t;
       t = vin; vin = vout; vout = t;
@@ -752,6 +779,10 @@ int vfm_build_index(int64_t B, int32_t F, int64_t T, int32_t id_bits, const void
   compaction_write(g.NBH, occ_ptr, T, (int)heavy_list, (int)heavy_list, w32 + g.blk, heavy_ids, heavy_items, cap_heavy, cap_items,
                    touched_ids, counts, n > 0 ? w32 + g.bad : (const uint32_t*)nullptr, NB, fused_w && n > 0 ? wpart : nullptr,
                    fused_w ? W : nullptr, (int)F, st);
+  if (counts_host) {                                  // the build's one readback, enqueued here (pinned host memory)
+    e = hipMemcpyAsync(counts_host, counts, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return fail_hip(e, "vfm_build_index: readback");
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "vfm_build_index");
   return 0;

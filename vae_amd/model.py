@@ -347,7 +347,7 @@ class VFM(nn.Module):
         self.inv_occ = ops.inv_occ_from_counts(self.nb_occ)
         self._wrec_ok = False
 
-    def plan(self, x, y=None, B_global=None, build_index=True, process_group=None, defer_readback=False) -> ops.BatchPlan:
+    def plan(self, x, y=None, B_global=None, build_index=True, process_group=None, defer_readback=False, stream=None) -> ops.BatchPlan:
         x = torch.as_tensor(x).to(self.device)
         if x.dtype not in (torch.int32, torch.int64):
             x = x.to(torch.int64)
@@ -360,7 +360,7 @@ class VFM(nn.Module):
             self._resolve_exchange(process_group)
         return ops.BatchPlan(self.spec(), x, y, self.inv_occ, B_global=B_global,
                              build_index=build_index and y is not None, process_group=process_group,
-                             defer_readback=defer_readback)
+                             defer_readback=defer_readback, stream=stream)
 
     def _resolve_exchange(self, process_group):
         """exchange == "auto" -> the pattern for this model / world size (see __init__)."""
@@ -523,15 +523,17 @@ class VFM(nn.Module):
             self._state_bufs[B] = b
         return b
 
-    def plan_async(self, x, y, pair_with: Optional[ops.BatchPlan] = None) -> ops.BatchPlan:
+    def plan_async(self, x, y, pair_with: Optional[ops.BatchPlan] = None, fork: bool = True) -> ops.BatchPlan:
         """The plan of a batch, built on the model's side stream while whatever is already enqueued on the current stream
         runs (`ops.PlanStream`): returns at once; the first `train_step` that uses the plan makes its stream wait for the
         build.  pair_with: the plan of the batch BEFORE this one -- the look-ahead step's row list of the pair is made on
-        the side stream too.  Single rank (a multi-rank plan sums W over the ranks: a collective, built in line)."""
+        the side stream too.  fork=False: x and y are long-lived (nothing on the current stream is still writing them), so the
+        build need not wait for the steps already enqueued there.  Single rank (a multi-rank plan sums W over the ranks: a
+        collective, built in line)."""
         if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != self.device:
             self._plan_stream = ops.PlanStream(self.device)
         pair = pair_with if (pair_with is not None and self.lookahead and self.lookahead_list and self.n_samples == 1) else None
-        return self._plan_stream.build(lambda: self.plan(x, y, defer_readback=True), pair_with=pair)
+        return self._plan_stream.build(lambda st: self.plan(x, y, defer_readback=True, stream=st), pair_with=pair, fork=fork)
 
     def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
                    process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None,
@@ -539,11 +541,22 @@ class VFM(nn.Module):
         """One iteration of vfm-torch.py:351-370 without autograd: forward, loss, backward, dense
         Adam (betas (0.9, 0.999), eps 1e-8).  Everything is enqueued on the current stream; nothing
         synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B]).
-        prefetch = (x, y) of the batch AFTER `next_plan` (after `plan` when no next batch is named): its plan is built on
-        the side stream while this step runs (`plan_async`) and waits in `self.prefetched` for the caller to take."""
+        prefetch = (x, y[, fork[, pair_with]]) of a LATER batch: its plan is built on the side stream while this step runs
+        (`plan_async`; enqueued after this step's own launches) and waits in `self.prefetched` for the caller to take.
+        pair_with: the plan of the batch right before it (default: `next_plan`, else `plan`) -- the look-ahead row list of
+        that pair is made with it.  Prefetch TWO batches beyond `next_plan` (as `fit(stream_plans=True)` does): a step reads
+        the size of its next batch's index on the host, so a plan enqueued during the previous step would be waited for."""
         self._ensure_opt_state()
+        self._sharing = prefetch is not None        # (plan builds run beside this step: its row kernels leave them slots)
         if prefetch is not None:
-            self.prefetched = self.plan_async(prefetch[0], prefetch[1], pair_with=next_plan if next_plan is not None else plan)
+            try:
+                return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)
+            finally:
+                pw = prefetch[3] if len(prefetch) > 3 else (next_plan if next_plan is not None else plan)
+                self.prefetched = self.plan_async(prefetch[0], prefetch[1], pair_with=pw, fork=prefetch[2] if len(prefetch) > 2 else True)
+        return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)
+
+    def _train_step(self, plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan):
         plan.use_on_current()
         if next_plan is not None:
             next_plan.use_on_current()
@@ -617,7 +630,7 @@ class VFM(nn.Module):
         ent, bia, scal = self._views(self._flat)
         loss3 = self._gflat[self._n_flat: self._n_flat + 3]
         sumz, grow, pred = self._step_buffers(plan.B)
-        flags = 0
+        flags = ops.FLAG_SHARE_GPU if getattr(self, "_sharing", False) else 0
         lazy = rows = None
         la = False
         scaled = self.scaled_moments and not self.sparse_adam
@@ -765,7 +778,8 @@ class VFM(nn.Module):
         if next_plan is not None and (next_plan.spec.T != self.T or next_plan.y is None):
             next_plan = None
 
-        st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials)
+        st = ops.elbo_forward_records(plan, cur, scal, self.rng_seed, step, pred, grow, self._partials,
+                                      flags=ops.FLAG_SHARE_GPU if getattr(self, "_sharing", False) else 0)
         mark("fwd")
         ops.elbo_backward_adam_pipe(plan, st, cur, nxt, next_plan, step + 1, ent, bia, scal, self.inv_occ,
                                     self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
@@ -880,17 +894,20 @@ class VFM(nn.Module):
         hist = {"epoch": [], "elbo": [], "train_rmse": [], "train_auc": [], "test": []}
         losses = torch.zeros(nb, dtype=torch.float32, device=self.device)
         total = n_epochs * nb
-        batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]])
-        cur = self.plan(*batch(0), defer_readback=True)
-        nxt = self.plan_async(*batch(1), pair_with=cur) if total > 1 else None
+        # (fork=False: Xd / yd are resident since before the loop -- the builds need not wait for the steps in flight)
+        batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]], False)
+        # three plans in hand: this batch's, the next one's (named to the step), and the one after (being built)
+        cur = self.plan(*batch(0)[:2], defer_readback=True)
+        nxt = self.plan_async(*batch(1)[:2], pair_with=cur) if total > 1 else None
+        nx2 = self.plan_async(*batch(2)[:2], pair_with=nxt) if total > 2 else None
         for t in range(total):
             epoch, i = divmod(t, nb)
             a, b = spans[i]
             loss3, pr = self.train_step(cur, next_plan=nxt if self.n_samples == 1 else None,
-                                        prefetch=batch(t + 2) if t + 2 < total else None)
+                                        prefetch=batch(t + 3) + (nx2,) if t + 3 < total else None)
             train_pred[a:b] = pr if self.n_samples == 1 else pr.mean(0)
             losses[i] = loss3[0]
-            cur, nxt = nxt, (self.prefetched if t + 2 < total else None)
+            cur, nxt, nx2 = nxt, nx2, (self.prefetched if t + 3 < total else None)
             if i == nb - 1:
                 if self.output == "reg":
                     self.save_weights()

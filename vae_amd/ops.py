@@ -30,6 +30,7 @@ FLAG_SPARSE_ADAM = 4
 FLAG_LINK_SOFTPLUS = 16
 FLAG_SCALED_MOMENTS = 32
 FLAG_ROWS_TOUCHED = 128
+FLAG_SHARE_GPU = 2048
 MOMENT_PERIOD = 128
 MAX_SAMPLES = 64
 _I63 = (1 << 63) - 1
@@ -104,13 +105,45 @@ _WS = {}
 _ENQUEUE_LOCK = __import__("threading").RLock()
 
 
-def _index_workspace(n_int32: int, dev) -> torch.Tensor:
-    """One scratch buffer per (device, stream) for vfm_build_index (stream-ordered reuse; grown on demand)."""
-    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+def _index_workspace(n_int32: int, dev, stream: int) -> torch.Tensor:
+    """One scratch buffer per (device, stream) for vfm_build_index (stream-ordered reuse; grown on demand).  `stream`: the
+    raw handle of the stream the build is enqueued on."""
+    key = (dev.index, stream)
     t = _WS.get(key)
     if t is None or t.numel() < n_int32:
         t = _WS[key] = torch.empty(n_int32, dtype=torch.int32, device=dev)
     return t
+
+
+_STREAMS = {}
+
+
+def _stream_obj(dev, raw: int):
+    """The torch Stream object of a raw stream handle (cached: torch.cuda.current_stream() costs 4.5 us a call)."""
+    s = _STREAMS.get((dev.index, raw))
+    if s is None:
+        s = torch.cuda.current_stream(dev)
+        if s.cuda_stream != raw:                     # (a stream that is not current: wrap the handle)
+            s = torch.cuda.ExternalStream(raw, device=dev)
+        if len(_STREAMS) > 64:
+            _STREAMS.clear()
+        _STREAMS[(dev.index, raw)] = s
+    return s
+
+
+_SIZES = {}
+
+
+def _index_sizes(B: int, F: int, T: int):
+    """(heavy-list length, workspace bytes) of a build: two library calls, cached per shape."""
+    hit = _SIZES.get((B, F, T))
+    if hit is None:
+        lib = _lib.load()
+        hit = (_lib.heavy_list_for(B * F, T), int(lib.vfm_index_workspace_bytes(B, F, T)))
+        if len(_SIZES) > 256:
+            _SIZES.clear()
+        _SIZES[(B, F, T)] = hit
+    return hit
 
 
 _PINNED = {"chunk": None, "used": 0}
@@ -141,9 +174,11 @@ class BatchPlan:
 
     def __init__(self, spec: Spec, x: torch.Tensor, y: Optional[torch.Tensor],
                  inv_occ: Optional[torch.Tensor], B_global: Optional[int] = None,
-                 build_index: bool = True, validate: bool = True, process_group=None, defer_readback: bool = False):
-        """defer_readback: enqueue the index build and return; its 16-byte readback (and the IndexError an id out
-        of range raises) happens when the plan is first used -- a loop that builds many plans then never waits."""
+                 build_index: bool = True, validate: bool = True, process_group=None, defer_readback: bool = False,
+                 stream=None):
+        """defer_readback: enqueue the index build and return; its 32-byte readback (and the IndexError an id out
+        of range raises) happens when the plan is first used -- a loop that builds many plans then never waits.
+        stream: a torch Stream to enqueue the build on instead of the current one (PlanStream)."""
         _need_cuda(x, "x")
         if x.dim() != 2 or x.shape[1] != spec.F:
             raise ValueError(f"x must be [B,{spec.F}], got {tuple(x.shape)}")
@@ -161,7 +196,8 @@ class BatchPlan:
             if self.y.shape != (self.B,):
                 raise ValueError("y must be [B]")
         self.W = None
-        self.occ_ptr = self.occ_rows = None
+        self.occ_ptr = None
+        self._occ_rows = self._status = self._occ_other = self._lay = None
         self._ready = None               # (event, stream) of a build enqueued on another stream (PlanStream): see use_on_current
         self._arena = None
         self._heavy = self._pend = None
@@ -175,7 +211,7 @@ class BatchPlan:
             self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
         if build_index and y is not None:
             # the batch normalisers W (vfm-torch.py:305-306) come out of the index build's own launches (the ids are read once)
-            self.build_index(validate=validate, defer=defer_readback, inv_occ=inv_occ if want_w else None)
+            self.build_index(validate=validate, defer=defer_readback, inv_occ=inv_occ if want_w else None, stream=stream)
         elif want_w:
             p = _problem(spec, self.B, self.B_global, self.id_bits)
             check(lib.vfm_batch_norms(C.byref(p), ptr(x), ptr(inv_occ), ptr(self.W),
@@ -191,59 +227,89 @@ class BatchPlan:
                 raise IndexError(f"entity id out of range [0,{spec.T}): min {int(x.min())}, max {int(x.max())}")
             self._checked = True
 
-    def build_index(self, validate: bool = False, defer: bool = False, inv_occ=None):
+    def build_index(self, validate: bool = False, defer: bool = False, inv_occ=None, stream=None):
         """Inverted index entity -> batch rows: `vfm_build_index` (a stable radix sort in HIP, csrc/vfm_index.hip;
         what the reference gets from torch.unique, vfm-torch.py:190-192).  Launch-only except for ONE small
         readback at the end: (ids out of range, number of heavy lists, number of their work items, entities in the
-        batch, most work items of one entity).  inv_occ: also fill self.W in the same launches."""
-        spec, dev = self.spec, self.x.device
-        lib = _lib.load()
+        batch, most work items of one entity).  inv_occ: also fill self.W in the same launches.  stream: a torch Stream
+        other than the current one to enqueue on (the buffers are then marked as in use there)."""
+        spec = self.spec
         n = self.B * spec.F
-        L = self.heavy_list = _lib.heavy_list_for(n, spec.T)
-        nbytes = int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T))
+        L, nbytes = _index_sizes(self.B, spec.F, spec.T)
+        self.heavy_list = L
         if nbytes < 0:
             raise ValueError("batch too large for a 32-bit index (B * F must stay below 2^31)")
         with _ENQUEUE_LOCK:
-            self._build_index_locked(lib, n, L, nbytes, validate, inv_occ)
+            self._build_index_locked(_lib.load(), n, L, nbytes, validate, inv_occ, stream)
         if not defer:
             self._finish()
 
-    def _build_index_locked(self, lib, n, L, nbytes, validate, inv_occ=None):
+    def _build_index_locked(self, lib, n, L, nbytes, validate, inv_occ=None, stream=None):
         spec, dev = self.spec, self.x.device
-        ws = _index_workspace(nbytes // 4 + 4, dev)       # scratch of the build only: shared by all plans of a device
+        raw = stream.cuda_stream if stream is not None else _lib.raw_stream(dev)
+        ws = _index_workspace(nbytes // 4 + 4, dev, raw)  # scratch of the build only: shared by all plans of a (device, stream)
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
         # ONE device allocation per plan, carved into the index's arrays (seven allocations per plan made the first
-        # build of a training set's plans twice as long as the kernels themselves)
-        sizes = [spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 8, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0]
-        arena = self._arena = torch.empty(sum((v + 3) & ~3 for v in sizes), dtype=torch.int32, device=dev)
-        occ_ptr, occ_rows, hid, items, counts, touched, other = _carve(arena, sizes)
-        items = items.view(cap_i, 4)
-        # two fields: also the entity in the other column of every occurrence (the pipelined step gathers its sample)
-        self.occ_other = other if spec.F == 2 else None
-        check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), ptr(occ_ptr),
-                                  ptr(occ_rows), L, ptr(hid), cap_h, ptr(items), cap_i, ptr(touched),
-                                  ptr(self.occ_other), ptr(inv_occ), ptr(self.W) if inv_occ is not None else None,
-                                  ptr(counts), current_stream_ptr(dev)), "vfm_build_index")
-        self.occ_ptr, self.occ_rows = occ_ptr, occ_rows[:n]
-        # counts[5]: the word the kernels that walk this index report clamped entries in (vfm_index_t.status); zeroed by the build
-        self.status = counts[5:6]
-        # the plan build's one readback: 32 bytes into pinned host memory, asynchronously
+        # build of a training set's plans twice as long as the kernels themselves); the views are made when first asked for
+        sizes = (spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 8, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0)
+        offs, o = [], 0
+        for v in sizes:
+            offs.append(o)
+            o += (v + 3) & ~3
+        arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev)
+        self._lay = (offs, sizes, cap_i)
+        if stream is not None:           # (allocated from the current stream's pool, used on `stream`)
+            arena.record_stream(stream)
+            if self.W is not None:
+                self.W.record_stream(stream)
+        base = arena.data_ptr()
+        P = [C.c_void_p(base + 4 * q) for q in offs]
         host = _pinned_ints(8)
-        host.copy_(counts, non_blocking=True)
+        check(lib.vfm_build_index(self.B, spec.F, spec.T, self.id_bits, ptr(self.x), ptr(ws), P[0], P[1], L, P[2], cap_h, P[3],
+                                  cap_i, P[5], P[6] if spec.F == 2 else None, ptr(inv_occ),
+                                  ptr(self.W) if inv_occ is not None else None, P[4], C.c_void_p(host.data_ptr()),
+                                  C.c_void_p(raw)), "vfm_build_index")
+        self.occ_ptr = arena[: spec.T + 1]
+        # the plan build's one readback (32 bytes into pinned host memory, enqueued by the library) is complete when `done` is
         done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(dev))
-        self._pend = (host, done, hid, items, touched, validate, counts)
+        done.record(stream if stream is not None else _stream_obj(dev, raw))
+        self._pend = (host, done, validate)
+
+    def _view(self, k):
+        offs, sizes, _ = self._lay
+        return self._arena[offs[k]: offs[k] + sizes[k]]
+
+    @property
+    def occ_rows(self):
+        if self._occ_rows is None and self._arena is not None:
+            self._occ_rows = self._view(1)[: self.B * self.spec.F]
+        return self._occ_rows
+
+    @property
+    def status(self):
+        """counts[5]: the word the kernels that walk this index report clamped entries in (vfm_index_t.status); zeroed by the build."""
+        if self._status is None and self._arena is not None:
+            self._status = self._view(4)[5:6]
+        return self._status
+
+    @property
+    def occ_other(self):
+        """Two fields: the entity in the other column of every occurrence (the pipelined step gathers its sample)."""
+        if self._occ_other is None and self._arena is not None and self.spec.F == 2:
+            self._occ_other = self._view(6)
+        return self._occ_other
 
     def _finish(self):
         """Complete a deferred index build: read (bad ids, heavy lists, work items, entities) and size the lists."""
         if self._pend is None:
             return
         self.use_on_current()            # (a build enqueued on a side stream: whatever is launched from here on comes after it)
-        host, done, hid, items, touched, validate, _keep = self._pend
+        host, done, validate = self._pend
         self._pend = None
         done.synchronize()
         n_bad, n_heavy, n_items, n_touched, max_items = (int(v) for v in host.tolist()[:5])
         spec, dev = self.spec, self.x.device
+        hid, items, touched = self._view(2), self._view(3).view(self._lay[2], 4), self._view(5)
         self._U = n_touched                              # entities in the batch
         self._touched = touched[:n_touched]
         # many rows per entity on a large table (rows in the data files' order: a few hundred users' consecutive ratings):
@@ -262,7 +328,7 @@ class BatchPlan:
             hid, items, counts2 = arena[:cap_h], arena[(cap_h + 3) & ~3:((cap_h + 3) & ~3) + 4 * cap_i].view(cap_i, 4), arena[-8:]
             lib = _lib.load()
             with _ENQUEUE_LOCK:
-                ws = _index_workspace(int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T)) // 4 + 4, dev)
+                ws = _index_workspace(int(lib.vfm_index_workspace_bytes(self.B, spec.F, spec.T)) // 4 + 4, dev, _lib.raw_stream(dev))
                 check(lib.vfm_rebuild_heavy(spec.T, ptr(self.occ_ptr), ptr(ws), L, thr, ptr(hid), cap_h, ptr(items), cap_i,
                                             ptr(counts2), current_stream_ptr(dev)), "vfm_rebuild_heavy")
                 _, n_heavy, n_items, _, max_items = (int(v) for v in counts2.tolist()[:5])      # (a second small readback, these plans only)
@@ -313,18 +379,16 @@ class BatchPlan:
         if hit is not None and hit[0]() is next_plan:
             if hit[2] is not None:               # deferred count: first use
                 host, done, src = hit[2]
-                done.synchronize()
-                cur = torch.cuda.current_stream(self.x.device)
-                if cur != src:                   # (made on a side stream: PlanStream)
-                    cur.wait_event(done)
-                    hit[1].record_stream(cur)
-                pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())].clone(), None)      # (frees the upper-bound buffer)
+                done.synchronize()               # (host-side: the list is complete -- whatever is enqueued from here on, on
+                                                 #  any stream, comes after it)
+                pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())], None)
             return pairs[id(next_plan)][1]
         self.prepare_lookahead(next_plan)
         return self.lookahead_rows(next_plan)
 
-    def prepare_lookahead(self, next_plan: "BatchPlan") -> None:
-        """Enqueue the build of `lookahead_rows(next_plan)` without waiting for its count."""
+    def prepare_lookahead(self, next_plan: "BatchPlan", stream=None) -> None:
+        """Enqueue the build of `lookahead_rows(next_plan)` without waiting for its count (stream: a torch Stream other than
+        the current one to enqueue on)."""
         import weakref
         pairs = self.__dict__.setdefault("_pairs", {})
         hit = pairs.get(id(next_plan))
@@ -333,19 +397,22 @@ class BatchPlan:
         dev, T = self.x.device, self.spec.T
         for q in (self, next_plan):
             if q.occ_ptr is None:
-                q.build_index(defer=True)
+                q.build_index(defer=True, stream=stream)
         lib = _lib.load()
-        rows = torch.empty(min(T, (self.B + next_plan.B) * self.spec.F) or 1, dtype=torch.int32, device=dev)
-        count = torch.empty(1, dtype=torch.int32, device=dev)
+        raw = stream.cuda_stream if stream is not None else _lib.raw_stream(dev)
+        buf = torch.empty((min(T, (self.B + next_plan.B) * self.spec.F) or 1) + 4, dtype=torch.int32, device=dev)
+        if stream is not None:
+            buf.record_stream(stream)
+        rows, count = buf[:-4], buf[-4:]
         with _ENQUEUE_LOCK:
-            ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev)
-            check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
-                                     current_stream_ptr(dev)), "vfm_union_rows")
+            ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev, raw)
             host = _pinned_ints(1)
-            host.copy_(count, non_blocking=True)
+            check(lib.vfm_union_rows(T, ptr(self.occ_ptr), ptr(next_plan.occ_ptr), ptr(ws), ptr(rows), ptr(count),
+                                     C.c_void_p(host.data_ptr()), C.c_void_p(raw)), "vfm_union_rows")
             done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(dev))
-        pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done, torch.cuda.current_stream(dev)))
+            src = stream if stream is not None else _stream_obj(dev, raw)
+            done.record(src)
+        pairs[id(next_plan)] = (weakref.ref(next_plan), rows, (host, done, src))
         if len(pairs) > 4:
             pairs.pop(next(iter(pairs)))
 
@@ -355,12 +422,10 @@ class BatchPlan:
         if self._ready is None:
             return
         ev, src = self._ready
-        cur = torch.cuda.current_stream(self.x.device)
-        if cur != src:
-            cur.wait_event(ev)
-            for t in (self._arena, self.W, self.y):
-                if t is not None:
-                    t.record_stream(cur)
+        dev = self.x.device
+        raw = _lib.raw_stream(dev)
+        if raw != src.cuda_stream:
+            _stream_obj(dev, raw).wait_event(ev)
         self._ready = None
 
     def check_status(self):
@@ -410,21 +475,25 @@ class PlanStream:
 
     def __init__(self, device):
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = torch.cuda.Stream(self.device, priority=int(__import__("os").environ.get("VFM_PLAN_PRIORITY", "-1")))
 
-    def build(self, make, pair_with: Optional[BatchPlan] = None) -> BatchPlan:
-        """`make()` -> BatchPlan, called with the side stream current (build it with defer_readback=True); `pair_with`: also
-        enqueue the look-ahead row list of (pair_with, new plan) there."""
-        main = torch.cuda.current_stream(self.device)
-        fork = torch.cuda.Event()
-        fork.record(main)
-        self.stream.wait_event(fork)
-        with torch.cuda.stream(self.stream):
-            plan = make()
-            if pair_with is not None:
-                pair_with.prepare_lookahead(plan)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
+    def build(self, make, pair_with: Optional[BatchPlan] = None, fork: bool = True) -> BatchPlan:
+        """`make(stream)` -> BatchPlan whose build is enqueued on `stream` (BatchPlan(..., defer_readback=True, stream=stream));
+        `pair_with`: also enqueue the look-ahead row list of (pair_with, new plan) there.  fork: the side stream first waits
+        for everything enqueued so far on the current stream -- needed when the ids / targets were produced there just now;
+        with long-lived inputs (a resident training set) fork=False lets the build start at once instead of behind the steps
+        already in flight (with the fork the caller's NEXT step found the build only just started: 0.25 instead of 0.21 ms per
+        step at the ML-20M shape)."""
+        if fork:
+            main = _stream_obj(self.device, _lib.raw_stream(self.device))
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            self.stream.wait_event(ev0)
+        plan = make(self.stream)
+        if pair_with is not None:
+            pair_with.prepare_lookahead(plan, stream=self.stream)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
         plan._ready = (ev, self.stream)
         return plan
 
@@ -547,14 +616,14 @@ def sample_records(plan: BatchPlan, entity_params, bias_params, inv_occ, zrec, s
           "vfm_sample_records_f32")
 
 
-def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, out_grow, out_partials, dev_step=None) -> FwdState:
+def elbo_forward_records(plan: BatchPlan, zrec, scalars, seed, step, out_pred, out_grow, out_partials, dev_step=None, flags=0) -> FwdState:
     """The forward of the pipelined step (VFM_FLAG_ZREC): a gather of this step's sample records; no sumz."""
     spec = plan.spec
-    p = _problem(spec, plan.B, plan.B_global, plan.id_bits, seed, step, FLAG_ZREC, dev_step=dev_step)
+    p = _problem(spec, plan.B, plan.B_global, plan.id_bits, seed, step, FLAG_ZREC | flags, dev_step=dev_step)
     check(_lib.load().vfm_elbo_fwd_f32(C.byref(p), ptr(plan.x), ptr(plan.y), ptr(zrec), None, None, ptr(scalars), None,
                                        None, None, None, ptr(out_pred), ptr(out_partials), None, ptr(out_grow),
                                        current_stream_ptr(zrec.device)), "vfm_elbo_fwd_f32 (records)")
-    p.flags = spec.link_flag
+    p.flags = spec.link_flag | (flags & FLAG_SHARE_GPU)
     return FwdState(out_pred, out_partials, None, out_grow, p, None)
 
 
@@ -585,7 +654,7 @@ def elbo_backward_adam_pipe(plan: BatchPlan, st: FwdState, zrec, zrec_next, next
             if rows.numel() > 0:
                 ix.touched_ids, ix.n_touched = rows.data_ptr(), rows.numel()
     p = st.problem
-    p.flags = plan.spec.link_flag | (FLAG_SCALED_MOMENTS if scaled_moments else 0)
+    p.flags = plan.spec.link_flag | (FLAG_SCALED_MOMENTS if scaled_moments else 0) | (p.flags & FLAG_SHARE_GPU)
     p.wrec = wrec.data_ptr() if wrec is not None else None
     p.dev_step = dev_step.data_ptr() if dev_step is not None else None
     check(_lib.load().vfm_elbo_bwd_adam_pipe_f32(
@@ -608,7 +677,8 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
     if next_plan.occ_ptr is None:
         next_plan.build_index()
     p = st.problem
-    p.flags = plan.spec.link_flag | FLAG_SCALED_MOMENTS
+    share = p.flags & FLAG_SHARE_GPU
+    p.flags = plan.spec.link_flag | FLAG_SCALED_MOMENTS | share
     p.wrec = wrec.data_ptr() if wrec is not None else None
     p.dev_step = dev_step.data_ptr() if dev_step is not None else None
     check(_lib.load().vfm_elbo_bwd_adam_lookahead_f32(
@@ -617,7 +687,7 @@ def elbo_backward_adam_lookahead(plan: BatchPlan, st: FwdState, next_plan: Batch
         ptr(m_views[2]), ptr(v_views[2]), lr, beta1, beta2, eps_adam, int(step), ptr(loss_out), ptr(last_step),
         ptr(next_plan.occ_ptr), ptr(step_tab), current_stream_ptr(entity_params.device)),
         "vfm_elbo_bwd_adam_lookahead_f32")
-    p.flags = plan.spec.link_flag
+    p.flags = plan.spec.link_flag | share
 
 
 def adam_catchup(entity_params, bias_params, m_views, v_views, last_step, ids, lr_of_step, upto, mark,
