@@ -311,12 +311,12 @@ def main():
         bt = setup.batches
         t0 = step_no[0]
         cur = model.plan(*bt[t0 % nbt], defer_readback=True)
-        nxt = model.plan_async(*bt[(t0 + 1) % nbt], pair_with=cur)
-        nx2 = model.plan_async(*bt[(t0 + 2) % nbt], pair_with=nxt)
+        nxt = model.plan_async(*bt[(t0 + 1) % nbt])
+        nx2 = model.plan_async(*bt[(t0 + 2) % nbt])
         for _ in range(n):       # three plans in hand: this batch's, the next one's (named to the step), the one after (being built)
             s = step_no[0]
             step_no[0] += 1
-            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 3) % nbt] + (False, nx2))   # (resident data: no fork)
+            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 3) % nbt] + (False,))   # (resident data: no fork)
             cur, nxt, nx2 = nxt, nx2, model.prefetched
 
     def run(plans, n, events, streamed=None):
@@ -469,25 +469,22 @@ def main():
     if not multi and args.streamed_steps > 0 and not args.unfused and eps_tables is None:
         setup.activate()
         m = measure(setup, "single", args.streamed_steps, nbt + 4, with_events=False, streamed=True)
-        # GPU time of ONE plan build (index + normalisers + the pair's row list), alone on the chip: HIP events around builds
-        # enqueued back to back on the current stream
+        # one plan build (index + normalisers) alone on the chip: HIP events around builds enqueued back to back on the current
+        # stream -- the larger of the build's GPU time and the host time to enqueue it
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        prev = model.plan(*setup.batches[0], defer_readback=True)
         torch.cuda.synchronize()
         e0.record()
-        for i_ in range(1, nbt + 1):
-            q_ = model.plan(*setup.batches[i_ % nbt], defer_readback=True)
-            if model.lookahead and model.lookahead_list:
-                prev.prepare_lookahead(q_)
-            prev = q_
+        keep_ = [model.plan(*setup.batches[i_ % nbt], defer_readback=True) for i_ in range(nbt)]
         e1.record()
         torch.cuda.synchronize()
+        del keep_
         streamed = {"steps": args.streamed_steps, "ms_per_step": round(m["dt"] / args.streamed_steps * 1e3, 4),
                     "triples_per_s": round(args.streamed_steps * B / m["dt"], 1),
                     "host_enqueue_ms_per_step": round(m["t_host"] / args.streamed_steps * 1e3, 4),
                     "plan_build_gpu_us_alone": round(e0.elapsed_time(e1) / nbt * 1e3, 2),
-                    "note": "every step builds the plan of the batch two steps ahead (inverted index, batch normalisers, look-ahead "
-                            "row list) on a side stream inside the timed region; nothing of a plan is reused"}
+                    "note": "every step builds the plan of the batch three steps ahead (inverted index + batch normalisers; the look-ahead "
+                            "kernel classifies the table rows itself) on a side stream inside the timed region; nothing of a plan is reused; "
+                            "plan_build_gpu_us_alone = max(GPU time, host enqueue time) of one build with nothing beside it"}
     if not multi and events is None and not args.no_events:
         # (--plans stream: the headline region carries no per-kernel events) per-kernel durations from a resident-plans pass
         m = measure(setup, "single", min(100, args.steps), 4, with_events=True)

@@ -232,6 +232,12 @@ typedef struct vfm_index {
    * VFM_HEAVY_DIRECT the main kernel adds every entity's item records itself and the k_heavy_sum launch -- which would
    * find nothing to do -- is left out (ML-100K shape: one launch of three per backward). */
   int32_t max_items;
+  /* optional: what the heavy lists were built with -- the work-item length (vfm_build_index's `heavy_list`) and the
+   * occurrence count above which an entity is heavy (the same, or vfm_rebuild_heavy's `threshold`); 0 = not known.  With
+   * both known, a SMALL table (T (2d + 2) 4 <= 2 MB: the ML-100K shape) takes the fused dense step through ONE launch that
+   * re-derives the work items from the lists themselves (one wave per table row, csrc/vfm_bwd_small.hpp) instead of the
+   * pre-reduction kernels + the row kernel: bitwise the same step, 31 -> ~10 us of backward at that shape. */
+  int32_t heavy_list, heavy_threshold;
   /* optional DEVICE word (e.g. vfm_build_index's counts[5]; zero it once): the kernels that walk the index BOUND what they
    * read -- a list length outside [0, B*F], a row number outside [0, B) or an entity outside [0, T) is clamped -- and add 1
    * here whenever a clamp fires, so a corrupted index shows up at the caller's next look at this word (vae_amd: end of every

@@ -654,3 +654,43 @@ def test_streamed_plans_give_the_resident_plans_trajectory(shape):
     assert h0["elbo"] == h1["elbo"] and h0["train_rmse"] == h1["train_rmse"] and h0["test"] == h1["test"]
     assert torch.equal(m0._flat, m1._flat) and torch.equal(m0._adam_m, m1._adam_m) and torch.equal(m0._mean_flat, m1._mean_flat)
     assert m1._plan_stream is not None and getattr(m0, "_plan_stream", None) is None
+
+
+@pytest.mark.parametrize("sizes,d,B,kw", [
+    ((943, 1682), 20, 8000, dict()),                                   # ML-100K shape (BASELINE configs[1]): ~3 work items per entity
+    ((5, 4), 32, 40000, dict()),                                       # nine entities, ~490 work items each: the partial-sum tree
+    ((400, 12), 128, 3000, dict()),                                    # d = 128: two lane groups per wave
+    ((60, 40), 8, 4000, dict(link="softplus", output="class")),        # d = 8 on the 4-lane shape, softplus link, Bernoulli
+    ((300, 200), 64, 500, dict()),                                     # mostly short lists (k_bwd's own walk), some rows not in the batch
+    ((943, 1682), 20, 8000, dict(scaled_moments=False)),               # plain moments
+])
+def test_small_table_step_is_bitwise_the_three_launch_step(sizes, d, B, kw, monkeypatch):
+    """k_bwd_small (one launch, a wave per table row, the work items re-derived from the lists) against k_heavy + k_heavy_sum +
+    k_bwd<ADAM> on the same plans: losses, parameters and both moments BIT FOR BIT over 140 steps (across a moment-period
+    boundary), three batches in turn, with the packed first-order records on.  VFM_BWD_SMALL=0 forces the old path."""
+    import vae_amd.model as M
+    from vae_amd.model import VFM
+    from vae_amd.data import synthetic_triples
+    monkeypatch.setattr(M, "_CHECK_WREC", True)
+    attrs = dict(kw)
+    link, output = attrs.pop("link", "abs"), attrs.pop("output", "reg")
+    X, y = synthetic_triples(list(sizes), 3 * B, seed=12, device="cuda", output=output, zipf=1.1)
+    runs = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("VFM_BWD_SMALL", small)
+        torch.manual_seed(2)
+        m = VFM(field_sizes=list(sizes), embedding_size=d, device="cuda", rng_seed=8, link=link, output=output)
+        m.lookahead = m.pipeline = False
+        m.lazy_adam = False
+        for k_, v_ in attrs.items():
+            setattr(m, k_, v_)
+        m.set_training_data(X, nb_train=3 * B)
+        plans = [m.plan(X[i * B:(i + 1) * B], y[i * B:(i + 1) * B]) for i in range(3)]
+        losses = [m.train_step(plans[s % 3], lr=0.03)[0].clone() for s in range(140)]
+        for pl in plans:
+            pl.check_status()
+        runs.append((m, torch.stack(losses)))
+    (a, la), (b, lb) = runs
+    assert torch.equal(la, lb)
+    assert torch.equal(a._flat, b._flat) and torch.equal(a._adam_m, b._adam_m) and torch.equal(a._adam_v, b._adam_v)
+    assert not torch.isnan(a._flat).any()

@@ -31,10 +31,10 @@ def resident(n, plans):
 
 def streamed(n):
     cur = model.plan(*bt[0], defer_readback=True)
-    nxt = model.plan_async(*bt[1], pair_with=cur)
-    nx2 = model.plan_async(*bt[2], pair_with=nxt)
+    nxt = model.plan_async(*bt[1])
+    nx2 = model.plan_async(*bt[2])
     for s in range(n):
-        model.train_step(cur, next_plan=nxt, prefetch=bt[(s + 3) % NB] + (False, nx2))
+        model.train_step(cur, next_plan=nxt, prefetch=bt[(s + 3) % NB] + (False,))
         cur, nxt, nx2 = nxt, nx2, model.prefetched
 
 

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 (cd $R && python3 -c "from vae_amd.build import sources_digest; print(sources_digest())") > $OUT/csrc_sha1.txt     # what is being profiled
 cd /tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline --sustained-steps 0 --event-every 1 ${EXTRA_ARGS:-}"     # e.g. EXTRA_ARGS="--workload ml20m_d16 --n-batches 4"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --sustained-steps 0 --streamed-steps 0 --event-every 1 ${EXTRA_ARGS:-}"     # e.g. EXTRA_ARGS="--workload ml20m_d16 --n-batches 4"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_write.json 2> $OUT/pmc_write.err

@@ -309,6 +309,16 @@ int bwd_adam_overlapped(const vfm_problem_t* p, const vfm_index_t* idx, const Sh
   return rc;
 }
 
+// The fused dense step of a SMALL table in one launch (csrc/vfm_bwd_small.hpp): every row, dense Adam, Philox eps, one
+// sample, d % 4 == 0 up to 256, and an index that says what its heavy lists were built with.  VFM_BWD_SMALL=0: A/B, tests.
+bool small_table_step(const vfm_problem_t* p, const vfm_index_t* idx, int eps, int rows_flags) {
+  if (eps != EPS_PHILOX || rows_flags != 0 || p->n_samples != 1 || (p->flags & VFM_FLAG_SPARSE_ADAM)) return false;
+  if ((p->d & 3) != 0 || p->d > 256) return false;
+  if (idx->heavy_list < VFM_HEAVY_MIN || idx->heavy_threshold < VFM_HEAVY_MIN || idx->heavy_threshold > idx->heavy_list) return false;
+  if (p->T * (2 * (int64_t)p->d + 2) * 4 > (2LL << 20)) return false;
+  return env_int("VFM_BWD_SMALL", 1) != 0;
+}
+
 int check_index(const vfm_problem_t* p, const vfm_index_t* idx, const char* who) {
   if (!idx) { snprintf(g_err, sizeof(g_err), "%s: inverted index missing", who); return VFM_E_INVALID; }
   if (int rc = check_struct(idx->struct_size, idx->abi_version, sizeof(vfm_index_t), "vfm_index_t")) return rc;
@@ -553,6 +563,17 @@ int vfm_elbo_bwd_adam_f32(const vfm_problem_t* p, const vfm_index_t* idx,
   a.row_filter = rows_flags == VFM_FLAG_ROWS_TOUCHED ? 2 : 0;
   BwdArgs b = bwd_args(p, idx);
   b.sumz = sumz; b.grow = grow; b.partials = partials; b.loss = loss;
+  if (small_table_step(p, idx, eps, rows_flags)) {       // one launch: no pre-reduction kernels, a wave per table row
+    AdamArgs ad{m_entity, v_entity, m_bias, v_bias, m_scalars, v_scalars, beta1, beta2, eps_adam, 0.f, 0.f};
+    adam_consts(lr, beta1, beta2, step, &ad.step_size, &ad.bc2_sqrt);
+    if (int rc = scaled_moment_consts(p, beta1, beta2, step, &ad)) return rc;
+    Shape s;
+    pick_shape(p->d, &s);
+    if (int rc = softplus(p) ? launch_bwd_small_softplus(s, a, b, ad, idx->heavy_list, idx->heavy_threshold, (hipStream_t)stream)
+                             : launch_bwd_small_abs(s, a, b, ad, idx->heavy_list, idx->heavy_threshold, (hipStream_t)stream))
+      return rc;
+    return after_launch("vfm_elbo_bwd_adam_f32");
+  }
   Side* sd = (!(p->flags & VFM_FLAG_SPARSE_ADAM) && heavy_overlap(p, idx)) ? side_of_device() : nullptr;
   if (!sd)
     if (int rc = run_heavy(p, idx, sumz, grow, (hipStream_t)stream, &b)) return rc;

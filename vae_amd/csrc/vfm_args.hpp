@@ -191,6 +191,9 @@ VFM_INTERNAL int launch_norms(int64_t B, int F, int64_t T, int id_bits, const vo
                                         const AdamArgs& ad, hipStream_t st);
 VFM_DECLARE_LAUNCHERS(abs)
 VFM_DECLARE_LAUNCHERS(softplus)
+// the small-table form of the fused dense step (vfm_bwd_small.hpp): L = work-item length, THR = heavy threshold of the index
+VFM_INTERNAL int launch_bwd_small_abs(const Shape& s, KArgs& a, const BwdArgs& b, const AdamArgs& ad, int L, int THR, hipStream_t st);
+VFM_INTERNAL int launch_bwd_small_softplus(const Shape& s, KArgs& a, const BwdArgs& b, const AdamArgs& ad, int L, int THR, hipStream_t st);
 // |.| link only: the specialised forward kernels and the record sampler of the pipelined step
 VFM_INTERNAL int launch_fwd2_abs(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);
 VFM_INTERNAL int launch_fwd2m_abs(int eps, int mode, KArgs& a, const FwdOut& o, hipStream_t st);

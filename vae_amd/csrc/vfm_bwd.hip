@@ -23,6 +23,9 @@ namespace {
 #include "vfm_reduce.hpp"
 #include "vfm_bwd.hpp"
 #include "vfm_sample.hpp"
+#if VFM_BWD_PART == 1
+#include "vfm_bwd_small.hpp"
+#endif
 
 constexpr int LINK = VFM_LINK;
 
@@ -118,6 +121,33 @@ int dispatch_sample_rec(const Shape& s, KArgs& a, const int32_t* ids, int n, flo
 int launch_sample_rec_abs(const Shape& s, KArgs& a, const int32_t* ids, int n, float* zrec, hipStream_t st) {
   return dispatch_sample_rec(s, a, ids, n, zrec, st);
 }
+#endif
+
+#if VFM_BWD_PART == 1
+namespace {
+int dispatch_bwd_small(const Shape& s, KArgs& a, const BwdArgs& b, const AdamArgs& ad, int L, int THR, hipStream_t st) {
+  if (s.vec != 4 || s.cpl != 1) return fail(VFM_E_UNSUPPORTED, "small-table backward: d % 4 == 0, d <= 256");
+  int64_t nb = (a.T + BLOCK / 64 - 1) / (BLOCK / 64);       // one wave per table row
+  if (nb > 256 * 16) nb = 256 * 16;
+#define X(L_)                                                                                                              \
+  if (s.lpe == L_) {                                                                                                       \
+    hipLaunchKernelGGL((k_bwd_small<L_, LINK>), dim3((unsigned)nb), dim3(BLOCK), 0, st, a, b, ad, L, THR);                 \
+    return 0;                                                                                                              \
+  }
+  X(4) X(8) X(16) X(32) X(64)
+#undef X
+  return fail(VFM_E_UNSUPPORTED, "small-table backward: no instance for this embedding size");
+}
+}  // namespace
+#if VFM_LINK == 0
+int launch_bwd_small_abs(const Shape& s, KArgs& a, const BwdArgs& b, const AdamArgs& ad, int L, int THR, hipStream_t st) {
+  return dispatch_bwd_small(s, a, b, ad, L, THR, st);
+}
+#else
+int launch_bwd_small_softplus(const Shape& s, KArgs& a, const BwdArgs& b, const AdamArgs& ad, int L, int THR, hipStream_t st) {
+  return dispatch_bwd_small(s, a, b, ad, L, THR, st);
+}
+#endif
 #endif
 
 #define VFM_CAT3(a, b, c) a##b##c

@@ -126,14 +126,17 @@ void elbo_finalize(Tensor partials, const Tensor& scalars, Tensor loss, int64_t 
 int64_t rec_len(int64_t d) { return 4 + ((d + 3) / 4) * 4; }
 
 // index = [occ_ptr, occ_rows, status] (+ [heavy_ids, heavy_items, heavy_acc]) (+ [touched_ids]) (+ a HOST int32 tensor
-// [max work items of one heavy entity]): status = one DEVICE int32 word (vfm_index_t.status: the kernels count the index
+// [max work items of one heavy entity, work-item length, heavy threshold]): status = one DEVICE int32 word (vfm_index_t.status: the kernels count the index
 // entries they had to clamp there), touched_ids = the batch's entities as a sorted list (vfm_index_t.touched_ids)
 vfm_index_t index_of(at::TensorList index_all, int64_t T, int64_t B, int64_t F, int64_t d, int64_t n_samples = 1) {
-  int32_t max_items = 0;
+  int32_t max_items = 0, heavy_list = 0, heavy_threshold = 0;
   if (index_all.size() > 0 && index_all[index_all.size() - 1].is_cpu()) {
     const at::Tensor& meta = index_all[index_all.size() - 1];
-    TORCH_CHECK(meta.scalar_type() == at::kInt && meta.numel() >= 1, "index: the trailing host tensor holds int32 [max_items]");
+    TORCH_CHECK(meta.scalar_type() == at::kInt && meta.numel() >= 3,
+                "index: the trailing host tensor holds int32 [max_items, heavy_list, heavy_threshold]");
     max_items = meta.data_ptr<int32_t>()[0];
+    heavy_list = meta.data_ptr<int32_t>()[1];
+    heavy_threshold = meta.data_ptr<int32_t>()[2];
     index_all = index_all.slice(0, index_all.size() - 1);
   }
   TORCH_CHECK(index_all.size() == 3 || index_all.size() == 4 || index_all.size() == 6 || index_all.size() == 7,
@@ -147,6 +150,7 @@ vfm_index_t index_of(at::TensorList index_all, int64_t T, int64_t B, int64_t F, 
   VFM_STRUCT_INIT(ix);
   ix.occ_ptr = index_all[0].data_ptr<int32_t>(); ix.occ_rows = index_all[1].data_ptr<int32_t>();
   ix.status = index_all[2].data_ptr<int32_t>();
+  ix.heavy_list = heavy_list; ix.heavy_threshold = heavy_threshold;
   if (has_heavy && index_all[3].numel() > 0) {
     const at::Tensor &hid = index_all[3], &items = index_all[4], &hacc = index_all[5];
     dev_tensor(hid, at::kInt, "heavy_ids"); dev_tensor(items, at::kInt, "heavy_items"); dev_tensor(hacc, at::kFloat, "heavy_acc");

@@ -532,6 +532,8 @@ class VFM(nn.Module):
         collective, built in line)."""
         if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != self.device:
             self._plan_stream = ops.PlanStream(self.device)
+        # (the pair's row list only where the caller asks for it: the streamed loop lets the look-ahead kernel classify the
+        #  table rows itself -- +4 us of kernel time against 35 us of host time and three more launches per step)
         pair = pair_with if (pair_with is not None and self.lookahead and self.lookahead_list and self.n_samples == 1) else None
         return self._plan_stream.build(lambda st: self.plan(x, y, defer_readback=True, stream=st), pair_with=pair, fork=fork)
 
@@ -543,8 +545,9 @@ class VFM(nn.Module):
         synchronises with the host.  Returns (loss3 device tensor [loss, nll, kl], pred [B]).
         prefetch = (x, y[, fork[, pair_with]]) of a LATER batch: its plan is built on the side stream while this step runs
         (`plan_async`; enqueued after this step's own launches) and waits in `self.prefetched` for the caller to take.
-        pair_with: the plan of the batch right before it (default: `next_plan`, else `plan`) -- the look-ahead row list of
-        that pair is made with it.  Prefetch TWO batches beyond `next_plan` (as `fit(stream_plans=True)` does): a step reads
+        pair_with: the plan of the batch right before it, or None (default) -- with it the look-ahead row list of that pair is
+        made too; without, a look-ahead step on such plans classifies the table rows itself (the scan form: what the
+        streamed loop takes).  Prefetch TWO batches beyond `next_plan` (as `fit(stream_plans=True)` does): a step reads
         the size of its next batch's index on the host, so a plan enqueued during the previous step would be waited for."""
         self._ensure_opt_state()
         self._sharing = prefetch is not None        # (plan builds run beside this step: its row kernels leave them slots)
@@ -552,7 +555,7 @@ class VFM(nn.Module):
             try:
                 return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)
             finally:
-                pw = prefetch[3] if len(prefetch) > 3 else (next_plan if next_plan is not None else plan)
+                pw = prefetch[3] if len(prefetch) > 3 else None
                 self.prefetched = self.plan_async(prefetch[0], prefetch[1], pair_with=pw, fork=prefetch[2] if len(prefetch) > 2 else True)
         return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)
 
@@ -709,7 +712,8 @@ class VFM(nn.Module):
         if la:      # ... visiting only the rows of this batch and of the next one (look-ahead lazy exact Adam)
             ops.elbo_backward_adam_lookahead(plan, st, next_plan, ent, bia, scal, self.inv_occ,
                                              self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t,
-                                             loss3, self._lazy_last, self._la_tab, listed=self.lookahead_list, wrec=wrec)
+                                             loss3, self._lazy_last, self._la_tab,
+                                             listed=self.lookahead_list and not getattr(self, "_sharing", False), wrec=wrec)
         else:
             ops.elbo_backward_adam(plan, st, ent, bia, scal, self.inv_occ, self._views(self._adam_m),
                                    self._views(self._adam_v), lr, self._adam_t, loss_out=loss3,
@@ -785,7 +789,7 @@ class VFM(nn.Module):
                                     self._views(self._adam_m), self._views(self._adam_v), lr, self._adam_t, loss3,
                                     scaled_moments=scaled, wrec=wrec,
                                     last_step=self._lazy_last if la else None, step_tab=self._la_tab if la else None,
-                                    listed=self.lookahead_list, la_next=la_next)
+                                    listed=self.lookahead_list and not getattr(self, "_sharing", False), la_next=la_next)
         mark("bwd_adam")
         out = st.pred
         if next_plan is not None:
@@ -898,13 +902,13 @@ class VFM(nn.Module):
         batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]], False)
         # three plans in hand: this batch's, the next one's (named to the step), and the one after (being built)
         cur = self.plan(*batch(0)[:2], defer_readback=True)
-        nxt = self.plan_async(*batch(1)[:2], pair_with=cur) if total > 1 else None
-        nx2 = self.plan_async(*batch(2)[:2], pair_with=nxt) if total > 2 else None
+        nxt = self.plan_async(*batch(1)[:2]) if total > 1 else None
+        nx2 = self.plan_async(*batch(2)[:2]) if total > 2 else None
         for t in range(total):
             epoch, i = divmod(t, nb)
             a, b = spans[i]
             loss3, pr = self.train_step(cur, next_plan=nxt if self.n_samples == 1 else None,
-                                        prefetch=batch(t + 3) + (nx2,) if t + 3 < total else None)
+                                        prefetch=batch(t + 3) if t + 3 < total else None)
             train_pred[a:b] = pr if self.n_samples == 1 else pr.mean(0)
             losses[i] = loss3[0]
             cur, nxt, nx2 = nxt, nx2, (self.prefetched if t + 3 < total else None)

@@ -340,12 +340,13 @@ class BatchPlan:
         # long lists (skewed data, small tables): cut in work items of at most `heavy_list` occurrences, pre-reduced
         # by their own lane groups in every backward call (vfm_index_t in include/vfm_hip.h)
         self._heavy = None
-        self.heavy_max_items = 0
+        # the most work items one entity has (from the build's own readback): at most VFM_HEAVY_DIRECT and the backward
+        # leaves its k_heavy_sum launch out (vfm_index_t.max_items); with it the work-item length and the heavy threshold
+        # the lists were built with (vfm_index_t.heavy_list / heavy_threshold: the small-table step re-derives the items)
+        self.heavy_max_items = max_items if n_heavy > 0 else 0
+        self._heavy_meta = torch.tensor([self.heavy_max_items, self.heavy_list, getattr(self, "heavy_threshold", self.heavy_list)],
+                                        dtype=torch.int32)
         if n_heavy > 0:
-            # the most work items one entity has (from the build's own readback): at most VFM_HEAVY_DIRECT and the
-            # backward leaves its k_heavy_sum launch out (vfm_index_t.max_items)
-            self.heavy_max_items = max_items
-            self._heavy_meta = torch.tensor([self.heavy_max_items], dtype=torch.int32)
             rec = 4 + (spec.d + 3) // 4 * 4
             self._heavy = (hid[:n_heavy], items[:n_items],       # scratch: entity records + work-item records
                            torch.zeros(spec.n_samples * (n_heavy + n_items) * rec, dtype=torch.float32, device=dev))
@@ -447,7 +448,7 @@ class BatchPlan:
             base = base + list(self.heavy)
         if with_touched:
             base = base + [self._touched]
-        return base + [self._heavy_meta] if self.heavy is not None else base       # (host tensor: vfm_index_t.max_items)
+        return base + [self._heavy_meta]       # (host tensor: vfm_index_t.max_items, heavy_list, heavy_threshold)
 
 
 def _index_struct(plan: BatchPlan) -> "_lib.Index":
@@ -457,6 +458,7 @@ def _index_struct(plan: BatchPlan) -> "_lib.Index":
     plan._finish()
     ix = _lib.Index()
     ix.occ_ptr, ix.occ_rows, ix.status = plan.occ_ptr.data_ptr(), plan.occ_rows.data_ptr(), plan.status.data_ptr()
+    ix.heavy_list, ix.heavy_threshold = plan.heavy_list, getattr(plan, "heavy_threshold", plan.heavy_list)
     if plan.heavy is not None:
         hid, items, acc = plan.heavy
         ix.heavy_ids, ix.heavy_items, ix.heavy_acc = hid.data_ptr(), items.data_ptr(), acc.data_ptr()
