@@ -5,9 +5,10 @@
 #   data files' order (sorted by user: a batch = ~900 users' consecutive ratings, 8 % of the table) | cfg5 shape on one GPU
 #   (lazy exact Adam: auto) and the same with the dense step | the software-pipelined step on / off where "auto"
 #   decides either way | cfg3 forward A/B: k_fwd (every occurrence sampled), k_fwd2 with table eps, k_fwd2 with the
-#   RNG compiled out, rows not sorted | cfg3 without the look-ahead lazy Adam form (every row every step)
-# usage: tools/bench_points.sh r02
-TAG=${1:-r02}
+#   RNG compiled out, rows not sorted | cfg3 without the look-ahead lazy Adam form (every row every step) | cfg2 with the
+#   three-launch backward (VFM_BWD_SMALL=0) | cfg3 with every plan built inside the timed region (--plans stream)
+# usage: tools/bench_points.sh r04
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/points_$TAG.jsonl
 mkdir -p $R/gpurun_out
@@ -22,7 +23,8 @@ j=json.loads(sys.stdin.readline()); j['point']='$label'; print(json.dumps(j))" >
 }
 COMMON="--sustained-steps 1000"
 run cfg2_ml100k_d20 "" --workload ml100k_d20 --steps 300 --warmup 30 $COMMON
-run cfg2_ml100k_d20_replayed_graphs "" --workload ml100k_d20 --steps 300 --warmup 30 --replay on $COMMON
+run cfg2_ml100k_d20_three_launch_step "VFM_BWD_SMALL=0" --workload ml100k_d20 --steps 300 --warmup 30 $COMMON
+run cfg3_plans_streamed "" --plans stream --steps 400 --warmup 20 --no-regions --sustained-steps 0 --streamed-steps 0
 run cfg3_no_packed_records "" --no-wrec --steps 200 --warmup 20 --no-regions $COMMON
 run cfg5_criteo_d256_k_fwd "VFM_FWD_KERNEL=1" --workload criteo_d256 --steps 200 --warmup 20 --sustained-steps 0
 run cfg3_B1048576 "" --batch 1048576 --n-batches 4 --steps 60 --warmup 6 --sustained-steps 0
@@ -48,5 +50,5 @@ for l in open("$OUT"):
     j = json.loads(l)
     if j.get("error"): print(j); continue
     print(j["point"], "ms/step", j["ms_per_step"], "value", j["value"], {k: v["avg_us"] for k, v in j["kernels"].items()},
-          "sustained", (j.get("sustained") or {}).get("ms_per_step"), "replayed", (j.get("replayed") or {}).get("ms_per_step"))
+          "sustained", (j.get("sustained") or {}).get("ms_per_step"), "streamed", j.get("ms_per_step_streamed"))
 PY

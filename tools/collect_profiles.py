@@ -56,7 +56,15 @@ stamp = os.path.join(src, "csrc_sha1.txt")      # written on the GPU box by tool
 traffic["_csrc_sha1"] = open(stamp).read().strip() if os.path.exists(stamp) else sources_digest()
 if traffic["_csrc_sha1"] != sources_digest():
     print("WARNING: the profiled sources are not the current ones (bench.py will not attach these figures)")
-json.dump(traffic, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
+# only the default bench command's passes feed bench.py's roofline.traffic (tags like r04cfg2 / r04b1m are other workloads:
+# their summaries are written as profiles/<round>_<point>_pmc_summary.* and nothing else)
+point = tag[3:] if len(tag) > 3 and tag[0] == "r" and tag[1:3].isdigit() else ""
+if not point:
+    json.dump(traffic, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
+else:
+    for ext in ("_kernel_stats.csv", "_pmc_summary.txt", "_pmc_summary.json"):
+        os.replace(os.path.join(dst, tag + ext), os.path.join(dst, f"{tag[:3]}_{point}{ext}"))
+    tag = f"{tag[:3]}_{point}"
 if len(sys.argv) > 2:
     shutil.copy(sys.argv[2], os.path.join(dst, f"{tag}_bench.json"))
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag) or f == "latest_traffic.json"))

@@ -14,18 +14,17 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("k_fwd", "k_bwd", "k_adam_catchup", "k_adam", "k_finalize", "k_norms", "k_zero", "k_inv_occ", "k_philox", "k_heavy_sum",
-        "k_heavy", "k_sample_rec", "k_radix", "k_index", "k_var_")
+import re
+
+# kernels of this library: every `k_*` function of namespace vfm, named with its template arguments
+_KERNEL = re.compile(r"vfm::(?:\(anonymous namespace\)::)?(k_[a-z0-9_]+)(<[^>]*>)?")
 
 
 def short(name):
-    for k in OURS:
-        if k in name:
-            if k in ("k_fwd", "k_bwd") and "<" in name:
-                i = name.index(k)
-                return name[i:name.index(">", i) + 1]
-            return k
-    return None
+    m = _KERNEL.search(name)
+    if not m:
+        return None
+    return m.group(1) + (m.group(2) or "")
 
 
 def main(argv):

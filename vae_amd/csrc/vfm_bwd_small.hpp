@@ -29,6 +29,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
   constexpr int LGW = 64 / LPE;                      // lane groups of a wave
   constexpr int GPBH = BLOCK / LPE;                  // lane groups of a k_heavy_sum workgroup: the partial sums P_g
   constexpr int WPB = BLOCK / 64;                    // waves (= table rows) per workgroup
+  constexpr int U = 8;                               // occurrences of a work item in flight
   AdamArgs ad = ad_in;
   RngKey key = a.key, next_key = b.next_key;
   int32_t la_step = 0, la_k = 0;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
   const int lig = lane % LPE, lg = lane / LPE;
   const int d = a.d;
   const int C = (d + VEC - 1) / VEC;
+  const int ligc = lig < C ? lig : C - 1;            // lanes past the last chunk re-load the last one (their sums are never used)
   if (tid < a.G) {
     sh_cs[tid] = (float)(a.group_n[tid] / a.W[tid]);
     sh_hi[tid] = a.group_hi[tid];
@@ -86,9 +88,9 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
   int nclamp = 0;
   const int n_occ = b.n_occ;
   const int Bm1 = a.B > 0 ? (int)a.B - 1 : 0;
-  auto row_ok = [&](int v) -> int {
+  auto row_ok = [&](int v, bool live = true) -> int {
     const bool ok = (unsigned)v <= (unsigned)Bm1;
-    nclamp += ok ? 0 : 1;
+    nclamp += (ok || !live) ? 0 : 1;
     return ok ? v : 0;
   };
   float(*P)[4 * LPE + 4] = sh_P[wave];
@@ -137,14 +139,32 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
 #pragma unroll
           for (int t = 0; t < VEC; ++t) Ai.v[t] = 0.f;
           float gi = 0.f;
-          for (int o = ib; o < ie; ++o) {
-            const int r = row_ok(b.occ_rows[o]);
-            const float g0 = b.grow[r];
-            gi += g0;
-            if (lig < C) {
-              const Chunk<VEC> sv = ld_chunk<VEC>(b.sumz + (size_t)r * d + (size_t)lig * VEC);
+          // U occurrences in flight: every load of a batch is issued before the first fma needs one; the sums themselves
+          // are formed one occurrence at a time in list order, as k_heavy forms them.  The row ids of the NEXT batch are
+          // fetched under the current one.
+          int rn[U];
 #pragma unroll
-              for (int t = 0; t < VEC; ++t) Ai.v[t] = fmaf(g0, sv.v[t], Ai.v[t]);
+          for (int u = 0; u < U; ++u) rn[u] = b.occ_rows[ib + u < ie ? ib + u : ie - 1];
+          for (int o = ib; o < ie; o += U) {
+            int r[U];
+            float g[U];
+            Chunk<VEC> sv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = row_ok(rn[u], o + u < ie);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              g[u] = b.grow[r[u]];
+              sv[u] = ld_chunk<VEC>(b.sumz + (size_t)r[u] * d + (size_t)ligc * VEC);      // (no load under a branch)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) rn[u] = b.occ_rows[o + U + u < ie ? o + U + u : ie - 1];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (o + u < ie) {
+                gi += g[u];
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) Ai.v[t] = fmaf(g[u], sv[u].v[t], Ai.v[t]);
+              }
             }
           }
           Pgs += gi;

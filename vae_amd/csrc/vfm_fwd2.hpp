@@ -183,6 +183,24 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const int tid = threadIdx.x;
   const int lig = tid % LPE;
   const int C = a.d >> 2;                       // chunks of 4 coordinates (d % 4 == 0 here)
+  // rows of this group: the batch is dealt in contiguous ranges over all groups of the grid (B * 2 < 2^31).  The ids of
+  // its first three rows are requested before anything else: at ~1 row per group (the ML-100K shape on a full grid) the
+  // wave's life is one chain  ids -> table rows -> sample -> outputs,  and the prologue's barrier would otherwise sit
+  // in front of that chain instead of under it
+  const int NG = (int)gridDim.x * GPB;
+  const int gid = (int)blockIdx.x * GPB + tid / LPE;
+  const int q = (int)(a.B / NG), rem = (int)(a.B % NG);
+  const int gbeg = gid * q + (gid < rem ? gid : rem);
+  const int gend = gbeg + q + (gid < rem ? 1 : 0);
+  const int glast = gend - 1;
+  RawIds<ID64> raw0, raw1, raw2;
+  float y_first = 0.f;
+  if (gbeg < gend) {
+    raw0 = load_row_ids<ID64>(a, gbeg);
+    raw1 = load_row_ids<ID64>(a, gbeg + 1 < gend ? gbeg + 1 : glast);
+    raw2 = load_row_ids<ID64>(a, gbeg + 2 < gend ? gbeg + 2 : glast);
+    if constexpr (MODE == MODE_TRAIN) y_first = a.y[gbeg];
+  }
   // eps stream step: the kernel argument, or (replayable step) device memory -- thread 0 of block 0 hands it on
   const RngKey key = key_of_step(a, blockIdx.x == 0 && tid == 0);
 
@@ -221,26 +239,17 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fwd2(const KArgs a, const FwdOut o
   const int off0 = 4 * (v0 ? j0 : C - 1), off1 = 4 * (v1 ? j1 : C - 1);
   const uint32_t pg = (uint32_t)lig + (key.chunk_off >> 1);      // Philox counter word 0 of this lane
 
-  // rows of this group: the batch is dealt in contiguous ranges over all groups of the grid (B * 2 < 2^31)
-  const int NG = (int)gridDim.x * GPB;
-  const int gid = (int)blockIdx.x * GPB + tid / LPE;
-  const int q = (int)(a.B / NG), rem = (int)(a.B % NG);
-  const int gbeg = gid * q + (gid < rem ? gid : rem);
-  const int gend = gbeg + q + (gid < rem ? 1 : 0);
-  const int glast = gend - 1;
-
   float tot[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // ll, kl, g, alpha-term, bad ids, (unused)
   if (gbeg < gend) {
     // ---- pipeline state: folded ids of the current row and the next one, raw ids of the row after ----
     int r0 = gbeg;                           // row of the current task
-    Ids id0 = fold_ids<ID64>(load_row_ids<ID64>(a, r0), T32);
-    Ids id1 = fold_ids<ID64>(load_row_ids<ID64>(a, r0 + 1 < gend ? r0 + 1 : glast), T32);
-    RawIds<ID64> id2 = load_row_ids<ID64>(a, r0 + 2 < gend ? r0 + 2 : glast);
+    Ids id0 = fold_ids<ID64>(raw0, T32);
+    Ids id1 = fold_ids<ID64>(raw1, T32);
+    RawIds<ID64> id2 = raw2;
     bool cur_item = true;                    // the first task of a range is always an item task
     EntRegs<EPS> A, Bq;
     load_ent<EPS, MODE, WREC>(a, entity_of(id0.i, true, tot[4]), off0, off1, A);
-    float ycur = 0.f;                        // target of the row the current task belongs to
-    if constexpr (MODE == MODE_TRAIN) ycur = a.y[r0];
+    float ycur = y_first;                    // target of the row the current task belongs to
     // the cached item
     float zi[8], wi = 0.f, klwi = 0.f;
 #pragma unroll
