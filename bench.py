@@ -24,7 +24,7 @@ entry is the fused forward ELBO kernel; `frac_fwd_8d` / `frac_K_8d` are SURVEY 8
 target); `kernels` lists all of them (HIP events on every 5th step of the timed region); `sustained` = 2,000
 more steps without events; `streamed` = the regime of a caller that cannot keep plans (streamed / shuffled batches): every
 step's plan -- inverted index, normalisers, look-ahead row list: what replaces the reference's torch.unique x3,
-vfm-torch.py:190-192 -- is built INSIDE the timed region, two steps ahead on a side stream (`--plans stream` makes that the
+vfm-torch.py:190-192 -- is built INSIDE the timed region, a few steps ahead on side streams (`--plans stream` makes that the
 headline region).  `cpu_baseline` = the reference-shaped torch-CPU restatement
 (oracle/vfm_oracle.py, pinned to the reference by tests/golden; the reference's two unused per-row lookups included)
 timed on this node's host cores.
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--plans", default="resident", choices=["resident", "stream"],
                     help="N=1.  resident (default): plans are built once per batch before the timed region and reused (the "
                          "reference's loader does not shuffle, vfm-torch.py:121-122); stream: the timed region builds every plan "
-                         "it uses, two steps ahead on a side stream -- the regime of a caller that streams or shuffles batches. "
+                         "it uses, a few steps ahead (VFM.plan_prefetch_depth) on side streams -- the regime of a caller that streams or shuffles batches. "
                          "Whatever this says, the line carries both figures (`ms_per_step` / `streamed`).")
     ap.add_argument("--streamed-steps", type=int, default=400, help="steps of the extra `streamed` region (0: none)")
     ap.add_argument("--scaling", default="both", choices=["both", "strong", "weak"],
@@ -305,19 +305,19 @@ def main():
     step_no = [0]                     # batches are cycled through in order across warm-up and timed regions
 
     def run_streamed(setup, n):
-        """n steps of a caller that keeps NO plan: the plan of batch t+2 (index, normalisers, the look-ahead row list of the
-        pair (t+1, t+2)) is built on the side stream while step t runs -- everything that replaces the reference's
+        """n steps of a caller that keeps NO plan: the plan of batch t + depth (index, normalisers) is built on a side stream
+        while step t runs -- everything that replaces the reference's
         torch.unique x3 (vfm-torch.py:190-192) is inside the loop."""
         bt = setup.batches
         t0 = step_no[0]
-        cur = model.plan(*bt[t0 % nbt], defer_readback=True)
-        nxt = model.plan_async(*bt[(t0 + 1) % nbt])
-        nx2 = model.plan_async(*bt[(t0 + 2) % nbt])
-        for _ in range(n):       # three plans in hand: this batch's, the next one's (named to the step), the one after (being built)
+        D = max(2, int(model.plan_prefetch_depth))
+        q = [model.plan(*bt[t0 % nbt], defer_readback=True)] + [model.plan_async(*bt[(t0 + k) % nbt]) for k in range(1, D)]
+        for _ in range(n):       # D plans in hand: this batch's, the next one's (named to the step), the ones being built
             s = step_no[0]
             step_no[0] += 1
-            model.train_step(cur, next_plan=nxt, fused=not args.unfused, prefetch=bt[(s + 3) % nbt] + (False,))   # (resident data: no fork)
-            cur, nxt, nx2 = nxt, nx2, model.prefetched
+            model.train_step(q[0], next_plan=q[1], fused=not args.unfused, prefetch=bt[(s + D) % nbt] + (False,))   # (resident data: no fork)
+            q.pop(0)
+            q.append(model.prefetched)
 
     def run(plans, n, events, streamed=None):
         if streamed is not None:
@@ -457,7 +457,7 @@ def main():
     nan_params = int(torch.isnan(model._flat).sum().item())
 
     # ---- N = 1: figures next to the commanded region: `sustained` = the same steps over a long region without events;
-    # `streamed` = the regime in which no plan is kept (every step's plan built inside the timed region, two steps ahead on a
+    # `streamed` = the regime in which no plan is kept (every step's plan built inside the timed region, a few steps ahead on a
     # side stream) -- with the GPU time of one plan build, measured alone, beside it
     sustained = streamed = None
     if not multi and args.sustained_steps > 0:
@@ -482,7 +482,8 @@ def main():
                     "triples_per_s": round(args.streamed_steps * B / m["dt"], 1),
                     "host_enqueue_ms_per_step": round(m["t_host"] / args.streamed_steps * 1e3, 4),
                     "plan_build_gpu_us_alone": round(e0.elapsed_time(e1) / nbt * 1e3, 2),
-                    "note": "every step builds the plan of the batch three steps ahead (inverted index + batch normalisers; the look-ahead "
+                    "prefetch_depth": int(model.plan_prefetch_depth),
+                    "note": "every step builds the plan of the batch `prefetch_depth` steps ahead (inverted index + batch normalisers; the look-ahead "
                             "kernel classifies the table rows itself) on a side stream inside the timed region; nothing of a plan is reused; "
                             "plan_build_gpu_us_alone = max(GPU time, host enqueue time) of one build with nothing beside it"}
     if not multi and events is None and not args.no_events:
@@ -587,7 +588,7 @@ def main():
                        "lazy_exact_adam": {"list": "rows of the batch only + replay pass", "la": "look-ahead (this batch + next batch)",
                                            None: False}[lazy_kind],
                        "pipelined_step": piped, "packed_first_order_records": bool(model.use_wrec and not multi and not args.unfused),
-                       "plans": ("built inside the timed region, two steps ahead on a side stream" if (not multi and args.plans == "stream")
+                       "plans": ("built inside the timed region, a few steps ahead on side streams" if (not multi and args.plans == "stream")
                                  else "resident: built once per batch before the timed region, reused every epoch (vfm-torch.py:121-122: no shuffling)"),
                        "exchange": model.exchange if multi else None, "exchange_note": exchange_note,
                        "step": ({"stats": "fwd+loss+bwd_acc+allreduce(stats)+apply_adam",

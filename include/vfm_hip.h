@@ -81,10 +81,10 @@ extern "C" {
                                      pipelined backward gathers the samples themselves): bias_params, inv_occ, W, sumz
                                      may be NULL.  Half the gather bytes of the (mu | s) rows, no RNG.  |.| link only. */
 #define VFM_FLAG_SHARE_GPU 2048   /* the caller runs other work BESIDE this step -- the next batches' index builds on a side stream
-                                     (vfm_build_index) -- so the two-field forward and the fused backward launch 7/8 of the
+                                     (vfm_build_index) -- so the two-field forward and the fused backward launch 15/16 of the
                                      workgroups the chip can hold instead of filling every slot: small kernels of the other
-                                     stream then find room at once (ML-20M shape, plans built inside the loop: 0.242 -> 0.220 ms
-                                     per step; with nothing beside it the step itself is 3 % slower, hence a flag)            */
+                                     stream then find room at once (ML-20M shape, plans built inside the loop: 0.245 -> 0.229 ms
+                                     per step; with nothing beside it the step itself is 2 % slower, hence a flag)            */
 #define VFM_FLAG_EPS_ZERO 2       /* eps = 0 everywhere: deterministic prediction from the
                                      posterior means (vfm-torch.py:248-259)                       */
 #define VFM_FLAG_LINK_SOFTPLUS 16 /* LINK = softplus instead of |.| (vfm-torch.py:125-126; applies to alpha,

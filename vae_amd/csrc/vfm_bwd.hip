@@ -37,9 +37,9 @@ int launch_bwd_t(KArgs& a, const BwdArgs& b, const AdamArgs& ad, hipStream_t st)
   if (ADAM != 0 && b.row_ids) nb = (b.n_rows + GPB - 1) / GPB;     // the listed rows only
   const int64_t cap = 256LL * per_cu;
   if (nb > cap) nb = cap;
-  // VFM_FLAG_SHARE_GPU: 7/8 of the 1,024 workgroups the chip holds (126 VGPRs: four per CU), so that another stream's small
-  // kernels find free slots while this one runs
-  if ((a.flags & VFM_FLAG_SHARE_GPU) && nb > 896) nb = 896;
+  // VFM_FLAG_SHARE_GPU: 15/16 of the 1,024 workgroups the chip holds (126 VGPRs: four per CU), so that another stream's small
+  // kernels (256 threads, <= 128 VGPRs: csrc/vfm_index.hip) find a free slot on 64 CUs while this one runs
+  { const int share = env_int("VFM_SHARE_CAP", 960); if ((a.flags & VFM_FLAG_SHARE_GPU) && share > 0 && nb > share) nb = share; }
   { const int forced = env_int("VFM_BWD_GRID", 0); if (forced > 0 && nb > forced) nb = forced; }      // (A/B runs)
   if (nb < 1) nb = 1;
   if constexpr (STAGE == STAGE_FULL && ADAM == 1 && EPS == EPS_PHILOX && VEC == 4 && LINK == LINK_ABS) {

@@ -28,7 +28,7 @@ int launch_fwd2_t(KArgs& a, const FwdOut& o, hipStream_t st) {
   int64_t cap = 256LL * per_cu;
   if (cap > VFM_MAX_FWD_BLOCKS) cap = VFM_MAX_FWD_BLOCKS;
   if (nb > cap) nb = cap;
-  if ((a.flags & VFM_FLAG_SHARE_GPU) && nb > 896) nb = 896;       // (leave workgroup slots to another stream: include/vfm_hip.h)
+  { const int share = env_int("VFM_SHARE_CAP", 960); if ((a.flags & VFM_FLAG_SHARE_GPU) && share > 0 && nb > share) nb = share; }       // (leave workgroup slots to another stream: include/vfm_hip.h)
   { const int forced = env_int("VFM_FWD2_GRID", 0); if (forced > 0 && nb > forced) nb = forced; }      // (A/B runs)
   if (nb < 1) nb = 1;
   if constexpr (EPS == EPS_PHILOX && MODE == MODE_TRAIN) {

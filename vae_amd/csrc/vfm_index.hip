@@ -41,8 +41,12 @@ constexpr int RS_SUB = RS_ITEMS * (RS_THREADS / 64); // 64-key sub-tiles of a ti
 constexpr int RS_MAXBITS = 9;
 constexpr int RS_MAXD = 1 << RS_MAXBITS;             // digits per pass, at most
 constexpr int RS_MAXPASS = 4;                        // ceil(32 / 9)
-constexpr int HV_CHUNK = 1024;                       // entities per workgroup of the compaction launches
-constexpr int HV_SELF = 4096;                        // chunks up to which a compaction workgroup adds up its predecessors itself
+// Entities per workgroup of the compaction launches = its threads.  256, not 1024: a build on a side stream runs BESIDE the
+// step's persistent kernels (k_bwd: 4 waves of 128 VGPRs per SIMD; under VFM_FLAG_SHARE_GPU half the CUs keep one
+// workgroup slot free = one wave of <= 128 VGPRs per SIMD).  A 1024-thread workgroup (4 waves per SIMD, 160-224 VGPRs) fits
+// nowhere until the step's kernel ENDS: traced at 86 us for 8 us of work (tools/stream_timeline.py).
+constexpr int HV_CHUNK = 256;
+constexpr int HV_SELF = 1024;                        // chunks up to which a compaction workgroup adds up its predecessors itself
 constexpr int NW_MAXF = 4;                           // fields up to which W is formed inside k_index_keys
 
 // ---- geometry of one build: shared by vfm_index_workspace_bytes and vfm_build_index ----
@@ -574,14 +578,16 @@ __global__ __launch_bounds__(HV_CHUNK) void k_index_write(const int32_t* __restr
       for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
       if (tid == 0) counts[0] = (int32_t)b;
     }
-    if (W && tid >= 64 && tid < 64 * (1 + NW_MAXF)) {       // W_f: wave 1 + f adds the tiles' shares of field f -- every lane its
-      const int f = (tid >> 6) - 1, lane = tid & 63;       // tiles in order, then the lanes in a fixed tree: reproducible
-      double t = 0.0;
-      if (wpart && f < F)
-        for (int j = lane; j < NB; j += 64) t += wpart[(size_t)j * NW_MAXF + f];
+    if (W) {                    // W_f: a wave adds the tiles' shares of field f -- every lane its tiles in order, then the
+      const int lane = tid & 63; //  lanes in a fixed tree: reproducible
+      for (int f = tid >> 6; f < F && f < NW_MAXF; f += HV_CHUNK / 64) {
+        double t = 0.0;
+        if (wpart)                  // (an empty batch has no tiles: W = 0)
+          for (int j = lane; j < NB; j += 64) t += wpart[(size_t)j * NW_MAXF + f];
 #pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-      if (lane == 0 && f < F) W[f] = t;
+        for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if (lane == 0) W[f] = t;
+      }
     }
   }
 }

@@ -130,6 +130,10 @@ class VFM(nn.Module):
         # ... so the pipelined step has a look-ahead form of its own (k_bwd<PIPE, LA>: rows in neither this batch nor the
         # next are skipped and replayed later, bitwise the every-row pipelined step): 0.113-0.131 ms per step on that shape.
         self.pipeline_lookahead = True
+        # plans a streamed loop (fit(stream_plans=True), bench.py --plans stream) keeps in hand: the build of batch t + depth
+        # is enqueued while step t runs.  The host reads a build's counts when the plan is first named to a step (as
+        # `next_plan`): with four, that build was enqueued three steps earlier and the host never waits for it
+        self.plan_prefetch_depth = int(__import__("os").environ.get("VFM_PLAN_DEPTH", "4"))
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"            # (row-list form: used when no next batch is named; with one, the look-ahead
@@ -900,18 +904,20 @@ class VFM(nn.Module):
         total = n_epochs * nb
         # (fork=False: Xd / yd are resident since before the loop -- the builds need not wait for the steps in flight)
         batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]], False)
-        # three plans in hand: this batch's, the next one's (named to the step), and the one after (being built)
-        cur = self.plan(*batch(0)[:2], defer_readback=True)
-        nxt = self.plan_async(*batch(1)[:2]) if total > 1 else None
-        nx2 = self.plan_async(*batch(2)[:2]) if total > 2 else None
+        # `plan_prefetch_depth` plans in hand: this batch's, the next one's (named to the step), and the ones being built
+        D = max(2, int(self.plan_prefetch_depth))
+        q = [self.plan(*batch(0)[:2], defer_readback=True)] + [self.plan_async(*batch(k)[:2]) for k in range(1, min(D, total))]
         for t in range(total):
             epoch, i = divmod(t, nb)
             a, b = spans[i]
-            loss3, pr = self.train_step(cur, next_plan=nxt if self.n_samples == 1 else None,
-                                        prefetch=batch(t + 3) if t + 3 < total else None)
+            nxt = q[1] if len(q) > 1 else None
+            loss3, pr = self.train_step(q[0], next_plan=nxt if self.n_samples == 1 else None,
+                                        prefetch=batch(t + D) if t + D < total else None)
             train_pred[a:b] = pr if self.n_samples == 1 else pr.mean(0)
             losses[i] = loss3[0]
-            cur, nxt, nx2 = nxt, nx2, (self.prefetched if t + 3 < total else None)
+            q.pop(0)
+            if t + D < total:
+                q.append(self.prefetched)
             if i == nb - 1:
                 if self.output == "reg":
                     self.save_weights()

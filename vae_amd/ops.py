@@ -475,9 +475,20 @@ class PlanStream:
     carries the event its first user waits for (`BatchPlan.use_on_current`).  The builds are small latency-bound launches
     (~40 us of GPU time per batch at the ML-20M shape) that fit beside the bandwidth-bound step kernels."""
 
-    def __init__(self, device):
+    def __init__(self, device, n_streams: Optional[int] = None):
+        import os
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(self.device, priority=int(__import__("os").environ.get("VFM_PLAN_PRIORITY", "-1")))
+        n = int(os.environ.get("VFM_PLAN_STREAMS", "2")) if n_streams is None else int(n_streams)
+        prio = int(os.environ.get("VFM_PLAN_PRIORITY", "-1"))
+        # builds alternate between the streams: a build is a chain of seven dependent small launches, each waiting for
+        # free workgroup slots beside the step's kernels -- on ONE stream the chain of batch t+3 also waits for the chain
+        # of batch t+2 to end, and the loop runs at the pace of that one queue
+        self.streams = [torch.cuda.Stream(self.device, priority=prio) for _ in range(max(1, n))]
+        self._turn = 0
+
+    @property
+    def stream(self):
+        return self.streams[self._turn % len(self.streams)]
 
     def build(self, make, pair_with: Optional[BatchPlan] = None, fork: bool = True) -> BatchPlan:
         """`make(stream)` -> BatchPlan whose build is enqueued on `stream` (BatchPlan(..., defer_readback=True, stream=stream));
@@ -486,17 +497,21 @@ class PlanStream:
         with long-lived inputs (a resident training set) fork=False lets the build start at once instead of behind the steps
         already in flight (with the fork the caller's NEXT step found the build only just started: 0.25 instead of 0.21 ms per
         step at the ML-20M shape)."""
+        self._turn += 1
+        st = self.stream
         if fork:
             main = _stream_obj(self.device, _lib.raw_stream(self.device))
             ev0 = torch.cuda.Event()
             ev0.record(main)
-            self.stream.wait_event(ev0)
-        plan = make(self.stream)
+            st.wait_event(ev0)
+        plan = make(st)
         if pair_with is not None:
-            pair_with.prepare_lookahead(plan, stream=self.stream)
+            if pair_with._ready is not None and pair_with._ready[1] is not st:      # (built on the other side stream)
+                st.wait_event(pair_with._ready[0])
+            pair_with.prepare_lookahead(plan, stream=st)
         ev = torch.cuda.Event()
-        ev.record(self.stream)
-        plan._ready = (ev, self.stream)
+        ev.record(st)
+        plan._ready = (ev, st)
         return plan
 
 
