@@ -311,6 +311,7 @@ def main():
         bt = setup.batches
         t0 = step_no[0]
         D = max(2, int(model.plan_prefetch_depth))
+        model.plan_streams().wait_current()
         q = [model.plan(*bt[t0 % nbt], defer_readback=True)] + [model.plan_async(*bt[(t0 + k) % nbt]) for k in range(1, D)]
         for _ in range(n):       # D plans in hand: this batch's, the next one's (named to the step), the ones being built
             s = step_no[0]

@@ -131,6 +131,7 @@ int main(int argc, char** argv) {
   VFM_STRUCT_INIT(idx);
   idx.occ_ptr = d_ptr; idx.occ_rows = d_rows;
   idx.status = d_counts + 5;                                          // the kernels count clamped index entries here (zeroed by the build)
+  idx.heavy_list = L; idx.heavy_threshold = L;                       // what the lists were cut with (small tables: the one-launch backward re-derives the items)
   if (counts[1] > 0) {                                                // lists longer than L: work items + scratch records
     idx.heavy_ids = d_hid; idx.heavy_items = d_items; idx.n_heavy = counts[1]; idx.n_items = counts[2];
     idx.max_items = counts[4];

@@ -17,27 +17,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
-# gpurun merges every call's output into gpurun_out/: keep only the newest process' files of each pass
-for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq"):
-    files = glob.glob(os.path.join(src, sub, "**", "*_agent_info.csv"), recursive=True)
-    if len(files) > 1:
-        newest = max(files, key=os.path.getmtime)
-        keep = os.path.basename(newest).split("_")[0]
-        for f in glob.glob(os.path.join(os.path.dirname(newest), "*.csv")):
-            if not os.path.basename(f).startswith(keep + "_"):
-                os.remove(f)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
-rows = list(csv.reader(open(stats)))
+if os.path.exists(os.path.join(src, "summary.json")) and not os.path.isdir(os.path.join(src, "trace")):
+    # summarised on the GPU box by tools/profile_round.sh (tools/pmc_summary.py there); the per-dispatch CSVs stayed behind
+    rows = list(csv.reader(open(os.path.join(src, "kernel_stats.csv"))))
+    shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{tag}_pmc_summary.json"))
+    shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, f"{tag}_pmc_summary.txt"))
+else:
+    # raw passes present (KEEP_RAW=1).  gpurun merges every call's output into gpurun_out/: keep only the newest process' files
+    for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq"):
+        files = glob.glob(os.path.join(src, sub, "**", "*_agent_info.csv"), recursive=True)
+        if len(files) > 1:
+            newest = max(files, key=os.path.getmtime)
+            keep = os.path.basename(newest).split("_")[0]
+            for f in glob.glob(os.path.join(os.path.dirname(newest), "*.csv")):
+                if not os.path.basename(f).startswith(keep + "_"):
+                    os.remove(f)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.reader(open(stats)))
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--json",
+                          os.path.join(dst, f"{tag}_pmc_summary.json"), os.path.join(src, "trace"), os.path.join(src, "pmc_fetch"),
+                          os.path.join(src, "pmc_write"), os.path.join(src, "pmc_sq")], capture_output=True, text=True, check=True).stdout
+    open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(txt)
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
     w = csv.writer(fh, quoting=csv.QUOTE_ALL)
     w.writerow(rows[0])
     for r in rows[1:]:
         if "vfm::" in r[0]:
             w.writerow(r)
-txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--json",
-                      os.path.join(dst, f"{tag}_pmc_summary.json"), os.path.join(src, "trace"), os.path.join(src, "pmc_fetch"),
-                      os.path.join(src, "pmc_write"), os.path.join(src, "pmc_sq")], capture_output=True, text=True, check=True).stdout
-open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w").write(txt)
 summ = json.load(open(os.path.join(dst, f"{tag}_pmc_summary.json")))
 traffic = {}
 for k, v in summ.items():
@@ -65,6 +71,9 @@ else:
     for ext in ("_kernel_stats.csv", "_pmc_summary.txt", "_pmc_summary.json"):
         os.replace(os.path.join(dst, tag + ext), os.path.join(dst, f"{tag[:3]}_{point}{ext}"))
     tag = f"{tag[:3]}_{point}"
+line = os.path.join(src, "trace.json")             # the bench line of the kernel-trace pass itself (its alg_bytes belong to these kernels)
+if os.path.exists(line) and os.path.getsize(line) > 0:
+    shutil.copy(line, os.path.join(dst, f"{tag}_profiled_line.json"))
 if len(sys.argv) > 2:
     shutil.copy(sys.argv[2], os.path.join(dst, f"{tag}_bench.json"))
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag) or f == "latest_traffic.json"))

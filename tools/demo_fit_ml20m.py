@@ -30,7 +30,7 @@ if os.environ.get("USER_ORDER"):     # USER_ORDER=1: the TRAINING rows in the da
 ntr = int(0.8 * n)
 torch.manual_seed(42)
 m = VFM(N, M, d, device=dev, rng_seed=1)
-for kv in os.environ.get("VFM_SET", "").split(","):        # e.g. VFM_SET=replay=False,pipeline_min_touch=0 (A/B of the step-form rules)
+for kv in os.environ.get("VFM_SET", "").split(","):        # e.g. VFM_SET=pipeline=False,pipeline_min_touch=0 (A/B of the step-form rules)
     if "=" in kv:
         key, val = kv.split("=")
         setattr(m, key, {"True": True, "False": False}.get(val, float(val) if val.replace(".", "").isdigit() else val))

@@ -16,4 +16,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py $ARGS --no-events > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 python3 $R/tools/pmc_summary.py --json $OUT/summary.json $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > $OUT/summary.txt
+cp $(find $OUT/trace -name '*kernel_stats.csv' | tail -1) $OUT/kernel_stats.csv
+# the per-dispatch CSVs of four passes are 10-40 MB per point (gpurun merges at most 64 MiB per call): summarised above,
+# dropped here unless KEEP_RAW=1
+[ "${KEEP_RAW:-0}" = "1" ] || rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
 cat $OUT/summary.txt | head -60

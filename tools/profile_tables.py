@@ -29,8 +29,9 @@ def bench_table(tag):
         rows.append(f"| `settle` ({j['settle']['untimed_steps_before_warmup']} untimed steps before the warm-up; the same warm-up + {j['settle']['cold_steps']} steps timed first, without them) | cold: {j['settle']['cold_ms_per_step']} ms/step |")
     if j.get("sustained"):
         rows.append(f"| `sustained` ({j['sustained']['steps']} eager steps, no events) | {j['sustained']['triples_per_s'] / 1e6:.1f} M triples/s, {j['sustained']['ms_per_step']} ms/step |")
-    if j.get("replayed"):
-        rows.append(f"| `replayed` ({j['replayed']['steps']} steps as {j['replayed']['graphs']} replayed HIP graphs) | {j['replayed']['triples_per_s'] / 1e6:.1f} M triples/s, {j['replayed']['ms_per_step']} ms/step (host {j['replayed']['host_enqueue_ms_per_step']} ms/step) |")
+    if j.get("streamed"):
+        t = j["streamed"]
+        rows.append(f"| `streamed` ({t['steps']} steps, every plan built inside the timed region, {t.get('prefetch_depth', 3)} in hand) | {t['triples_per_s'] / 1e6:.1f} M triples/s, **{t['ms_per_step']} ms/step** (host {t['host_enqueue_ms_per_step']} ms/step; one build alone {t.get('plan_build_gpu_us_alone')} µs) |")
     for name in ("fwd", "bwd_adam"):
         if name in k:
             v = k[name]
@@ -51,13 +52,13 @@ def bench_table(tag):
 
 
 def points_table(tag):
-    rows = ["| point | ms / step | triples/s | kernels µs (HIP events) | sustained / replayed ms |", "|---|---|---|---|---|"]
+    rows = ["| point | ms / step | triples/s | kernels µs (HIP events) | sustained / streamed ms |", "|---|---|---|---|---|"]
     for j in load_lines(os.path.join(P, f"{tag}_points.jsonl")):
         if j.get("error"):
             rows.append(f"| {j['point']} | error | | | |")
             continue
         ks = ", ".join(f"{k} {v['avg_us']}" for k, v in j["kernels"].items())
-        s, r = (j.get("sustained") or {}).get("ms_per_step"), (j.get("replayed") or {}).get("ms_per_step")
+        s, r = (j.get("sustained") or {}).get("ms_per_step"), j.get("ms_per_step_streamed")
         rows.append(f"| {j['point']} | {j['ms_per_step']} | {j['value'] / 1e6:.1f} M | {ks} | {s if s else '—'} / {r if r else '—'} |")
     return "\n".join(rows)
 
@@ -74,6 +75,36 @@ def kernel_table(tag):
         us = v["avg_us"].get("trace") or list(v["avg_us"].values())[0]
         rows.append(f"| `{k}` | {v['launches']} | {us} | {v['hbm_bytes_per_launch'] / 1e6:.1f} MB | {v['hbm_bytes_per_launch'] / us / 1e3:.0f} | {v.get('l2_hit_rate')} | "
                     f"{c.get('SQ_INSTS_VALU', 0) / 1e6:.1f} M | {c.get('SQ_WAIT_ANY', 0) / max(c.get('SQ_WAVE_CYCLES', 1), 1):.2f} |")
+    return "\n".join(rows)
+
+
+def profiled_points_table(tag):
+    """Per profiled point (tools/final_measure.sh: the default line, cfg2, cfg5, B = 1,048,576, data-file order, cfg5 row-list
+    form): the step's two kernels with SURVEY 8(d)'s / the bench line's algorithmic bytes / rocprofv3's average duration /
+    8 TB/s, and the fabric bytes of the PMC passes / the algorithmic ones."""
+    rows = ["| point | kernel | launches | avg µs (rocprofv3 trace pass) | algorithmic MB | → frac of 8 TB/s | fabric MB (PMC) | PMC ÷ algorithmic | L2 hit |",
+            "|---|---|---|---|---|---|---|---|---|"]
+    for point in ("", "cfg2", "cfg5", "b1m", "fileorder", "cfg5list"):
+        stem = f"{tag}_{point}" if point else tag
+        sj, lj = os.path.join(P, f"{stem}_pmc_summary.json"), os.path.join(P, f"{stem}_profiled_line.json")
+        if not (os.path.exists(sj) and os.path.exists(lj)):
+            continue
+        summ, line = json.load(open(sj)), load_lines(lj)[0]
+        label = point or "cfg3 (default line)"
+        for name, pref in (("fwd", "k_fwd"), ("bwd_adam", "k_bwd"), ("catchup", "k_adam_catchup")):
+            if name not in line["kernels"]:
+                continue
+            alg = line["kernels"][name]["alg_bytes"]
+            cands = [(k, v) for k, v in summ.items() if k.startswith(pref) and "hbm_bytes_per_launch" in v and v.get("launches", 0) >= 20]
+            if not cands:
+                continue
+            k, v = max(cands, key=lambda kv: kv[1]["launches"])
+            us = v["avg_us"].get("trace") or list(v["avg_us"].values())[0]
+            rows.append(f"| {label} | `{k}` | {v['launches']} | {us} | {alg / 1e6:.1f} | **{alg / us / 1e3 / 8000:.3f}** | "
+                        f"{v['hbm_bytes_per_launch'] / 1e6:.1f} | {v['hbm_bytes_per_launch'] / alg:.2f} | {v.get('l2_hit_rate')} |")
+        r = line["roofline"]
+        rows.append(f"| {label} | SURVEY 8(d): forward {r.get('bytes_fwd_8d', 0) / 1e6:.1f} MB, region K {r.get('bytes_K_8d', 0) / 1e6:.1f} MB | | "
+                    f"step {line['ms_per_step']} ms under the profiler | | `frac_fwd_8d` {r.get('frac_fwd_8d')}, `frac_K_8d` {r.get('frac_K_8d')} | | | |")
     return "\n".join(rows)
 
 
@@ -113,8 +144,16 @@ def stats_rows(tag, names):
 
 def main():
     tag = sys.argv[1]
-    parts = {"bench": bench_table(tag), "kernels": kernel_table(tag), "points": points_table(tag), "gather": gather_table(tag),
-             "stats": stats_rows(tag, ("k_fwd", "k_bwd", "k_adam", "k_finalize"))}
+    makers = {"bench": lambda: bench_table(tag), "kernels": lambda: kernel_table(tag), "points": lambda: points_table(tag),
+              "gather": lambda: gather_table(tag),
+              "stats": lambda: stats_rows(tag, ("k_fwd", "k_bwd", "k_adam", "k_finalize", "k_index", "k_radix", "k_heavy")),
+              "profiled": lambda: profiled_points_table(tag)}
+    parts = {}
+    for name, make in makers.items():
+        try:
+            parts[name] = make()
+        except FileNotFoundError as e:           # (a round that has not produced that file yet)
+            print(f"[profile_tables] {name}: {e.filename} missing, table skipped", file=sys.stderr)
     if "--write" in sys.argv:
         path = os.path.join(P, "README.md")
         txt = open(path).read()

@@ -534,12 +534,16 @@ class VFM(nn.Module):
         the side stream too.  fork=False: x and y are long-lived (nothing on the current stream is still writing them), so the
         build need not wait for the steps already enqueued there.  Single rank (a multi-rank plan sums W over the ranks: a
         collective, built in line)."""
-        if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != self.device:
-            self._plan_stream = ops.PlanStream(self.device)
         # (the pair's row list only where the caller asks for it: the streamed loop lets the look-ahead kernel classify the
         #  table rows itself -- +4 us of kernel time against 35 us of host time and three more launches per step)
         pair = pair_with if (pair_with is not None and self.lookahead and self.lookahead_list and self.n_samples == 1) else None
-        return self._plan_stream.build(lambda st: self.plan(x, y, defer_readback=True, stream=st), pair_with=pair, fork=fork)
+        return self.plan_streams().build(lambda st: self.plan(x, y, defer_readback=True, stream=st), pair_with=pair, fork=fork)
+
+    def plan_streams(self) -> "ops.PlanStream":
+        """The side streams of this model's plan builds (made on first use)."""
+        if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != self.device:
+            self._plan_stream = ops.PlanStream(self.device)
+        return self._plan_stream
 
     def train_step(self, plan: ops.BatchPlan, lr: Optional[float] = None, eps=None, out_pred=None,
                    process_group=None, adam: bool = True, mark=None, fused: Optional[bool] = None,
@@ -906,6 +910,7 @@ class VFM(nn.Module):
         batch = lambda t: (Xd[spans[t % nb][0]:spans[t % nb][1]], yd[spans[t % nb][0]:spans[t % nb][1]], False)
         # `plan_prefetch_depth` plans in hand: this batch's, the next one's (named to the step), and the ones being built
         D = max(2, int(self.plan_prefetch_depth))
+        self.plan_streams().wait_current()       # (Xd / yd were put together on this stream: the fork=False builds come after that)
         q = [self.plan(*batch(0)[:2], defer_readback=True)] + [self.plan_async(*batch(k)[:2]) for k in range(1, min(D, total))]
         for t in range(total):
             epoch, i = divmod(t, nb)

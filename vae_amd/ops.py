@@ -490,6 +490,15 @@ class PlanStream:
     def stream(self):
         return self.streams[self._turn % len(self.streams)]
 
+    def wait_current(self):
+        """Every side stream waits (an event, no host sync) for what is enqueued so far on the current stream: call once
+        after producing long-lived inputs (a training set moved to the device, sorted) and before a run of `fork=False`
+        builds that read them."""
+        ev = torch.cuda.Event()
+        ev.record(_stream_obj(self.device, _lib.raw_stream(self.device)))
+        for st in self.streams:
+            st.wait_event(ev)
+
     def build(self, make, pair_with: Optional[BatchPlan] = None, fork: bool = True) -> BatchPlan:
         """`make(stream)` -> BatchPlan whose build is enqueued on `stream` (BatchPlan(..., defer_readback=True, stream=stream));
         `pair_with`: also enqueue the look-ahead row list of (pair_with, new plan) there.  fork: the side stream first waits
