@@ -84,8 +84,13 @@ def sweep(n, seed, verbose=True):
         mags = {"g_alpha": scale * float((0.5 * (y[None, :] - pr_) ** 2 + 0.5 / a_).sum()) if output == "reg" else 1.0,
                 "g_global_bias_mean": sum_abs_g + abs(float(P["global_bias_mean"][0])),
                 "g_global_bias_scale": float(np.abs(eg).max()) * sum_abs_g + sg0 + 1.0 / sg0}
-        errs["g_sc"] = max(abs(g_sc[i].item() - r[k][0]) / (5e-4 * abs(r[k][0]) + 1e-4 * mags[k])
-                           for i, k in enumerate(("g_alpha", "g_global_bias_mean", "g_global_bias_scale")))
+        per_sc = {k: abs(g_sc[i].item() - r[k][0]) / (5e-4 * abs(r[k][0]) + 1e-4 * mags[k])
+                  for i, k in enumerate(("g_alpha", "g_global_bias_mean", "g_global_bias_scale"))}
+        errs["g_sc"] = max(per_sc.values())
+        if os.environ.get("FUZZ_TRACK") and errs["g_sc"] > worst["g_sc"]:       # which scalar, which configuration
+            print("   new worst g_sc", {k: float("%.3g" % v) for k, v in per_sc.items()}, dict(it=it, F=F, d=d, B=B, S=S, link=link, output=output),
+                  {k: (float("%.6g" % g_sc[i].item()), float("%.6g" % r[k][0]), float("%.3g" % mags[k]))
+                   for i, k in enumerate(("g_alpha", "g_global_bias_mean", "g_global_bias_scale"))}, flush=True)
         tol = {k: 2e-4 for k in errs}
         tol["g_sc"] = 1.0          # (already in units of its bound)
         if F == 1:
@@ -118,6 +123,20 @@ def sweep(n, seed, verbose=True):
             ops.elbo_backward_adam(plan, st2, e2, b2, s2, inv_occ, mv[0], mv[1], 0.01, 1, scaled_moments=scaled,
                                    loss_out=torch.zeros(3, device=dev))       # (also reduces the forward's slots)
             key = "adam_scaled" if scaled else "adam_plain"
+            if os.environ.get("FUZZ_SMALL_AB"):       # the one-launch small-table backward against the three-launch path, bit for bit
+                os.environ["VFM_BWD_SMALL"] = "0"
+                e3, b3, s3 = ent.clone(), bia.clone(), scal.clone()
+                mv3 = [(torch.zeros_like(e3), torch.zeros_like(b3), torch.zeros(3, device=dev)) for _ in range(2)]
+                st3 = ops.elbo_forward(plan, e3, b3, s3, inv_occ, seed=seed, step=step)
+                ops.elbo_backward_adam(plan, st3, e3, b3, s3, inv_occ, mv3[0], mv3[1], 0.01, 1, scaled_moments=scaled,
+                                       loss_out=torch.zeros(3, device=dev))
+                del os.environ["VFM_BWD_SMALL"]
+                if not (torch.equal(e2, e3) and torch.equal(b2, b3) and torch.equal(s2, s3) and torch.equal(mv[0][0], mv3[0][0])):
+                    rows = (e2 != e3).any(1).nonzero().reshape(-1).tolist()
+                    cnts = [int((x == r_).sum()) for r_ in rows[:8]]
+                    print("   SMALL != THREE-LAUNCH", dict(it=it, F=F, d=d, B=B, S=S, link=link, scaled=scaled, L=plan.heavy_list,
+                                                         thr=getattr(plan, "heavy_threshold", None), max_items=plan.heavy_max_items),
+                          "rows", rows[:8], "their counts", cnts, "bias differs", bool((b2 != b3).any()), flush=True)
             sc_ok = slice(1, 3) if output == "class" else slice(0, 3)       # alpha: no gradient under Bernoulli
             # Adam's first step is -lr * sign(g): a gradient entry that is pure rounding noise (|g| ~ 1e-9 of the row's
             # scale) may land on either side, so the check is the FRACTION of entries that differ, not the maximum

@@ -663,6 +663,9 @@ def test_streamed_plans_give_the_resident_plans_trajectory(shape):
     ((60, 40), 8, 4000, dict(link="softplus", output="class")),        # d = 8 on the 4-lane shape, softplus link, Bernoulli
     ((300, 200), 64, 500, dict()),                                     # mostly short lists (k_bwd's own walk), some rows not in the batch
     ((943, 1682), 20, 8000, dict(scaled_moments=False)),               # plain moments
+    ((60, 40), 256, 4000, dict()),                                     # 64 lanes per entity: k_heavy_sum has FOUR lane groups, fewer than
+                                                                       #  VFM_HEAVY_DIRECT -- 5..8 items are k_bwd's in-order sum (fuzz-found)
+    ((60, 40), 192, 40000, dict()),                                    # ... and ~45 items each: the four partial sums
 ])
 def test_small_table_step_is_bitwise_the_three_launch_step(sizes, d, B, kw, monkeypatch):
     """k_bwd_small (one launch, a wave per table row, the work items re-derived from the lists) against k_heavy + k_heavy_sum +

@@ -28,14 +28,28 @@ host = []
 ru0 = resource.getrusage(resource.RUSAGE_SELF)
 print("loadavg", open("/proc/loadavg").read().strip(), "| pressure cpu:", open("/proc/pressure/cpu").read().split("\n")[0] if os.path.exists("/proc/pressure/cpu") else "n/a", flush=True)
 t_region = time.perf_counter()
+evs = []
 for s in range(steps):
     t0 = time.perf_counter()
-    model.train_step(plans[s % NB], next_plan=plans[(s + 1) % NB])
+    mark = None
+    if s % 5 == 0:                 # HIP events on every 5th step, as bench.py's commanded region records them
+        ev = {}
+        evs.append(ev)
+
+        def mark(name, ev=ev):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[name] = e
+    model.train_step(plans[s % NB], next_plan=plans[(s + 1) % NB], mark=mark)
     host.append(time.perf_counter() - t0)
     if (s + 1) % 250 == 0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         h = host[-250:]
+        bw = [e["fwd"].elapsed_time(e["bwd_adam"]) * 1e3 for e in evs if "fwd" in e and "bwd_adam" in e]
+        fw = [e["start"].elapsed_time(e["fwd"]) * 1e3 for e in evs if "fwd" in e and "start" in e]
+        evs.clear()
+        print(f"[events: start->fwd {sum(fw) / max(len(fw), 1):6.1f} us, fwd->bwd mean {sum(bw) / max(len(bw), 1):6.1f} max {max(bw) if bw else 0:7.1f} us] ", end="")
         print(f"steps {s - 249:5d}..{s:5d}: {(t1 - t_region) / 250 * 1e3:.4f} ms/step  host mean {sum(h) / 250 * 1e6:6.1f} us, max {max(h) * 1e6:8.1f} us, "
               f"> 0.5 ms: {sum(1 for v in h if v > 5e-4)}", end="")
         ru = resource.getrusage(resource.RUSAGE_SELF)

@@ -17,7 +17,7 @@
 //   an item:          A = fma(g_r, sumz_r, A) over its occurrences in list order, gs += g_r              (k_heavy)
 //   a heavy entity:   P_g = items g, g + GPB, g + 2 GPB ... added in that order, GPB = 256 / LPE (k_heavy_sum's lane
 //                     groups), then P_0 + P_1 + ... in order; with at most VFM_HEAVY_DIRECT items k_bwd adds the items in
-//                     order itself -- the same sum, since every P_g then holds at most one item and 0 + x = x
+//                     order itself -- here: VFM_HEAVY_DIRECT partial sums of one item each (0 + x = x)
 //   a short list:     k_bwd's own walk: A = fma(g1, s1, fma(g0, s0, A)) two occurrences at a time, gs += g0 + g1
 // -- and the epilogue (eps regeneration, KL part, link, Adam) is k_bwd's, expression for expression (the unit is compiled
 // with -ffp-contract=on: fusion follows the source expression, so equal source gives equal bits).  tests/test_gpu_model.py
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
   __shared__ float sh_cs[VFM_MAX_FIELDS];
   __shared__ int64_t sh_hi[VFM_MAX_FIELDS];
   __shared__ double sh_fin[7][BLOCK / 64];
-  __shared__ __attribute__((aligned(16))) float sh_P[WPB][GPBH][4 * LPE + 4];     // per wave: P_g = (A[0 .. 4 LPE) | gs, -, -, -)
+  constexpr int NPMAX = GPBH > VFM_HEAVY_DIRECT ? GPBH : VFM_HEAVY_DIRECT;
+  __shared__ __attribute__((aligned(16))) float sh_P[WPB][NPMAX][4 * LPE + 4];     // per wave: P_g = (A[0 .. 4 LPE) | gs, -, -, -)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lig = lane % LPE, lg = lane / LPE;
   const int d = a.d;
@@ -128,12 +129,15 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
       // heavy: the items of the list, L occurrences each, in list order.  Lane group lg forms the partial sums P_g of
       // g = lg, lg + LGW, ... (g < GPBH): items g, g + GPBH, ... -- each item a sequential fma chain as k_heavy forms it
       const int n_items = (cnt + L - 1) / L;
-      for (int g = lg; g < GPBH; g += LGW) {
+      // partial sums: k_heavy_sum's lane groups (items g, g + GPBH, ...) -- or, with at most VFM_HEAVY_DIRECT items, one per
+      // item, which is k_bwd's own in-order sum of the item records (with 64 lanes per entity GPBH is 4: fewer than that)
+      const int NP = n_items <= VFM_HEAVY_DIRECT ? VFM_HEAVY_DIRECT : GPBH;
+      for (int g = lg; g < NP; g += LGW) {
         Chunk<VEC> Pg;
 #pragma unroll
         for (int t = 0; t < VEC; ++t) Pg.v[t] = 0.f;
         float Pgs = 0.f;
-        for (int it = g; it < n_items; it += GPBH) {
+        for (int it = g; it < n_items; it += NP) {
           const int ib = beg + it * L, ie = (ib + L < end) ? ib + L : end;
           Chunk<VEC> Ai;
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_small(const KArgs a, const BwdArg
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // (one wave: its LDS writes are ordered before the reads below)
       __builtin_amdgcn_wave_barrier();
       if (lg == 0) {                                 // P_0 + P_1 + ... in order
-        for (int g = 0; g < GPBH; ++g) {
+        for (int g = 0; g < NP; ++g) {
           const float4 t4 = *reinterpret_cast<const float4*>(&P[g][4 * lig]);
           A.v[0] += t4.x; A.v[1] += t4.y; A.v[2] += t4.z; A.v[3] += t4.w;
           gs += P[g][4 * LPE];
