@@ -320,6 +320,19 @@ def main():
             q.pop(0)
             q.append(model.prefetched)
 
+    # HIP timing events of the commanded region are CREATED before it (measure() fills the pool and records each once: torch
+    # makes the hipEvent at the first record).  Creating them inside cost the first process of a session ONE stall of 15-20 ms
+    # around the 80th event -- the runtime growing its pool of profiling signals -- i.e. 0.222-0.256 instead of 0.191-0.195 ms
+    # per step over 500 steps; later processes on the box did not show it (tools/first_run_ab.sh, VFM_BENCH_DUMP_EVENTS).
+    event_pool = []
+
+    def fill_event_pool(n):
+        while len(event_pool) < n:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            event_pool.append(e)
+        torch.cuda.synchronize()
+
     def run(plans, n, events, streamed=None):
         if streamed is not None:
             return run_streamed(streamed, n)
@@ -332,7 +345,7 @@ def main():
                 events.append(ev)
 
                 def mark(name, ev=ev):
-                    e = torch.cuda.Event(enable_timing=True)
+                    e = event_pool.pop() if event_pool else torch.cuda.Event(enable_timing=True)
                     e.record()
                     ev[name] = e
             model.train_step(plans[s % nbt], process_group=pg, mark=mark, fused=not args.unfused, eps=eps_tables,
@@ -381,6 +394,8 @@ def main():
                 if max_over_ranks(time.perf_counter() - t0) >= args.settle_max_s:     # (every rank takes the same decision)
                     break
             cold["settle_steps"] = done
+        if with_events:
+            fill_event_pool(6 * (steps // max(1, args.event_every) + 2))
         run(plans, warmup, None, stm)
         barrier()
         events = [] if with_events else None
@@ -634,10 +649,17 @@ def kernel_report(events, model, args, world, B, d, F, U, lazy_kind=None):
     roof = None
     if events:
         acc = {}                                  # marks in launch order: start, fwd, finalize, ...
+        dump = os.environ.get("VFM_BENCH_DUMP_EVENTS")       # debug: every sampled step's durations, one line each
+        lines = []
         for ev in events:
             order = list(ev.keys())
+            row = {}
             for a_, b_ in zip(order[:-1], order[1:]):
-                acc[b_] = acc.get(b_, 0.0) + ev[a_].elapsed_time(ev[b_])
+                row[b_] = ev[a_].elapsed_time(ev[b_])
+                acc[b_] = acc.get(b_, 0.0) + row[b_]
+            lines.append(" ".join(f"{k} {v * 1e3:.1f}" for k, v in row.items()))
+        if dump:
+            open(dump, "w").write("\n".join(lines) + "\n")
         n_params = model._n_flat
         # ALGORITHMIC bytes per launch (fp32 params, ids as given, eps in-kernel):
         idb = 4 if args.id32 else 8
