@@ -14,11 +14,17 @@ CSRC = os.path.join(ROOT, "vae_amd", "csrc")
 # (translation unit, extra flags, substring of the demangled instance, what it is)
 WANT = [
     ("vfm_fwd2.hip", [], "k_fwd2<16, true, 0, 1, true, 0, true>", "cfg3 forward (d = 128, Philox, training, int64 ids, |.| link, packed records)"),
+    ("vfm_fwd2.hip", [], "k_fwd2<4, false, 0, 1, true, 0, true>", "cfg2 forward (d = 20)"),
     ("vfm_fwdg.hip", [], "k_fwdg<32, true, 0, 1, true, 0, true>", "cfg5 forward (F = 32, d = 256: fields split over lane groups)"),
-    ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg3 fused backward + dense Adam, look-ahead form"),
-    ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<64, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg5 fused backward + dense Adam, look-ahead form"),
-    ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, true, true>", "pipelined step's backward in the look-ahead form (data-file-order batches; the rows exchange)"),
-    ("vfm_bwd.hip", ["-ffp-contract=on"], "k_bwd<32, 1, 4, 0, 1, 2, 0, false, false, false>", "multi-rank apply stage (epilogue + Adam from the summed statistics)"),
+    ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg3 fused backward + dense Adam, look-ahead form"),
+    ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<64, 1, 4, 0, 1, 0, 0, false, false, true>", "cfg5 fused backward + dense Adam, look-ahead form"),
+    ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, true, true>", "pipelined step's backward in the look-ahead form (data-file-order batches; the rows exchange)"),
+    ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd_small<8, 0>", "cfg2 one-launch backward + dense Adam (a wave per table row; the 48 bytes of scratch are the epilogue's eps chunk select, once per row)"),
+    ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<32, 1, 4, 0, 1, 2, 0, false, false, false>", "multi-rank apply stage (epilogue + Adam from the summed statistics)"),
+    ("vfm_index.hip", [], "k_index_keys", "index build: ids -> keys, first digit counts, batch normalisers"),
+    ("vfm_index.hip", [], "k_radix_scatter<true>", "index build: last radix pass (writes occ_rows / occ_other)"),
+    ("vfm_index.hip", [], "k_index_count<true>", "index build: occ_ptr by LDS-staged lower bounds + per-chunk counts (256-thread workgroups)"),
+    ("vfm_index.hip", [], "k_index_write<false>", "index build: heavy lists, work items, touched list, totals, W"),
 ]
 CLASSES = ["global_load_dwordx4", "global_load_dwordx2", "global_load_dword", "global_store_dwordx4", "global_store_dwordx2",
            "global_store_dword", "ds_read_b128", "ds_write_b128", "ds_read", "ds_write", "s_barrier", "v_pk_fma_f32", "v_pk_mul_f32",
