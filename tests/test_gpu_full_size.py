@@ -305,3 +305,72 @@ def test_cfg4_compact_statistics_exchange_equals_the_dense_one(monkeypatch):
         del models, out
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][2] < 0.7 * outs[1][2]
+
+
+# --------------------------------------------------------------------------------------- cfg3 / cfg2 at their full single-GPU sizes
+def test_cfg3_plans_built_inside_the_loop_follow_the_resident_plans_run():
+    """BASELINE configs[2] at its real size (B = 100,000, T = 165,237, d = 128): a loop that keeps NO plan -- every batch's
+    inverted index + normalisers built a few batches ahead on the side streams (train_step(prefetch=), VFM_FLAG_SHARE_GPU
+    grids, the scan-form look-ahead step) -- against the loop with resident plans (row-list look-ahead step, full grids).
+    Every table row's update is the same arithmetic in both; what differs is the number of fp64 loss slots (15/16 of the
+    workgroups), i.e. the ORDER of the sums behind the loss and the three scalar gradients: losses to 1e-6, tables to 1e-5
+    of their largest entry after 24 steps over 6 batches (an id out of place in an index would be O(1) in its rows)."""
+    cfg = CFG4
+    nb, steps = 6, 24
+    X, y = _data(cfg, nb * cfg["B"])
+    from vae_amd.model import sort_rows_within_batches
+    X, y = sort_rows_within_batches(X, y, cfg["B"])
+    occ = _occ(cfg, X)
+    bt = [(X[i * cfg["B"]:(i + 1) * cfg["B"]], y[i * cfg["B"]:(i + 1) * cfg["B"]]) for i in range(nb)]
+    runs = []
+    for streamed in (False, True):
+        m = _model(cfg)
+        m.set_training_data(X, nb_train=cfg["nb_train"], nb_occ=occ)
+        losses = []
+        if not streamed:
+            plans = [m.plan(*b) for b in bt]
+            for s in range(steps):
+                l3, _ = m.train_step(plans[s % nb], lr=0.01, next_plan=plans[(s + 1) % nb])
+                losses.append(l3.clone())
+        else:
+            D = int(m.plan_prefetch_depth)
+            m.plan_streams().wait_current()
+            q = [m.plan(*bt[0], defer_readback=True)] + [m.plan_async(*bt[k % nb]) for k in range(1, D)]
+            for s in range(steps):
+                l3, _ = m.train_step(q[0], lr=0.01, next_plan=q[1], prefetch=bt[(s + D) % nb] + (False,))
+                losses.append(l3.clone())
+                q.pop(0)
+                q.append(m.prefetched)
+            for p in q:
+                p.check_status()
+        m.sync_lazy()
+        runs.append((m, torch.stack(losses)))
+    (a, la), (b, lb) = runs
+    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
+    assert float(((la - lb).abs() / la.abs().clamp_min(1e-30)).max()) < 1e-6
+    for name in ("_flat", "_adam_m", "_adam_v"):
+        for pa, pb in zip(a._views(getattr(a, name)), b._views(getattr(b, name))):
+            assert float((pa - pb).abs().max()) <= 1e-5 * float(pb.abs().max()) + 1e-30, name
+
+
+def test_cfg2_small_table_step_at_full_size_is_bitwise_the_three_launch_step(monkeypatch):
+    """BASELINE configs[1] at its real size -- 943 x 1,682 entities, d = 20, ONE batch of 80,000 rows (vfm-torch.py:31-57,77):
+    12 epochs through the one-launch backward (k_bwd_small: a wave per table row) and through forward + k_heavy + k_heavy_sum +
+    k_bwd (VFM_BWD_SMALL=0): losses, parameters and both moments bit for bit."""
+    cfg = dict(sizes=[943, 1682], d=20, B=80000, output="reg", nb_train=80000)
+    X, y = _data(cfg, cfg["B"], seed=5)
+    occ = _occ(cfg, X)
+    runs = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("VFM_BWD_SMALL", small)
+        m = _model(cfg)
+        m.set_training_data(X, nb_train=cfg["nb_train"], nb_occ=occ)
+        plan = m.plan(X, y)
+        losses = [m.train_step(plan, lr=0.02, next_plan=plan)[0].clone() for _ in range(12)]
+        m.sync_lazy()
+        plan.check_status()
+        runs.append((m, torch.stack(losses)))
+    (a, la), (b, lb) = runs
+    assert torch.equal(la, lb)
+    for name in ("_flat", "_adam_m", "_adam_v"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name

@@ -15,6 +15,7 @@ once-per-dataset helpers and the tests of the raw ABI use ctypes on the same lib
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional
@@ -208,7 +209,9 @@ class BatchPlan:
         lib = _lib.load()
         want_w = inv_occ is not None and y is not None
         if want_w:
-            self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
+            # (a build on a side stream: its buffers come from THAT stream's pool -- see _build_index_locked)
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
         if build_index and y is not None:
             # the batch normalisers W (vfm-torch.py:305-306) come out of the index build's own launches (the ids are read once)
             self.build_index(validate=validate, defer=defer_readback, inv_occ=inv_occ if want_w else None, stream=stream)
@@ -256,12 +259,15 @@ class BatchPlan:
         for v in sizes:
             offs.append(o)
             o += (v + 3) & ~3
-        arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev)
+        # A build on a side stream allocates from THAT stream's pool.  (From the current stream's pool a block may be one a
+        # dropped plan has just returned -- free for the current stream, whose queued steps still read it, but the side stream
+        # would start overwriting it at once: a build enqueued with fork=False is not ordered behind those steps.  Found by
+        # tests/test_gpu_full_size.py::test_cfg3_plans_built_inside_the_loop_follow_the_resident_plans_run: losses drifting
+        # from the 10th step on, equal with a device sync before every step.)  The consumer's stream is recorded when the plan
+        # is first used there (use_on_current), so the block is not handed out again under ITS queued work either.
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev)
         self._lay = (offs, sizes, cap_i)
-        if stream is not None:           # (allocated from the current stream's pool, used on `stream`)
-            arena.record_stream(stream)
-            if self.W is not None:
-                self.W.record_stream(stream)
         base = arena.data_ptr()
         P = [C.c_void_p(base + 4 * q) for q in offs]
         host = _pinned_ints(8)
@@ -382,6 +388,9 @@ class BatchPlan:
                 host, done, src = hit[2]
                 done.synchronize()               # (host-side: the list is complete -- whatever is enqueued from here on, on
                                                  #  any stream, comes after it)
+                cur = _stream_obj(self.x.device, _lib.raw_stream(self.x.device))
+                if src.cuda_stream != cur.cuda_stream:
+                    hit[1].record_stream(cur)    # (allocated on the build's stream, read on this one)
                 pairs[id(next_plan)] = (hit[0], hit[1][:int(host.item())], None)
             return pairs[id(next_plan)][1]
         self.prepare_lookahead(next_plan)
@@ -401,9 +410,8 @@ class BatchPlan:
                 q.build_index(defer=True, stream=stream)
         lib = _lib.load()
         raw = stream.cuda_stream if stream is not None else _lib.raw_stream(dev)
-        buf = torch.empty((min(T, (self.B + next_plan.B) * self.spec.F) or 1) + 4, dtype=torch.int32, device=dev)
-        if stream is not None:
-            buf.record_stream(stream)
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):     # (from the build stream's pool: see _build_index_locked)
+            buf = torch.empty((min(T, (self.B + next_plan.B) * self.spec.F) or 1) + 4, dtype=torch.int32, device=dev)
         rows, count = buf[:-4], buf[-4:]
         with _ENQUEUE_LOCK:
             ws = _index_workspace(int(lib.vfm_union_workspace_bytes(T)) // 4 + 4, dev, raw)
@@ -426,7 +434,11 @@ class BatchPlan:
         dev = self.x.device
         raw = _lib.raw_stream(dev)
         if raw != src.cuda_stream:
-            _stream_obj(dev, raw).wait_event(ev)
+            cur = _stream_obj(dev, raw)
+            cur.wait_event(ev)
+            for t in (self._arena, self.W):
+                if t is not None:
+                    t.record_stream(cur)      # (allocated on the build's stream, used on this one from here on)
         self._ready = None
 
     def check_status(self):
