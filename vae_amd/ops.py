@@ -112,7 +112,8 @@ def _index_workspace(n_int32: int, dev, stream: int) -> torch.Tensor:
     key = (dev.index, stream)
     t = _WS.get(key)
     if t is None or t.numel() < n_int32:
-        t = _WS[key] = torch.empty(n_int32, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(_stream_obj(dev, stream)):       # (from the pool of the stream that writes it)
+            t = _WS[key] = torch.empty(n_int32, dtype=torch.int32, device=dev)
     return t
 
 
