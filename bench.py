@@ -313,12 +313,18 @@ def main():
         D = max(2, int(model.plan_prefetch_depth))
         model.plan_streams().wait_current()
         q = [model.plan(*bt[t0 % nbt], defer_readback=True)] + [model.plan_async(*bt[(t0 + k) % nbt]) for k in range(1, D)]
-        for _ in range(n):       # D plans in hand: this batch's, the next one's (named to the step), the ones being built
+        trace = os.environ.get("VFM_BENCH_TRACE")      # debug: host time of every 50 steps of the streamed loop
+        tt = time.perf_counter()
+        for i in range(n):       # D plans in hand: this batch's, the next one's (named to the step), the ones being built
             s = step_no[0]
             step_no[0] += 1
             model.train_step(q[0], next_plan=q[1], fused=not args.unfused, prefetch=bt[(s + D) % nbt] + (False,))   # (resident data: no fork)
             q.pop(0)
             q.append(model.prefetched)
+            if trace and i % 50 == 49:
+                print(f"[trace] steps ..{s}: host {(time.perf_counter() - tt) / 50 * 1e3:.4f} ms/step, adam_t {model._adam_t}, "
+                      f"reserved {torch.cuda.memory_reserved() >> 20} MiB", file=sys.stderr, flush=True)
+                tt = time.perf_counter()
 
     # HIP timing events of the commanded region are CREATED before it (measure() fills the pool and records each once: torch
     # makes the hipEvent at the first record).  Creating them inside cost the first process of a session ONE stall of 15-20 ms

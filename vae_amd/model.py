@@ -134,6 +134,9 @@ class VFM(nn.Module):
         # is enqueued while step t runs.  The host reads a build's counts when the plan is first named to a step (as
         # `next_plan`): with four, that build was enqueued three steps earlier and the host never waits for it
         self.plan_prefetch_depth = int(__import__("os").environ.get("VFM_PLAN_DEPTH", "4"))
+        # ... and how many steps the host may queue ahead of the stream in such a loop (each holds its plan's buffers until the
+        # stream gets there; without a bound the host, which no longer waits for anything, runs hundreds of steps ahead)
+        self.step_lead = int(__import__("os").environ.get("VFM_STEP_LEAD", "16"))
         self._zrec = None                  # two record tables [T, 4 + d]
         self._zrec_for = None              # (plan, philox step, version of _flat) the first table was prepared for
         self.lazy_adam = "auto"            # (row-list form: used when no next batch is named; with one, the look-ahead
@@ -563,6 +566,16 @@ class VFM(nn.Module):
             try:
                 return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)
             finally:
+                # the host stays within `plan_prefetch_depth` steps of this stream: builds with fork=False do not wait for the
+                # steps in flight, so nothing else would stop the host from queueing hundreds of steps -- every one of them
+                # holding its plan's buffers until the stream gets there (measured: +1.1 MB of reserved memory per step and a
+                # device allocation -- a stall -- every other step: 0.33 instead of 0.23 ms per step)
+                dq = self.__dict__.setdefault("_steps_in_flight", [])
+                ev = torch.cuda.Event()
+                ev.record()
+                dq.append(ev)
+                if len(dq) > self.step_lead:
+                    dq.pop(0).synchronize()
                 pw = prefetch[3] if len(prefetch) > 3 else None
                 self.prefetched = self.plan_async(prefetch[0], prefetch[1], pair_with=pw, fork=prefetch[2] if len(prefetch) > 2 else True)
         return self._train_step(plan, lr, eps, out_pred, process_group, adam, mark, fused, next_plan)

@@ -209,10 +209,8 @@ class BatchPlan:
         dev = x.device
         lib = _lib.load()
         want_w = inv_occ is not None and y is not None
-        if want_w:
-            # (a build on a side stream: its buffers come from THAT stream's pool -- see _build_index_locked)
-            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-                self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
+        if want_w and not (build_index and y is not None):
+            self.W = torch.empty(spec.F, dtype=torch.float64, device=dev)
         if build_index and y is not None:
             # the batch normalisers W (vfm-torch.py:305-306) come out of the index build's own launches (the ids are read once)
             self.build_index(validate=validate, defer=defer_readback, inv_occ=inv_occ if want_w else None, stream=stream)
@@ -255,7 +253,9 @@ class BatchPlan:
         cap_h, cap_i = n // L + 1, 2 * n // L + 2
         # ONE device allocation per plan, carved into the index's arrays (seven allocations per plan made the first
         # build of a training set's plans twice as long as the kernels themselves); the views are made when first asked for
-        sizes = (spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 8, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0)
+        # (the last piece: W [F] fp64, when the build makes the normalisers -- one allocation, one stream to record)
+        sizes = (spec.T + 1, max(n, 1), cap_h, 4 * cap_i, 8, max(min(n, spec.T), 1), max(n, 1) if spec.F == 2 else 0,
+                 2 * spec.F if inv_occ is not None else 0)
         offs, o = [], 0
         for v in sizes:
             offs.append(o)
@@ -269,6 +269,8 @@ class BatchPlan:
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev)
         self._lay = (offs, sizes, cap_i)
+        if inv_occ is not None:
+            self.W = arena[offs[7]: offs[7] + 2 * spec.F].view(torch.float64)
         base = arena.data_ptr()
         P = [C.c_void_p(base + 4 * q) for q in offs]
         host = _pinned_ints(8)
@@ -437,9 +439,8 @@ class BatchPlan:
         if raw != src.cuda_stream:
             cur = _stream_obj(dev, raw)
             cur.wait_event(ev)
-            for t in (self._arena, self.W):
-                if t is not None:
-                    t.record_stream(cur)      # (allocated on the build's stream, used on this one from here on)
+            if self._arena is not None:
+                self._arena.record_stream(cur)      # (allocated on the build's stream, used on this one from here on; W is a piece of it)
         self._ready = None
 
     def check_status(self):
