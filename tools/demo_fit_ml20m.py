@@ -36,7 +36,8 @@ for kv in os.environ.get("VFM_SET", "").split(","):        # e.g. VFM_SET=pipeli
         setattr(m, key, {"True": True, "False": False}.get(val, float(val) if val.replace(".", "").isdigit() else val))
 t0 = time.perf_counter()
 hist = m.fit(X[:ntr], y[:ntr], n_epochs=int(os.environ.get("EPOCHS", "6")), batch_size=100000,
-             X_test=X[ntr:], y_test=y[ntr:], display_every=1, verbose=True)
+             X_test=X[ntr:], y_test=y[ntr:], display_every=1, verbose=True,
+             stream_plans=bool(os.environ.get("STREAM_PLANS")))      # STREAM_PLANS=1: no plan kept, every batch's built inside the loop
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"fit: {len(hist['epoch'])} epochs of {ntr} triples in {dt:.2f} s (incl. plan building, per-epoch "

@@ -117,6 +117,23 @@ def _index_workspace(n_int32: int, dev, stream: int) -> torch.Tensor:
     return t
 
 
+_ARENAS = {}
+
+
+def _side_arena(dev, stream, numel: int) -> torch.Tensor:
+    """An uninitialised int32 buffer from the allocator pool of `stream` (a side stream of plan builds).  Eight at a time:
+    entering and leaving a stream context costs the host ~25 us, once per plan it was a third of the streamed loop's
+    enqueue time; the buffers of one (stream, size) wait here until a build takes them (sizes repeat: B, F, T fix them)."""
+    key = (dev.index, stream.cuda_stream, numel)
+    stash = _ARENAS.get(key)
+    if not stash:
+        if len(_ARENAS) > 8:             # (batches of many different sizes: drop the other stashes)
+            _ARENAS.clear()
+        with torch.cuda.stream(stream):
+            stash = _ARENAS[key] = [torch.empty(numel, dtype=torch.int32, device=dev) for _ in range(8)]
+    return stash.pop()
+
+
 _STREAMS = {}
 
 
@@ -266,8 +283,7 @@ class BatchPlan:
         # tests/test_gpu_full_size.py::test_cfg3_plans_built_inside_the_loop_follow_the_resident_plans_run: losses drifting
         # from the 10th step on, equal with a device sync before every step.)  The consumer's stream is recorded when the plan
         # is first used there (use_on_current), so the block is not handed out again under ITS queued work either.
-        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-            arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev)
+        arena = self._arena = torch.empty(o, dtype=torch.int32, device=dev) if stream is None else _side_arena(dev, stream, o)
         self._lay = (offs, sizes, cap_i)
         if inv_occ is not None:
             self.W = arena[offs[7]: offs[7] + 2 * spec.F].view(torch.float64)
