@@ -481,14 +481,27 @@ def main():
     # ---- N = 1: figures next to the commanded region: `sustained` = the same steps over a long region without events;
     # `streamed` = the regime in which no plan is kept (every step's plan built inside the timed region, a few steps ahead on a
     # side stream) -- with the GPU time of one plan build, measured alone, beside it
+    # (the auxiliary regions run AFTER the commanded one and must not cost the line: a Python error in one of them is
+    #  reported in its key and on stderr, and the run goes on)
     sustained = streamed = None
-    if not multi and args.sustained_steps > 0:
+
+    def aux(name, fn):
+        try:
+            return fn()
+        except Exception as exc:
+            print("[bench] %s region failed: %s: %s" % (name, type(exc).__name__, str(exc)[:300]), file=sys.stderr)
+            return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+
+    def sustained_region():
         setup.activate()
         m = measure(setup, "single", args.sustained_steps, 4, with_events=False)
-        sustained = {"steps": args.sustained_steps, "ms_per_step": round(m["dt"] / args.sustained_steps * 1e3, 4),
-                     "triples_per_s": round(args.sustained_steps * B / m["dt"], 1),
-                     "host_enqueue_ms_per_step": round(m["t_host"] / args.sustained_steps * 1e3, 4)}
-    if not multi and args.streamed_steps > 0 and not args.unfused and eps_tables is None:
+        return {"steps": args.sustained_steps, "ms_per_step": round(m["dt"] / args.sustained_steps * 1e3, 4),
+                "triples_per_s": round(args.sustained_steps * B / m["dt"], 1),
+                "host_enqueue_ms_per_step": round(m["t_host"] / args.sustained_steps * 1e3, 4)}
+    if not multi and args.sustained_steps > 0:
+        sustained = aux("sustained", sustained_region)
+
+    def streamed_region():
         setup.activate()
         m = measure(setup, "single", args.streamed_steps, nbt + 4, with_events=False, streamed=True)
         # one plan build (index + normalisers) alone on the chip: HIP events around builds enqueued back to back on the current
@@ -500,14 +513,16 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         del keep_
-        streamed = {"steps": args.streamed_steps, "ms_per_step": round(m["dt"] / args.streamed_steps * 1e3, 4),
-                    "triples_per_s": round(args.streamed_steps * B / m["dt"], 1),
-                    "host_enqueue_ms_per_step": round(m["t_host"] / args.streamed_steps * 1e3, 4),
-                    "plan_build_gpu_us_alone": round(e0.elapsed_time(e1) / nbt * 1e3, 2),
-                    "prefetch_depth": int(model.plan_prefetch_depth),
-                    "note": "every step builds the plan of the batch `prefetch_depth` steps ahead (inverted index + batch normalisers; the look-ahead "
-                            "kernel classifies the table rows itself) on a side stream inside the timed region; nothing of a plan is reused; "
-                            "plan_build_gpu_us_alone = max(GPU time, host enqueue time) of one build with nothing beside it"}
+        return {"steps": args.streamed_steps, "ms_per_step": round(m["dt"] / args.streamed_steps * 1e3, 4),
+                "triples_per_s": round(args.streamed_steps * B / m["dt"], 1),
+                "host_enqueue_ms_per_step": round(m["t_host"] / args.streamed_steps * 1e3, 4),
+                "plan_build_gpu_us_alone": round(e0.elapsed_time(e1) / nbt * 1e3, 2),
+                "prefetch_depth": int(model.plan_prefetch_depth), "step_lead": int(model.step_lead),
+                "note": "every step builds the plan of the batch `prefetch_depth` steps ahead (inverted index + batch normalisers; the look-ahead "
+                        "kernel classifies the table rows itself) on a side stream inside the timed region; nothing of a plan is reused; "
+                        "plan_build_gpu_us_alone = max(GPU time, host enqueue time) of one build with nothing beside it"}
+    if not multi and args.streamed_steps > 0 and not args.unfused and eps_tables is None:
+        streamed = aux("streamed", streamed_region)
     if not multi and events is None and not args.no_events:
         # (--plans stream: the headline region carries no per-kernel events) per-kernel durations from a resident-plans pass
         m = measure(setup, "single", min(100, args.steps), 4, with_events=True)
@@ -524,7 +539,8 @@ def main():
     # full step.  The timed step fuses the backward with Adam, so K comes from a short run of the UNFUSED step
     # (separate k_bwd writing the dense gradient, then k_adam) after the timed region.
     regions = None
-    if not multi and kern and not args.unfused and not args.no_regions:
+
+    def regions_region():
         ev2 = []
         for s_ in range(5):
             model.train_step(plans[s_ % nbt], fused=False, eps=eps_tables)
@@ -546,7 +562,7 @@ def main():
                 per[b_].append(ev[a_].elapsed_time(ev[b_]))
         un = {k: sorted(v)[len(v) // 2] * 1e3 for k, v in per.items()}        # medians (one-off stalls do not count)
         K_us = un["fwd"] + un["finalize"] + un["bwd"]
-        regions = {"F_us": kern["fwd"]["avg_us"], "K_us": round(K_us, 2),
+        regions_ = {"F_us": kern["fwd"]["avg_us"], "K_us": round(K_us, 2),
                    "S_us": round(dt / args.steps * 1e6, 2),
                    "K_triples_per_s": round(B / (K_us * 1e-6), 1),
                    "unfused_step_us": {k: round(v, 2) for k, v in un.items()},
@@ -562,11 +578,14 @@ def main():
             roof["frac_K_8d"] = round(b_K / (K_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             roof["bytes_fwd_8d"], roof["bytes_K_8d"] = int(b_fwd), int(b_K)
             roof["target_8d"] = 0.60
+        return regions_
+    if not multi and kern and not args.unfused and not args.no_regions:
+        regions = aux("regions", regions_region)
 
     # ---- CPU baseline (rank 0, N=1): reference-shaped restatement on the host cores
     cpu = None
     if rank == 0 and not multi and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sizes, d, B, nb_train, output, plans[0], setup.occ, args.cpu_seconds)
+        cpu = aux("cpu_baseline", lambda: cpu_baseline(sizes, d, B, nb_train, output, plans[0], setup.occ, args.cpu_seconds))
 
     if rank == 0:
         def line_of(m, reg):
@@ -627,7 +646,7 @@ def main():
                        f"table rows on every rank), one all-reduce per step"},
             "roofline": roof, "kernels": kern, "kernel_events_on_every_nth_step": max(1, args.event_every), "regions": regions,
             "sustained": sustained, "streamed": streamed,
-            "ms_per_step_streamed": streamed["ms_per_step"] if streamed else None,
+            "ms_per_step_streamed": streamed.get("ms_per_step") if streamed else None,
             "settle": None if not head.get("cold") else {
                 "untimed_steps_before_warmup": head["cold"]["settle_steps"],
                 "cold_ms_per_step": round(head["cold"]["ms_per_step"], 4), "cold_steps": head["cold"]["steps"],
