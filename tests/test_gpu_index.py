@@ -39,6 +39,7 @@ CASES = [  # (B, field sizes, zipf exponent or None, id dtype)
     (3000, [200, 300], 1.2, torch.int64),           # 9-bit keys: ONE radix pass (the first pass is the last)
     (5000, [1024, 1024], None, torch.int32),        # T a multiple of the compaction chunk: occ_ptr[T] has no thread of its own
     (70000, [2, 3], None, torch.int64),             # 3-bit keys, 69 sort tiles in three tile groups, five enormous lists
+    (1048576, [138493, 26744], None, torch.int64),  # the bench's largest batch: 1,024 sort tiles in 32 groups, 646 compaction chunks
 ]
 
 
