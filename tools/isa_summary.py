@@ -21,6 +21,7 @@ WANT = [
     ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<32, 1, 4, 0, 1, 0, 0, false, true, true>", "pipelined step's backward in the look-ahead form (data-file-order batches; the rows exchange)"),
     ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd_small<8, 0>", "cfg2 one-launch backward + dense Adam (a wave per table row; the 48 bytes of scratch are the epilogue's eps chunk select, once per row)"),
     ("vfm_bwd.hip", ["-ffp-contract=on", "-DVFM_BWD_PART=1"], "k_bwd<32, 1, 4, 0, 1, 2, 0, false, false, false>", "multi-rank apply stage (epilogue + Adam from the summed statistics)"),
+    ("vfm_abi.hip", ["-ffp-contract=on"], "k_heavy<32, 1, 4>", "pre-reduction of the long lists' work items (eight occurrences in flight, the next eight's row numbers fetched under them)"),
     ("vfm_index.hip", [], "k_index_keys", "index build: ids -> keys, first digit counts, batch normalisers"),
     ("vfm_index.hip", [], "k_radix_scatter<true>", "index build: last radix pass (writes occ_rows / occ_other)"),
     ("vfm_index.hip", [], "k_index_count<true>", "index build: occ_ptr by LDS-staged lower bounds + per-chunk counts (256-thread workgroups)"),
